@@ -1,0 +1,171 @@
+/* liblsa_hip.so -- C-ABI of the MI355X-native shift-invert eigen path for LSA-FW.
+ *
+ * The reference (ferdean/lsa-fw) has no native code of its own: the hot path is one Python call,
+ *     Solver/eigen.py:136  ->  Solver/utils.py:270  ->  SLEPc.EPS.solve()
+ * and every numeric step runs inside petsc4py/slepc4py.  This header is therefore the interface a
+ * maintainer binds *instead of* slepc4py for that path (ctypes stub: INTEGRATION.md).  Each entry point
+ * names the petsc4py/slepc4py call site in the reference it stands in for.
+ *
+ * Conventions
+ *   - every function returns an int status: LSA_OK (0) or a negative lsa_status; no exception and no HIP
+ *     error crosses the boundary; lsa_last_error(ctx) gives the text of the last failure;
+ *   - host buffers are owned by the caller and only read/written during the call; device memory is owned
+ *     by the library behind opaque handles and released by the matching *_destroy;
+ *   - complex values are interleaved (re, im) doubles; CSR uses int32 row pointers / column indices,
+ *     columns sorted inside each row, explicit zeros allowed, a structurally present diagonal is required
+ *     for factorisation;
+ *   - a context is bound to one GPU and one HIP stream and is not thread-safe.
+ */
+#ifndef LSA_HIP_H
+#define LSA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { LSA_F64 = 0, LSA_C128 = 1 } lsa_dtype;
+
+typedef enum {
+    LSA_OK = 0,
+    LSA_ERR_ARG = -1,        /* bad argument / shape / dtype            -> Python ValueError  (Solver/eigen.py:79-87) */
+    LSA_ERR_HIP = -2,        /* HIP runtime failure (OOM, launch, ...)  -> RuntimeError                                 */
+    LSA_ERR_ZERO_PIVOT = -3, /* factorisation hit a zero pivot          -> RuntimeError (tests/unit/Solver/test_eigen.py:272-281) */
+    LSA_ERR_DIVERGED = -4,   /* inner solve did not reach rtol          -> RuntimeError (Solver/eigen2.py:179-181) */
+    LSA_ERR_NONFINITE = -5,  /* NaN/Inf produced                        -> RuntimeError (Solver/eigen2.py:186-189) */
+    LSA_ERR_TIMEOUT = -6,    /* a bounded device-side wait expired      -> RuntimeError                                 */
+    LSA_ERR_COMM = -7        /* RCCL failure                            -> RuntimeError                                 */
+} lsa_status;
+
+typedef struct lsa_ctx lsa_ctx;
+typedef struct lsa_mat lsa_mat;   /* CSR matrix on the device             (PETSc.Mat AIJ, FEM/utils.py:104)  */
+typedef struct lsa_vec lsa_vec;   /* dense vector on the device           (PETSc.Vec,      FEM/utils.py:662)  */
+typedef struct lsa_ilu lsa_ilu;   /* ILU(k) factors + triangular schedule (PETSc.PC ILU,   Solver/utils.py:261-266) */
+typedef struct lsa_op lsa_op;     /* shift-invert operator (C^-1 M)       (SLEPc.ST SINVERT, Solver/utils.py:256-259) */
+typedef struct lsa_krylov lsa_krylov; /* Arnoldi basis + recurrences      (SLEPc.BV + EPS Krylov-Schur, Solver/utils.py:270) */
+
+/* counters filled by the solvers (all cumulative since creation of the object they belong to) */
+typedef struct {
+    int64_t op_applies;      /* shift-invert applies (outer Arnoldi steps)           */
+    int64_t gmres_iters;     /* inner GMRES iterations                                */
+    int64_t spmv_calls;      /* SpMV launches                                         */
+    int64_t sptrsv_calls;    /* triangular-solve launches (L and U counted apart)     */
+    double last_rel_res;     /* relative residual estimate of the last inner solve    */
+    double max_rel_res;      /* worst one seen                                        */
+    double seconds_factor;   /* wall seconds spent in symbolic + numeric factorisation */
+    double seconds_solve;    /* wall seconds spent inside lsa_op_apply / lsa_krylov_extend */
+} lsa_stats;
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int lsa_ctx_create(int device, lsa_ctx **out);
+void lsa_ctx_destroy(lsa_ctx *ctx);
+const char *lsa_last_error(const lsa_ctx *ctx);
+int lsa_ctx_synchronize(lsa_ctx *ctx);
+/* name of the GPU architecture the context runs on, e.g. "gfx950" */
+const char *lsa_ctx_arch(const lsa_ctx *ctx);
+
+/* ---- vectors ------------------------------------------------------------------------------------ */
+int lsa_vec_create(lsa_ctx *ctx, int64_t n, int dtype, lsa_vec **out);
+void lsa_vec_destroy(lsa_vec *v);
+int lsa_vec_upload(lsa_ctx *ctx, lsa_vec *v, const void *host);
+int lsa_vec_download(lsa_ctx *ctx, const lsa_vec *v, void *host);
+
+/* ---- CSR matrices: iPETScMatrix.from_matrix / as_scipy_array (FEM/utils.py:183-220,585-588) -------- */
+int lsa_csr_upload(lsa_ctx *ctx, int32_t n, int64_t nnz, const int32_t *rowptr, const int32_t *col,
+                   const void *val, int dtype, lsa_mat **out);
+void lsa_mat_destroy(lsa_mat *m);
+int lsa_mat_download_values(lsa_ctx *ctx, const lsa_mat *m, void *host_val);
+/* C = alpha*A + beta*B on one shared sparsity pattern: MatDuplicate + MatAXPY of ST sinvert
+ * (explicit in Solver/eigen2.py:110-111).  alpha/beta are (re, im); out_dtype LSA_F64 needs real inputs
+ * and zero imaginary parts.  The result shares A's index arrays. */
+int lsa_csr_axpby(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *B, const double alpha[2], const double beta[2],
+                  int out_dtype, lsa_mat **out);
+/* y = A x: MatMult (Solver/eigen2.py:174).  Real matrix with complex vectors is supported. */
+int lsa_spmv(lsa_ctx *ctx, const lsa_mat *A, const lsa_vec *x, lsa_vec *y);
+/* y = A^T x or A^H x (conj != 0) without forming the transpose: the adjoint eigenproblem of
+ * Sensitivity/__init__.py:47-57,247-248 */
+int lsa_spmv_transpose(lsa_ctx *ctx, const lsa_mat *A, int conj, const lsa_vec *x, lsa_vec *y);
+/* Launch y = A x `iters` times back to back on the context's stream, bracketed by HIP events on that
+ * stream; *avg_ms = mean duration of one launch.  This is the measurement bench.py's roofline uses. */
+int lsa_spmv_time(lsa_ctx *ctx, const lsa_mat *A, const lsa_vec *x, lsa_vec *y, int iters, double *avg_ms);
+
+/* ---- ILU(k): PC ILU of the ST's KSP (Solver/utils.py:261-266, PreconditionerType.ILU) ------------ */
+/* levels = level of fill (0 = ILU(0)); pivots with |u_ii| < shift_tol are replaced by shift_tol*sign
+ * (PETSc -pc_factor_shift_type nonzero); shift_tol = 0 makes a zero pivot an error.  Symbolic analysis
+ * and the dependency schedule are computed on the host, the numeric factorisation on the device. */
+int lsa_ilu_create(lsa_ctx *ctx, const lsa_mat *C, int levels, double shift_tol, lsa_ilu **out);
+void lsa_ilu_destroy(lsa_ilu *pc);
+/* which: 0 = x = L^-1 b (unit lower), 1 = x = U^-1 b, 2 = x = U^-1 L^-1 b (MatSolve) */
+int lsa_ilu_solve(lsa_ctx *ctx, lsa_ilu *pc, int which, const lsa_vec *b, lsa_vec *x);
+/* introspection for tests: nnz of the factor pattern, number of dependency levels (lower, upper),
+ * number of shifted pivots */
+int lsa_ilu_info(const lsa_ilu *pc, int64_t *nnz, int32_t *levels_lower, int32_t *levels_upper, int32_t *nshift);
+/* copy the factor out (CSR, L strictly below the diagonal with unit diagonal implied, U on and above) */
+int lsa_ilu_download(lsa_ctx *ctx, const lsa_ilu *pc, int32_t *rowptr, int32_t *col, void *val);
+
+/* ---- GMRES: KSPSolve of the ST (reference default PREONLY+LU; north star: GMRES+ILU) ----------------- */
+/* right-preconditioned restarted GMRES with CGS2; pc may be NULL.  x holds the initial guess on entry
+ * when use_x0 != 0.  Returns LSA_ERR_DIVERGED if rtol is not reached within maxit iterations. */
+int lsa_gmres(lsa_ctx *ctx, const lsa_mat *C, lsa_ilu *pc, const lsa_vec *b, lsa_vec *x, int use_x0, double rtol,
+              int restart, int maxit, int32_t *iters, double *rel_res);
+
+/* ---- shift-invert operator: ST SINVERT (Solver/utils.py:244-266; Solver/eigen2.py:109-201) ---------- */
+typedef struct {
+    int32_t ilu_levels;   /* level of fill of the preconditioner (default 0)                  */
+    double ilu_shift;     /* pivot shift tolerance (0 = zero pivot is an error)              */
+    double ksp_rtol;      /* inner GMRES relative tolerance                                  */
+    int32_t ksp_restart;  /* GMRES restart length                                            */
+    int32_t ksp_maxit;    /* GMRES iteration cap                                             */
+    int32_t pc_type;      /* 0 = none, 1 = ILU(k)                                            */
+} lsa_op_options;
+
+/* Builds C = A - sigma*M (complex if sigma has an imaginary part or A/M are complex), factors it, and
+ * allocates the inner-solver workspace.  M may be NULL (standard problem, M = I).
+ * mode: 0 = shift-invert  y = (A - sigma M)^-1 M x     (iSTType.SINVERT)
+ *       1 = shift         y = M^-1 (A - sigma M) x     (iSTType.SHIFT; needs M = NULL here, then y = (A - sigma I) x) */
+int lsa_op_create(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, const double sigma[2], int mode,
+                  const lsa_op_options *opts, lsa_op **out);
+void lsa_op_destroy(lsa_op *op);
+int lsa_op_apply(lsa_ctx *ctx, lsa_op *op, const lsa_vec *x, lsa_vec *y);
+int lsa_op_stats(const lsa_op *op, lsa_stats *out);
+
+/* ---- Krylov basis: BV + Arnoldi recurrences of EPS Krylov-Schur (SLEPc.EPS.solve, Solver/utils.py:270) -- */
+/* Basis of up to ncv+1 complex vectors of length n, resident in HBM, column-major. */
+int lsa_krylov_create(lsa_ctx *ctx, lsa_op *op, int32_t ncv, lsa_krylov **out);
+void lsa_krylov_destroy(lsa_krylov *k);
+/* v_0 = v / ||v||  (host complex vector of length n) */
+int lsa_krylov_set_start(lsa_ctx *ctx, lsa_krylov *k, const void *host_v);
+/* v_j = host vector orthonormalised (CGS2) against v_0..v_{j-1}: used to continue after an exact breakdown
+ * (invariant subspace found, e.g. repeated eigenvalues) with a fresh direction; j = 0 equals set_start. */
+int lsa_krylov_inject(lsa_ctx *ctx, lsa_krylov *k, int32_t j, const void *host_v);
+/* Arnoldi steps j = j0 .. j1-1:  w = OP v_j;  CGS2 against v_0..v_j;  v_{j+1} = w/||w||.
+ * H is the caller's (ncv+1) x ncv column-major complex Hessenberg; columns j0..j1-1 are written.
+ * Returns LSA_OK and *breakdown = step index if ||w|| underflowed (invariant subspace), else -1. */
+int lsa_krylov_extend(lsa_ctx *ctx, lsa_krylov *k, int32_t j0, int32_t j1, void *H, int32_t ldh, int32_t *breakdown);
+/* Krylov-Schur truncation: V[:, 0:knew] = V[:, 0:m] Q (Q is m x knew column-major complex on the host)
+ * and V[:, knew] = V[:, m]. */
+int lsa_krylov_restart(lsa_ctx *ctx, lsa_krylov *k, int32_t m, int32_t knew, const void *Q, int32_t ldq);
+/* X = V[:, 0:m] Y, Y m x nvec on the host; X (n x nvec column-major complex) is written to the host,
+ * each column normalised to unit 2-norm when normalise != 0 (SLEPc convention, Solver/utils.py:309). */
+int lsa_krylov_ritz_vectors(lsa_ctx *ctx, lsa_krylov *k, int32_t m, int32_t nvec, const void *Y, int32_t ldy,
+                            int normalise, void *X);
+/* residual check of Solver/eigen2.py:48-56 on the device:
+ * res[i] = ||A x_i - lam_i M x_i|| / (||A x_i|| + |lam_i| ||M x_i|| + 1e-16), X on the host (n x nvec). */
+int lsa_eig_residuals(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, int32_t nvec, const void *lam, const void *X,
+                      double *res);
+
+/* ---- multi-GPU (one process per GPU; rows of C, M and the factors are sharded, the basis replicated) ---- */
+/* RCCL bootstrap: rank 0 calls lsa_comm_unique_id, the launcher broadcasts the 128 bytes (e.g. with
+ * torch.distributed), every rank then calls lsa_comm_init. */
+int lsa_comm_unique_id(void *id128);
+int lsa_comm_init(lsa_ctx *ctx, int nranks, int rank, const void *id128);
+/* Row-block shard of a global CSR: this rank owns rows [row0, row1); x and y of lsa_spmv stay global-length
+ * and replicated, each rank computes its rows and the blocks are exchanged with ncclAllGather. */
+int lsa_csr_upload_shard(lsa_ctx *ctx, int32_t n_global, int32_t row0, int32_t row1, int64_t nnz_local,
+                         const int32_t *rowptr_local, const int32_t *col, const void *val, int dtype, lsa_mat **out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSA_HIP_H */

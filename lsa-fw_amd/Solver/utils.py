@@ -1,0 +1,485 @@
+"""Drop-in for the EPS half of ``/root/reference/Solver/utils.py`` on MI355X.
+
+Same names, argument meaning and error behaviour as the reference wrapper over ``SLEPc.EPS``
+(``Solver/utils.py:27-328``); the arithmetic runs in ``liblsa_hip.so`` (HIP kernels) instead of SLEPc/PETSc:
+
+============================  ======================================================================================
+reference (slepc4py)          here
+============================  ======================================================================================
+``EPS`` Krylov-Schur          ``lsa_hip.krylov_schur`` (host logic) over ``lsa_hip.KrylovBasis`` (device basis, CGS2)
+``ST`` SINVERT / SHIFT        ``lsa_hip.ShiftInvertOperator`` (C = A - sigma M built on the device)
+``KSP`` of the ST             device GMRES (right-preconditioned, CGS2)
+``PC`` ILU / LU               device ILU(k) + sync-free SpTRSV; LU/CHOLESKY map to a higher fill level
+``BV`` / ``DS``               HIP tall-skinny kernels / LAPACK on the ncv x ncv Hessenberg
+============================  ======================================================================================
+
+There is no CPU fallback: ``solve()`` raises if the HIP library or a GPU is missing.
+"""
+
+from __future__ import annotations
+
+import logging
+from enum import Enum
+from typing import Iterator
+
+import numpy as np
+import scipy.sparse as sp
+
+from FEM.utils import iComplexPETScVector, iPETScMatrix, iPETScVector
+
+logger = logging.getLogger(__name__)
+
+Scalar = complex
+"""Scalar type of the solver. The HIP path always iterates in complex128 (the reference targets are complex,
+``.examples/eigenvalues.py:37-49``), so the reference's real/complex *build* switch does not exist here."""
+
+
+class _LowerStrEnum(str, Enum):
+    """``enum.StrEnum`` + ``auto()`` semantics of the reference (members compare equal to their lower-case name)."""
+
+    def __str__(self) -> str:
+        return str(self.value)
+
+
+class iEpsProblemType(Enum):
+    """EPS problem types (``Solver/utils.py:27-63``); values follow SLEPc's ``EPSProblemType`` numbering."""
+
+    HEP = 1
+    GHEP = 2
+    NHEP = 3
+    GNHEP = 4
+    PGNHEP = 5
+    GHIEP = 6
+
+    def to_slepc(self) -> int:
+        return self.value
+
+    @classmethod
+    def from_slepc(cls, problem_type) -> "iEpsProblemType":
+        try:
+            return cls(problem_type) if not hasattr(problem_type, "name") else cls[problem_type.name]
+        except (KeyError, ValueError):
+            raise ValueError(f"Unsupported SLEPc EPS ProblemType: {problem_type}")
+
+    @classmethod
+    def from_string(cls, name: str) -> "iEpsProblemType":
+        try:
+            return cls[name.upper()]
+        except KeyError:
+            raise ValueError(f"Invalid problem type: {name}. Choose from {list(cls.__members__.keys())}.")
+
+
+class PreconditionerType(_LowerStrEnum):
+    """Preconditioner names accepted by ``set_st_pc_type`` (``Solver/utils.py:66-93``)."""
+
+    NONE = "none"
+    JACOBI = "jacobi"
+    SOR = "sor"
+    ASM = "asm"
+    ILU = "ilu"
+    ICC = "icc"
+    LU = "lu"
+    CHOLESKY = "cholesky"
+    GAMG = "gamg"
+    HYPRE = "hypre"
+    REDUNDANT = "redundant"
+    SHELL = "shell"
+
+
+class KSPType(_LowerStrEnum):
+    """KSP names (``Solver/utils.py:96-128``)."""
+
+    CG = "cg"
+    GMRES = "gmres"
+    BICG = "bicg"
+    BICGSTAB = "bicgstab"
+    RICHARDSON = "richardson"
+    CHEBYSHEV = "chebyshev"
+    PREONLY = "preonly"
+    QCG = "qcg"
+    CGS = "cgs"
+    GCR = "gcr"
+    LSQR = "lsqr"
+    LGMRES = "lgmres"
+    FGMRES = "fgmres"
+
+    def to_petsc(self) -> str:
+        return self.name.lower()
+
+
+class iSTType(Enum):
+    """Spectral transformations (``Solver/utils.py:131-149``)."""
+
+    SHELL = "shell"
+    SHIFT = "shift"
+    SINVERT = "sinvert"
+    CAYLEY = "cayley"
+    PRECOND = "precond"
+    FILTER = "filter"
+
+    def to_slepc(self) -> str:
+        return self.value
+
+
+class iEpsWhich(Enum):
+    """Which eigenpairs (``Solver/utils.py:152-187``). SMALLEST_MAGNITUDE is an alias of LARGEST_REAL there
+    (``:157``) and therefore here."""
+
+    ALL = 10
+    LARGEST_MAGNITUDE = 1
+    LARGEST_REAL = 3
+    SMALLEST_MAGNITUDE = 3
+    SMALLEST_REAL = 4
+    LARGEST_IMAGINARY = 5
+    SMALLEST_IMAGINARY = 6
+    TARGET_MAGNITUDE = 7
+    TARGET_REAL = 8
+    TARGET_IMAGINARY = 9
+    USER = 11
+
+    def to_slepc(self) -> int:
+        return self.value
+
+    def to_arpack(self) -> str:
+        table = {
+            iEpsWhich.LARGEST_REAL: "LR",
+            iEpsWhich.LARGEST_IMAGINARY: "LI",
+            iEpsWhich.SMALLEST_REAL: "SR",
+            iEpsWhich.SMALLEST_IMAGINARY: "SI",
+            iEpsWhich.LARGEST_MAGNITUDE: "LM_abs",
+        }
+        if self not in table:
+            raise ValueError(f"Unsupported type for ARPACK-based eigensolver: {self.name}.")
+        return table[self]
+
+
+def _lambda_rank_key(which: iEpsWhich, target: complex):
+    """Sort key on eigenvalues lambda (small = wanted), following SLEPc's EPSWhich semantics."""
+    keys = {
+        iEpsWhich.LARGEST_MAGNITUDE: lambda lam: -np.abs(lam),
+        iEpsWhich.LARGEST_REAL: lambda lam: -lam.real,
+        iEpsWhich.SMALLEST_REAL: lambda lam: lam.real,
+        iEpsWhich.LARGEST_IMAGINARY: lambda lam: -lam.imag,
+        iEpsWhich.SMALLEST_IMAGINARY: lambda lam: lam.imag,
+        iEpsWhich.TARGET_MAGNITUDE: lambda lam: np.abs(lam - target),
+        iEpsWhich.TARGET_REAL: lambda lam: np.abs(lam.real - target.real),
+        iEpsWhich.TARGET_IMAGINARY: lambda lam: np.abs(lam.imag - target.imag),
+    }
+    if which not in keys:
+        raise ValueError(f"which = {which.name} is not supported by the HIP eigensolver")
+    return keys[which]
+
+
+def pivot_safe_rcm(C: sp.csr_matrix) -> np.ndarray:
+    """Bandwidth-reducing symmetric permutation that keeps ILU pivots non-zero on saddle-point matrices.
+
+    Reverse Cuthill-McKee on the pattern (the analogue of PETSc's ``-pc_factor_mat_ordering_type rcm``), then every
+    row with a zero diagonal (the pressure rows: ``tests/unit/FEM/test_operators.py:209-210``) that RCM placed before
+    *all* rows it couples to is moved right behind the first of them, so its pivot receives fill.
+    """
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+    n = C.shape[0]
+    pattern = sp.csr_matrix((np.ones(C.nnz, dtype=np.int8), C.indices, C.indptr), shape=C.shape)
+    perm = np.asarray(reverse_cuthill_mckee(pattern, symmetric_mode=False), dtype=np.int64)
+    pos = np.empty(n, dtype=np.float64)
+    pos[perm] = np.arange(n)
+    zero_diag = np.flatnonzero(C.diagonal() == 0)
+    if zero_diag.size:
+        row_of = np.repeat(np.arange(n), np.diff(C.indptr))
+        coupled = (C.data != 0) & (C.indices != row_of)
+        nb_pos = np.where(coupled, pos[C.indices], np.inf)
+        lens = np.diff(C.indptr)
+        first = np.full(n, np.inf)
+        nz_rows = np.flatnonzero(lens > 0)
+        first[nz_rows] = np.minimum.reduceat(nb_pos, C.indptr[:-1][nz_rows])
+        late = zero_diag[(first[zero_diag] > pos[zero_diag]) & np.isfinite(first[zero_diag])]
+        key = pos.copy()
+        key[late] = first[late] + 0.5
+        perm = np.argsort(key, kind="stable")
+    return perm.astype(np.int64)
+
+
+class _RawPC:
+    def __init__(self, owner: "iEpsSolver"):
+        self._o = owner
+
+    def getType(self) -> str:
+        return self._o._pc_type.name.lower()
+
+
+class _RawKSP:
+    def __init__(self, owner: "iEpsSolver"):
+        self._o = owner
+
+    def getPC(self) -> _RawPC:
+        return _RawPC(self._o)
+
+    def getType(self) -> str:
+        return self._o._ksp_type.to_petsc()
+
+    def getIterationNumber(self) -> int:
+        return int(self._o._stats.get("gmres_iters", 0))
+
+
+class _RawST:
+    def __init__(self, owner: "iEpsSolver"):
+        self._o = owner
+
+    def getKSP(self) -> _RawKSP:
+        return _RawKSP(self._o)
+
+    def getType(self) -> str:
+        return self._o._st_type.to_slepc()
+
+    def getShift(self) -> complex:
+        return self._o._target
+
+
+class _RawEPS:
+    """The few ``SLEPc.EPS`` getters the reference's callers and tests poke through ``iEpsSolver.raw``
+    (``Solver/eigen.py:140-144``; ``tests/unit/Solver/test_eigen.py:97-104,320-322``)."""
+
+    def __init__(self, owner: "iEpsSolver"):
+        self._o = owner
+
+    def getTolerances(self) -> tuple[float, int]:
+        return self._o._tol, self._o._max_it
+
+    def getDimensions(self) -> tuple[int, int, int]:
+        return self._o._nev, self._o._ncv, self._o._ncv
+
+    def getProblemType(self) -> int:
+        return self._o._problem_type.to_slepc()
+
+    def getST(self) -> _RawST:
+        return _RawST(self._o)
+
+    def getConverged(self) -> int:
+        return self._o.get_num_converged()
+
+    def getIterationNumber(self) -> int:
+        return int(self._o._restarts)
+
+
+_HERMITIAN = {iEpsProblemType.HEP, iEpsProblemType.GHEP}
+
+
+class iEpsSolver:
+    """SLEPc-shaped eigensolver front end running on the HIP path (reference: ``Solver/utils.py:190-328``).
+
+    Build-only knobs (the reference leaves them to the PETSc options database) are keyword arguments:
+    ``ksp_type`` (inner Krylov method, GMRES), ``ksp_rtol``, ``restart``, ``ksp_max_it``, ``ilu_levels``,
+    ``ilu_shift``, ``device``.
+    """
+
+    def __init__(self, A=None, M=None, comm=None, *, device: int = 0, ksp_type: KSPType = KSPType.GMRES,
+                 ksp_rtol: float | None = None, restart: int = 200, ksp_max_it: int = 4000, ilu_levels: int | None = None,
+                 ilu_shift: float = 1e-12, ordering: str = "rcm", seed: int = 0) -> None:
+        if M is not None and A is None:
+            raise ValueError("Cannot set right-hand operator M without left-hand operator A.")
+        self._A = self._M = None
+        self._problem_type = iEpsProblemType.NHEP
+        self._nev, self._ncv = 1, None
+        self._tol, self._max_it = 1e-8, 100
+        self._which: iEpsWhich | None = None
+        self._target: complex = 0.0
+        self._interval = None
+        self._st_type = iSTType.SHIFT
+        self._pc_type = PreconditionerType.LU  # SLEPc's default for the ST's KSP is preonly + LU
+        self._ksp_type = ksp_type
+        self._ksp_rtol, self._restart_len, self._ksp_max_it = ksp_rtol, restart, ksp_max_it
+        self._ilu_levels, self._ilu_shift = ilu_levels, ilu_shift
+        self._ordering = ordering
+        self._device, self._seed = device, seed
+        self._eigenvalues = np.zeros(0, dtype=np.complex128)
+        self._eigenvectors = np.zeros((0, 0), dtype=np.complex128)
+        self._residual_estimates = np.zeros(0)
+        self._stats: dict = {}
+        self._restarts = 0
+        if A is not None:
+            self.set_operators(A, M)
+
+    # ---- configuration (same names as the reference) ----------------------------------------------------------------
+    @property
+    def raw(self) -> _RawEPS:
+        return _RawEPS(self)
+
+    def set_operators(self, A, M=None) -> None:
+        self._A = A if isinstance(A, iPETScMatrix) else iPETScMatrix.from_matrix(A)
+        self._M = None if M is None else M if isinstance(M, iPETScMatrix) else iPETScMatrix.from_matrix(M)
+
+    def set_problem_type(self, problem_type: iEpsProblemType) -> None:
+        self._problem_type = problem_type
+
+    def set_dimensions(self, number_eigenpairs: int, subspace_dimension: int | None = None) -> None:
+        self._nev = int(number_eigenpairs)
+        self._ncv = None if subspace_dimension is None else int(subspace_dimension)
+
+    def set_tolerances(self, atol: float, max_it: int) -> None:
+        self._tol, self._max_it = float(atol), int(max_it)
+
+    def set_which_eigenpairs(self, which: iEpsWhich) -> None:
+        self._which = which
+
+    def set_target(self, sigma: float | complex) -> None:
+        self._target = complex(Scalar(sigma))
+
+    def set_interval(self, a: float, b: float) -> None:
+        self._interval = (float(a), float(b), -np.inf, np.inf)
+
+    def set_interval_complex(self, a: float, b: float, c: float, d: float) -> None:
+        self._interval = (float(a), float(b), float(c), float(d))
+
+    def set_st_type(self, st_type: iSTType) -> None:
+        self._st_type = st_type
+
+    def set_st_pc_type(self, pc_type: PreconditionerType) -> None:
+        self._pc_type = PreconditionerType(pc_type)
+
+    # ---- solve ---------------------------------------------------------------------------------------------------------
+    def _fill_level(self) -> tuple[int, int]:
+        """(pc_type code, ILU fill level) for the requested PETSc PC name."""
+        if self._pc_type is PreconditionerType.NONE:
+            return 0, 0
+        if self._ilu_levels is not None:
+            return 1, int(self._ilu_levels)
+        if self._pc_type in (PreconditionerType.ILU, PreconditionerType.ICC):
+            return 1, 0  # PETSc's PCILU default: zero fill
+        # LU / CHOLESKY (exact solves in the reference) and every other name: stronger factors, tight GMRES
+        return 1, 2
+
+    def solve(self) -> None:
+        """Run the eigensolver on the GPU (reference: ``self._eps.solve()``, ``Solver/utils.py:268-270``)."""
+        import lsa_hip
+        from lsa_hip.krylov_schur import krylov_schur
+
+        if self._A is None:
+            raise ValueError("Operators are not set.")
+        if self._st_type not in (iSTType.SHIFT, iSTType.SINVERT):
+            raise NotImplementedError(f"Spectral transformation {self._st_type.name} is not available on the HIP path.")
+        A = self._A.as_scipy_array()
+        M = None if self._M is None else self._M.as_scipy_array()
+        n = A.shape[0]
+        ncv = min(self._ncv if self._ncv is not None else max(2 * self._nev, self._nev + 15), n)
+        nev = min(self._nev, ncv)
+        sinvert = self._st_type is iSTType.SINVERT
+        sigma = self._target if sinvert else 0.0
+        which = self._which or (iEpsWhich.TARGET_MAGNITUDE if sinvert else iEpsWhich.LARGEST_MAGNITUDE)
+        lam_key = _lambda_rank_key(which, self._target)
+
+        # one shared sparsity pattern for A and M (explicit zeros where only the other matrix has an entry)
+        if M is not None and (A.nnz != M.nnz or not (np.array_equal(A.indptr, M.indptr) and np.array_equal(A.indices, M.indices))):
+            ones = lambda X: sp.csr_matrix((np.ones(X.nnz), X.indices, X.indptr), shape=X.shape)  # noqa: E731
+            union = (ones(A) + ones(M)).tocsr()
+            union.sort_indices()
+            A, M = _onto_pattern(A, union), _onto_pattern(M, union)
+
+        # symmetric permutation for the factorisation; the whole iteration runs in permuted numbering
+        pc_code, levels = self._fill_level()
+        if sinvert:
+            K = _combine(A, M, sigma) if M is not None else A  # the matrix that gets factorised
+        else:
+            K = M
+        if self._ordering == "rcm" and n > 8 and pc_code == 1 and K is not None:
+            perm = pivot_safe_rcm(sp.csr_matrix(K))
+        else:
+            perm = np.arange(n)
+        Ap = _permute(A, perm)
+        Mp = None if M is None else _permute(M, perm)
+
+        ctx = lsa_hip.Context(self._device)
+        try:
+            dA = lsa_hip.CsrMatrix.from_scipy(ctx, Ap)
+            dM = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, Mp)
+            ksp_rtol = self._ksp_rtol if self._ksp_rtol is not None else float(np.clip(self._tol * 1e-2, 1e-13, 1e-8))
+            op = lsa_hip.ShiftInvertOperator(
+                ctx, dA, dM, sigma, mode=0 if sinvert else 1, ilu_levels=levels, ilu_shift=self._ilu_shift, ksp_rtol=ksp_rtol,
+                ksp_restart=min(self._restart_len, max(n, 1)), ksp_maxit=self._ksp_max_it, pc_type=pc_code,
+            )
+            basis = lsa_hip.KrylovBasis(ctx, op, ncv)
+            if sinvert:
+                theta_key = lambda th: lam_key(sigma + 1.0 / np.where(th == 0, np.finfo(float).tiny, th))  # noqa: E731
+            else:
+                theta_key = lambda th: lam_key(th + sigma)  # noqa: E731
+            res = krylov_schur(basis, nev, self._tol, self._max_it, theta_key, rng_seed=self._seed)
+            theta = res.theta
+            lam = sigma + 1.0 / theta if sinvert else theta + sigma
+            X = np.empty_like(res.vectors)
+            X[perm, :] = res.vectors
+            self._stats = op.stats()
+            self._stats["krylov_restarts"] = res.restarts
+        finally:
+            # handles hold device memory; drop them before the context
+            basis = op = dA = dM = None
+            import gc
+
+            gc.collect()
+            ctx.close()
+        order = np.argsort(lam_key(lam), kind="stable")
+        self._eigenvalues = lam[order]
+        self._eigenvectors = X[:, order]
+        self._residual_estimates = res.residuals[order]
+        self._restarts = res.restarts
+
+    # ---- results (same names as the reference) ---------------------------------------------------------------------------
+    def get_num_converged(self) -> int:
+        return int(self._eigenvalues.shape[0])
+
+    def get_eigenvalue(self, idx: int) -> float | complex:
+        lam = complex(self._eigenvalues[idx])
+        if self._problem_type in _HERMITIAN:
+            return float(lam.real)
+        return lam
+
+    def get_eigenvector(self, idx: int) -> iComplexPETScVector:
+        """Eigenvector ``idx`` with unit 2-norm; the imaginary part is dropped when its norm is <= 1e-6, as the
+        reference's real build does (``Solver/utils.py:280-291``)."""
+        v = self._eigenvectors[:, idx]
+        # fix the arbitrary complex phase so that a real eigenvector comes out real
+        k = int(np.argmax(np.abs(v)))
+        if v[k] != 0:
+            v = v * (np.abs(v[k]) / v[k])
+        if np.linalg.norm(v.imag) <= 1e-6:
+            return iComplexPETScVector(iPETScVector(v.real / np.linalg.norm(v.real)))
+        return iComplexPETScVector(iPETScVector(v.real), iPETScVector(v.imag))
+
+    def get_eigenpair(self, idx: int) -> tuple[float | complex, iComplexPETScVector]:
+        return self.get_eigenvalue(idx), self.get_eigenvector(idx)
+
+    def get_all_eigenpairs_up_to(self, num: int) -> Iterator[tuple[float | complex, iComplexPETScVector]]:
+        for i in range(min(self.get_num_converged(), num)):
+            yield self.get_eigenpair(i)
+
+    def get_eigenvector_array(self, idx: int) -> np.ndarray:
+        """Complex ndarray of eigenvector ``idx`` (convenience; not in the reference)."""
+        return self._eigenvectors[:, idx].copy()
+
+    @property
+    def stats(self) -> dict:
+        """Counters of the last solve (outer applies, inner iterations, kernel launches, factor/solve seconds)."""
+        return dict(self._stats)
+
+
+def _onto_pattern(A: sp.csr_matrix, pattern: sp.csr_matrix) -> sp.csr_matrix:
+    """A's values scattered onto ``pattern`` (a superset of A's pattern); missing entries become explicit zeros."""
+    n = A.shape[0]
+    key_new = np.repeat(np.arange(n, dtype=np.int64), np.diff(pattern.indptr)) * A.shape[1] + pattern.indices
+    key_old = np.repeat(np.arange(n, dtype=np.int64), np.diff(A.indptr)) * A.shape[1] + A.indices
+    data = np.zeros(pattern.nnz, dtype=A.dtype)
+    data[np.searchsorted(key_new, key_old)] = A.data
+    return sp.csr_matrix((data, pattern.indices.copy(), pattern.indptr.copy()), shape=A.shape)
+
+
+def _combine(A: sp.csr_matrix, M: sp.csr_matrix, sigma: complex) -> sp.csr_matrix:
+    """A - sigma M on the shared pattern (host copy, used only to look for zero diagonals)."""
+    return sp.csr_matrix((A.data - sigma * M.data, A.indices, A.indptr), shape=A.shape)
+
+
+def _permute(A: sp.csr_matrix, perm: np.ndarray) -> sp.csr_matrix:
+    if np.array_equal(perm, np.arange(A.shape[0])):
+        out = sp.csr_matrix(A)
+    else:
+        out = A[perm][:, perm].tocsr()
+    out.sort_indices()
+    return out

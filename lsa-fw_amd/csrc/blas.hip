@@ -1,0 +1,323 @@
+// Vector and tall-skinny kernels of the Krylov loops (BVOrthogonalize / VecNorm / VecAXPY of the reference's
+// SLEPc path).  All are HBM-bound streams over n-long columns: reductions are two-stage (per-block partials in
+// a fixed order, then one small finishing kernel) so results are bitwise reproducible run to run and identical
+// on every GPU that holds a replica of the basis.
+#include "lsa_internal.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kColTile = 8;  // basis columns handled per block in the multi-dot
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v);
+template <>
+__device__ __forceinline__ double wave_sum<double>(double v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+template <>
+__device__ __forceinline__ cplx wave_sum<cplx>(cplx v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        v.re += __shfl_xor(v.re, m, 64);
+        v.im += __shfl_xor(v.im, m, 64);
+    }
+    return v;
+}
+
+// sum over the 256 threads of a block; result valid in thread 0
+template <typename T>
+__device__ __forceinline__ T block_sum(T v, T* smem /* >= 4 */) {
+    v = wave_sum<T>(v);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) smem[wave] = v;
+    __syncthreads();
+    T r = smem[0];
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) r = s_add(r, smem[w]);
+    return r;
+}
+
+template <typename T>
+__global__ void copy_kernel(int64_t n, const T* __restrict__ x, T* __restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = x[i];
+}
+
+template <typename T>
+__global__ void axpy_kernel(int64_t n, T alpha, const T* __restrict__ x, T* __restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T acc = y[i];
+        fma_acc(acc, alpha, x[i]);
+        y[i] = acc;
+    }
+}
+
+// partial[(c) * nchunks + chunk] = sum over the chunk's rows of conj(V[i,c]) w[i]
+template <typename T>
+__global__ __launch_bounds__(kThreads) void multi_dot_partial_kernel(int64_t n, int j, int64_t rows_per_block,
+                                                                     const T* __restrict__ V, int64_t ldv,
+                                                                     const T* __restrict__ w, T* __restrict__ partial,
+                                                                     int nchunks) {
+    __shared__ T smem[4];
+    const int chunk = blockIdx.x;
+    const int c0 = blockIdx.y * kColTile;
+    const int64_t r0 = (int64_t)chunk * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
+    T acc[kColTile];
+#pragma unroll
+    for (int c = 0; c < kColTile; ++c) acc[c] = scalar_traits<T>::zero();
+    const int nc = (j - c0 < kColTile) ? (j - c0) : kColTile;
+    if (nc == kColTile) {
+        for (int64_t i = r0 + threadIdx.x; i < r1; i += kThreads) {
+            const T wv = w[i];
+#pragma unroll
+            for (int c = 0; c < kColTile; ++c) fma_conj_acc(acc[c], V[i + (int64_t)(c0 + c) * ldv], wv);
+        }
+    } else {
+        for (int64_t i = r0 + threadIdx.x; i < r1; i += kThreads) {
+            const T wv = w[i];
+#pragma unroll
+            for (int c = 0; c < kColTile; ++c)
+                if (c < nc) fma_conj_acc(acc[c], V[i + (int64_t)(c0 + c) * ldv], wv);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < kColTile; ++c) {
+        T s = block_sum<T>(acc[c], smem);
+        if (threadIdx.x == 0 && c < nc) partial[(int64_t)(c0 + c) * nchunks + chunk] = s;
+    }
+}
+
+// h[c] = sum_chunk partial[c*nchunks + chunk]; one wave per column, fixed order
+template <typename T>
+__global__ __launch_bounds__(64) void multi_dot_finish_kernel(int j, const T* __restrict__ partial, int nchunks,
+                                                               T* __restrict__ h) {
+    const int c = blockIdx.x;
+    if (c >= j) return;
+    T acc = scalar_traits<T>::zero();
+    for (int k = threadIdx.x; k < nchunks; k += 64) acc = s_add(acc, partial[(int64_t)c * nchunks + k]);
+    acc = wave_sum<T>(acc);
+    if (threadIdx.x == 0) h[c] = acc;
+}
+
+// w -= V h ; optionally partial_nrm[block] = sum |w_i|^2 over the block's rows
+template <typename T>
+__global__ __launch_bounds__(kThreads) void multi_axpy_kernel(int64_t n, int j, const T* __restrict__ V, int64_t ldv,
+                                                              const T* __restrict__ h, T* __restrict__ w,
+                                                              double* __restrict__ partial_nrm) {
+    __shared__ double smem[4];
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    T* hs = (T*)dyn;
+    for (int c = threadIdx.x; c < j; c += kThreads) hs[c] = h[c];
+    __syncthreads();
+    double nrm = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T acc = scalar_traits<T>::zero();
+        int c = 0;
+        for (; c + 4 <= j; c += 4) {
+            const T v0 = V[i + (int64_t)c * ldv], v1 = V[i + (int64_t)(c + 1) * ldv];
+            const T v2 = V[i + (int64_t)(c + 2) * ldv], v3 = V[i + (int64_t)(c + 3) * ldv];
+            fma_acc(acc, hs[c], v0);
+            fma_acc(acc, hs[c + 1], v1);
+            fma_acc(acc, hs[c + 2], v2);
+            fma_acc(acc, hs[c + 3], v3);
+        }
+        for (; c < j; ++c) fma_acc(acc, hs[c], V[i + (int64_t)c * ldv]);
+        const T r = s_sub(w[i], acc);
+        w[i] = r;
+        nrm += s_abs2(r);
+    }
+    if (partial_nrm) {
+        double s = block_sum<double>(nrm, smem);
+        if (threadIdx.x == 0) partial_nrm[blockIdx.x] = s;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void nrm2_partial_kernel(int64_t n, const T* __restrict__ x,
+                                                                double* __restrict__ partial) {
+    __shared__ double smem[4];
+    double nrm = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) nrm += s_abs2(x[i]);
+    double s = block_sum<double>(nrm, smem);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+__global__ __launch_bounds__(64) void nrm2_finish_kernel(int nblocks, const double* __restrict__ partial,
+                                                          double* __restrict__ out) {
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < nblocks; k += 64) acc += partial[k];
+    acc = wave_sum<double>(acc);
+    if (threadIdx.x == 0) out[0] = acc;
+}
+
+template <typename T>
+__global__ void scale_inv_norm_kernel(int64_t n, const T* __restrict__ x, const double* __restrict__ nrm2,
+                                      T* __restrict__ y) {
+    const double s = 1.0 / sqrt(nrm2[0]);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = s_mul(s, x[i]);
+}
+
+template <typename T>
+__global__ void hess_column_kernel(int cnt, const T* __restrict__ h1, const T* __restrict__ h2,
+                                   const double* __restrict__ nrm2, T* __restrict__ hout) {
+    for (int c = threadIdx.x; c < cnt; c += blockDim.x) hout[c] = h2 ? s_add(h1[c], h2[c]) : h1[c];
+    if (threadIdx.x == 0) s_from(hout[cnt], sqrt(nrm2[0]), 0.0);
+}
+
+// Out[i, k0+t] = sum_c V[i, c] Q[c, k0+t], t < kOutTile
+constexpr int kOutTile = 4;
+template <typename T>
+__global__ __launch_bounds__(kThreads) void basis_gemm_kernel(int64_t n, int m, int k, const T* __restrict__ V, int64_t ldv,
+                                                              const T* __restrict__ Q, int ldq, T* __restrict__ Out,
+                                                              int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    T* qs = (T*)dyn;  // m x kOutTile, column-major
+    const int k0 = blockIdx.y * kOutTile;
+    const int nk = (k - k0 < kOutTile) ? (k - k0) : kOutTile;
+    for (int idx = threadIdx.x; idx < m * kOutTile; idx += kThreads) {
+        const int t = idx / m, c = idx % m;
+        qs[idx] = (t < nk) ? Q[c + (int64_t)(k0 + t) * ldq] : scalar_traits<T>::zero();
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T acc[kOutTile];
+#pragma unroll
+        for (int t = 0; t < kOutTile; ++t) acc[t] = scalar_traits<T>::zero();
+        for (int c = 0; c < m; ++c) {
+            const T v = V[i + (int64_t)c * ldv];
+#pragma unroll
+            for (int t = 0; t < kOutTile; ++t) fma_acc(acc[t], qs[c + t * m], v);
+        }
+#pragma unroll
+        for (int t = 0; t < kOutTile; ++t)
+            if (t < nk) Out[i + (int64_t)(k0 + t) * ldo] = acc[t];
+    }
+}
+
+inline int stream_blocks(lsa_ctx* ctx, int64_t n) {
+    int64_t want = (n + kThreads - 1) / kThreads;
+    int64_t cap = (int64_t)ctx->num_cu * 8;
+    return (int)(want < 1 ? 1 : (want > cap ? cap : want));
+}
+
+inline int check_launch(lsa_ctx* ctx, const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+    return LSA_OK;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, CALL)                 \
+    do {                                        \
+        if ((dtype) == LSA_C128) { using T = cplx; CALL; } \
+        else { using T = double; CALL; }        \
+    } while (0)
+
+int k_copy(lsa_ctx* ctx, int dtype, int64_t n, const void* x, void* y) {
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(y, x, (size_t)n * (dtype == LSA_C128 ? 16 : 8), hipMemcpyDeviceToDevice, ctx->stream));
+    return LSA_OK;
+}
+
+int k_set_zero(lsa_ctx* ctx, int dtype, int64_t n, void* x) {
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(x, 0, (size_t)n * (dtype == LSA_C128 ? 16 : 8), ctx->stream));
+    return LSA_OK;
+}
+
+int k_axpy(lsa_ctx* ctx, int dtype, int64_t n, const double alpha[2], const void* x, void* y) {
+    if (dtype == LSA_C128)
+        hipLaunchKernelGGL((axpy_kernel<cplx>), dim3(stream_blocks(ctx, n)), dim3(kThreads), 0, ctx->stream, n,
+                           cplx{alpha[0], alpha[1]}, (const cplx*)x, (cplx*)y);
+    else
+        hipLaunchKernelGGL((axpy_kernel<double>), dim3(stream_blocks(ctx, n)), dim3(kThreads), 0, ctx->stream, n, alpha[0],
+                           (const double*)x, (double*)y);
+    return check_launch(ctx, "axpy");
+}
+
+static int64_t dot_rows_per_block(int64_t n) {
+    int64_t r = (n + 2047) / 2048;          // at most 2048 chunks
+    r = ((r + kThreads - 1) / kThreads) * kThreads;
+    return r < 512 ? 512 : r;
+}
+
+int k_multi_dot(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, const void* w, void* h_dev) {
+    if (j <= 0) return LSA_OK;
+    const int64_t rpb = dot_rows_per_block(n);
+    const int nchunks = (int)((n + rpb - 1) / rpb);
+    const size_t esz = dtype == LSA_C128 ? 16 : 8;
+    LSA_CHECK(lsa_ensure_scratch(ctx, (size_t)j * nchunks * esz, 0));
+    dim3 grid(nchunks, (j + kColTile - 1) / kColTile);
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((multi_dot_partial_kernel<T>), grid, dim3(kThreads), 0, ctx->stream, n, j, rpb, (const T*)V, ldv,
+                           (const T*)w, (T*)ctx->dscratch, nchunks);
+        hipLaunchKernelGGL((multi_dot_finish_kernel<T>), dim3(j), dim3(64), 0, ctx->stream, j, (const T*)ctx->dscratch, nchunks,
+                           (T*)h_dev);
+    });
+    return check_launch(ctx, "multi_dot");
+}
+
+int k_multi_axpy(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, const void* h_dev, void* w,
+                 double* nrm2_dev) {
+    const int blocks = stream_blocks(ctx, n);
+    const size_t esz = dtype == LSA_C128 ? 16 : 8;
+    double* partial = nullptr;
+    if (nrm2_dev) {
+        LSA_CHECK(lsa_ensure_scratch(ctx, sizeof(double) * (size_t)blocks, 0));
+        partial = (double*)ctx->dscratch;
+    }
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((multi_axpy_kernel<T>), dim3(blocks), dim3(kThreads), (size_t)(j > 0 ? j : 1) * esz, ctx->stream, n, j,
+                           (const T*)V, ldv, (const T*)h_dev, (T*)w, partial);
+    });
+    if (nrm2_dev) hipLaunchKernelGGL(nrm2_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, blocks, partial, nrm2_dev);
+    return check_launch(ctx, "multi_axpy");
+}
+
+int k_nrm2(lsa_ctx* ctx, int dtype, int64_t n, const void* x, double* nrm2_dev) {
+    const int blocks = stream_blocks(ctx, n);
+    LSA_CHECK(lsa_ensure_scratch(ctx, sizeof(double) * (size_t)blocks, 0));
+    double* partial = (double*)ctx->dscratch;
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((nrm2_partial_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, (const T*)x, partial);
+    });
+    hipLaunchKernelGGL(nrm2_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, blocks, partial, nrm2_dev);
+    return check_launch(ctx, "nrm2");
+}
+
+int k_scale_by_inv_norm(lsa_ctx* ctx, int dtype, int64_t n, const void* x, const double* nrm2_dev, void* y) {
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((scale_inv_norm_kernel<T>), dim3(stream_blocks(ctx, n)), dim3(kThreads), 0, ctx->stream, n, (const T*)x,
+                           nrm2_dev, (T*)y);
+    });
+    return check_launch(ctx, "scale");
+}
+
+int k_hess_column(lsa_ctx* ctx, int dtype, int cnt, const void* h1, const void* h2, const double* nrm2_dev, void* hout) {
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((hess_column_kernel<T>), dim3(1), dim3(64), 0, ctx->stream, cnt, (const T*)h1, (const T*)h2, nrm2_dev,
+                           (T*)hout);
+    });
+    return check_launch(ctx, "hess_column");
+}
+
+int k_basis_gemm(lsa_ctx* ctx, int dtype, int64_t n, int m, int k, const void* V, int64_t ldv, const void* Q, int ldq,
+                 void* Out, int64_t ldo) {
+    if (k <= 0 || m <= 0) return LSA_OK;
+    const size_t esz = dtype == LSA_C128 ? 16 : 8;
+    int bx = stream_blocks(ctx, n);
+    dim3 grid(bx, (k + kOutTile - 1) / kOutTile);
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((basis_gemm_kernel<T>), grid, dim3(kThreads), (size_t)m * kOutTile * esz, ctx->stream, n, m, k,
+                           (const T*)V, ldv, (const T*)Q, ldq, (T*)Out, ldo);
+    });
+    return check_launch(ctx, "basis_gemm");
+}

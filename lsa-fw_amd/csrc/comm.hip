@@ -1,0 +1,113 @@
+// RCCL plumbing for the row-sharded path (one process per GPU).  RCCL is opened with dlopen so that a
+// single-GPU user never needs it and so that the copy bundled with PyTorch (used only by bench.py's barrier)
+// cannot clash with the one the data path uses.
+#include <dlfcn.h>
+
+#include "lsa_internal.h"
+
+namespace {
+
+// the slice of the NCCL API the data path needs
+typedef struct { char internal[128]; } nccl_uid;
+typedef void* nccl_comm;
+typedef int (*fn_get_uid)(nccl_uid*);
+typedef int (*fn_init_rank)(nccl_comm*, int, nccl_uid, int);
+typedef int (*fn_all_gather)(const void*, void*, size_t, int, nccl_comm, hipStream_t);
+typedef int (*fn_comm_destroy)(nccl_comm);
+typedef const char* (*fn_err_string)(int);
+
+struct Rccl {
+    void* handle = nullptr;
+    fn_get_uid get_uid = nullptr;
+    fn_init_rank init_rank = nullptr;
+    fn_all_gather all_gather = nullptr;
+    fn_comm_destroy comm_destroy = nullptr;
+    fn_err_string err_string = nullptr;
+    std::string why;
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    if (r.handle || !r.why.empty()) return r;
+    const char* env = getenv("LSA_RCCL_PATH");
+    const char* candidates[] = {env, "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+    for (const char* c : candidates) {
+        if (!c || !*c) continue;
+        r.handle = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) {
+        r.why = "librccl.so not found (set LSA_RCCL_PATH)";
+        return r;
+    }
+    r.get_uid = (fn_get_uid)dlsym(r.handle, "ncclGetUniqueId");
+    r.init_rank = (fn_init_rank)dlsym(r.handle, "ncclCommInitRank");
+    r.all_gather = (fn_all_gather)dlsym(r.handle, "ncclAllGather");
+    r.comm_destroy = (fn_comm_destroy)dlsym(r.handle, "ncclCommDestroy");
+    r.err_string = (fn_err_string)dlsym(r.handle, "ncclGetErrorString");
+    if (!r.get_uid || !r.init_rank || !r.all_gather || !r.comm_destroy) {
+        r.why = "librccl.so lacks the expected symbols";
+        dlclose(r.handle);
+        r.handle = nullptr;
+    }
+    return r;
+}
+
+constexpr int kNcclChar = 0;  // ncclInt8 / ncclChar
+
+}  // namespace
+
+// in-place all-gather of equal-sized blocks of a replicated vector: block r (bytes_per_rank bytes at offset
+// r * bytes_per_rank) is this rank's contribution when r == ctx->rank
+int k_allgather_inplace(lsa_ctx* ctx, void* vec, size_t bytes_per_rank) {
+    if (ctx->nranks <= 1) return LSA_OK;
+    Rccl& r = rccl();
+    if (!r.handle || !ctx->comm) return lsa_set_error(ctx, LSA_ERR_COMM, "all-gather requested without an initialised communicator");
+    const char* send = (const char*)vec + (size_t)ctx->rank * bytes_per_rank;
+    int rc = r.all_gather(send, vec, bytes_per_rank, kNcclChar, (nccl_comm)ctx->comm, ctx->stream);
+    if (rc != 0) return lsa_set_error(ctx, LSA_ERR_COMM, "ncclAllGather failed: %s", r.err_string ? r.err_string(rc) : "?");
+    return LSA_OK;
+}
+
+void comm_release(lsa_ctx* ctx) {
+    if (ctx->comm) {
+        Rccl& r = rccl();
+        if (r.handle) r.comm_destroy((nccl_comm)ctx->comm);
+        ctx->comm = nullptr;
+    }
+}
+
+extern "C" {
+
+int lsa_comm_unique_id(void* id128) {
+    if (!id128) return LSA_ERR_ARG;
+    Rccl& r = rccl();
+    if (!r.handle) return LSA_ERR_COMM;
+    nccl_uid uid;
+    if (r.get_uid(&uid) != 0) return LSA_ERR_COMM;
+    memcpy(id128, &uid, sizeof uid);
+    return LSA_OK;
+}
+
+int lsa_comm_init(lsa_ctx* ctx, int nranks, int rank, const void* id128) {
+    if (!ctx || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_comm_init: bad argument");
+    if (nranks == 1) {
+        ctx->nranks = 1;
+        ctx->rank = 0;
+        return LSA_OK;
+    }
+    Rccl& r = rccl();
+    if (!r.handle) return lsa_set_error(ctx, LSA_ERR_COMM, "RCCL unavailable: %s", r.why.c_str());
+    LSA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    nccl_uid uid;
+    memcpy(&uid, id128, sizeof uid);
+    nccl_comm comm = nullptr;
+    int rc = r.init_rank(&comm, nranks, uid, rank);
+    if (rc != 0) return lsa_set_error(ctx, LSA_ERR_COMM, "ncclCommInitRank failed: %s", r.err_string ? r.err_string(rc) : "?");
+    ctx->comm = comm;
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    return LSA_OK;
+}
+
+}  // extern "C"

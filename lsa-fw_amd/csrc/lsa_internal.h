@@ -1,0 +1,186 @@
+// Internal declarations shared by the translation units of liblsa_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/lsa_hip.h"
+
+// ---- scalar helpers ---------------------------------------------------------------------------------
+struct cplx {
+    double re, im;
+};
+static_assert(sizeof(cplx) == 16, "complex128 layout");
+
+__host__ __device__ inline cplx make_cplx(double r, double i) { return cplx{r, i}; }
+
+template <typename T>
+struct scalar_traits;
+template <>
+struct scalar_traits<double> {
+    static constexpr int dtype = LSA_F64;
+    __host__ __device__ static double zero() { return 0.0; }
+};
+template <>
+struct scalar_traits<cplx> {
+    static constexpr int dtype = LSA_C128;
+    __host__ __device__ static cplx zero() { return cplx{0.0, 0.0}; }
+};
+
+// acc += a * b for every (matrix scalar, vector scalar) pair the path needs
+__host__ __device__ inline void fma_acc(double& acc, double a, double b) { acc = fma(a, b, acc); }
+__host__ __device__ inline void fma_acc(cplx& acc, double a, cplx b) {
+    acc.re = fma(a, b.re, acc.re);
+    acc.im = fma(a, b.im, acc.im);
+}
+__host__ __device__ inline void fma_acc(cplx& acc, cplx a, cplx b) {
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(-a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im);
+    acc.im = fma(a.im, b.re, acc.im);
+}
+// acc += conj(a) * b
+__host__ __device__ inline void fma_conj_acc(double& acc, double a, double b) { acc = fma(a, b, acc); }
+__host__ __device__ inline void fma_conj_acc(cplx& acc, cplx a, cplx b) {
+    acc.re = fma(a.re, b.re, acc.re);
+    acc.re = fma(a.im, b.im, acc.re);
+    acc.im = fma(a.re, b.im, acc.im);
+    acc.im = fma(-a.im, b.re, acc.im);
+}
+__host__ __device__ inline double s_mul(double a, double b) { return a * b; }
+__host__ __device__ inline cplx s_mul(double a, cplx b) { return cplx{a * b.re, a * b.im}; }
+__host__ __device__ inline cplx s_mul(cplx a, cplx b) { return cplx{a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__host__ __device__ inline double s_add(double a, double b) { return a + b; }
+__host__ __device__ inline cplx s_add(cplx a, cplx b) { return cplx{a.re + b.re, a.im + b.im}; }
+__host__ __device__ inline double s_sub(double a, double b) { return a - b; }
+__host__ __device__ inline cplx s_sub(cplx a, cplx b) { return cplx{a.re - b.re, a.im - b.im}; }
+__host__ __device__ inline double s_conj(double a) { return a; }
+__host__ __device__ inline cplx s_conj(cplx a) { return cplx{a.re, -a.im}; }
+__host__ __device__ inline double s_abs2(double a) { return a * a; }
+__host__ __device__ inline double s_abs2(cplx a) { return a.re * a.re + a.im * a.im; }
+__host__ __device__ inline double s_inv(double a) { return 1.0 / a; }
+__host__ __device__ inline cplx s_inv(cplx a) {
+    // Smith's algorithm: no overflow for large / tiny pivots
+    if (fabs(a.re) >= fabs(a.im)) {
+        double r = a.im / a.re, d = a.re + a.im * r;
+        return cplx{1.0 / d, -r / d};
+    }
+    double r = a.re / a.im, d = a.re * r + a.im;
+    return cplx{r / d, -1.0 / d};
+}
+__host__ __device__ inline cplx to_cplx(double a) { return cplx{a, 0.0}; }
+__host__ __device__ inline cplx to_cplx(cplx a) { return a; }
+__host__ __device__ inline void s_from(double& out, double re, double) { out = re; }
+__host__ __device__ inline void s_from(cplx& out, double re, double im) { out = cplx{re, im}; }
+
+// ---- objects behind the opaque handles ----------------------------------------------------------------
+struct lsa_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+    std::string arch;
+    int num_cu = 256;
+    // pinned host scratch for small device->host reads (Hessenberg columns, flags)
+    void* pinned = nullptr;
+    size_t pinned_bytes = 0;
+    // device scratch for reductions
+    void* dscratch = nullptr;
+    size_t dscratch_bytes = 0;
+    // RCCL (multi-GPU); null when single-process
+    void* comm = nullptr;
+    int nranks = 1, rank = 0;
+};
+
+struct lsa_vec {
+    lsa_ctx* ctx;
+    int64_t n;
+    int dtype;
+    void* d;
+};
+
+struct lsa_mat {
+    lsa_ctx* ctx;
+    int32_t n;        // rows held locally
+    int32_t ncols;    // global column count
+    int32_t row0;     // first global row of this shard (0 when unsharded)
+    int64_t nnz;
+    int dtype;
+    int32_t* rp;      // device, n+1
+    int32_t* ci;      // device, nnz
+    void* val;        // device, nnz
+    bool owns_index;  // false when the index arrays are shared with another matrix
+    std::vector<int32_t> h_rp, h_ci;  // host copy of the pattern (analysis phases)
+};
+
+int lsa_set_error(lsa_ctx* ctx, int code, const char* fmt, ...);
+int lsa_ensure_scratch(lsa_ctx* ctx, size_t dbytes, size_t hbytes);
+
+#define LSA_HIP_CHECK(ctx, expr)                                                                         \
+    do {                                                                                                 \
+        hipError_t _e = (expr);                                                                          \
+        if (_e != hipSuccess)                                                                            \
+            return lsa_set_error((ctx), LSA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                                 __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define LSA_CHECK(expr)            \
+    do {                           \
+        int _rc = (expr);          \
+        if (_rc != LSA_OK) return _rc; \
+    } while (0)
+
+// ---- kernels launched across translation units --------------------------------------------------------
+// (all launch on ctx->stream and return LSA_OK or a status)
+
+// y = A x                       (spmv.hip)
+int k_spmv(lsa_ctx* ctx, const lsa_mat* A, int xdtype, const void* x, void* y);
+int k_spmv_transpose(lsa_ctx* ctx, const lsa_mat* A, int conj, int xdtype, const void* x, void* y);
+
+// BLAS-1 / tall-skinny kernels (blas.hip); T selected by dtype
+int k_copy(lsa_ctx* ctx, int dtype, int64_t n, const void* x, void* y);
+int k_set_zero(lsa_ctx* ctx, int dtype, int64_t n, void* x);
+// y += alpha x
+int k_axpy(lsa_ctx* ctx, int dtype, int64_t n, const double alpha[2], const void* x, void* y);
+// h[c] = sum_i conj(V[i,c]) w[i], c < j   -> device array h (same dtype); V column-major with leading dim ldv
+int k_multi_dot(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, const void* w, void* h_dev);
+// w -= V h, and nrm2_dev[0] = ||w||^2 afterwards when nrm2_dev != null
+int k_multi_axpy(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, const void* h_dev, void* w,
+                 double* nrm2_dev);
+// nrm2_dev[0] = ||x||^2
+int k_nrm2(lsa_ctx* ctx, int dtype, int64_t n, const void* x, double* nrm2_dev);
+// y = x / sqrt(nrm2_dev[0])   (no host round trip)
+int k_scale_by_inv_norm(lsa_ctx* ctx, int dtype, int64_t n, const void* x, const double* nrm2_dev, void* y);
+// hsum[c] += hadd[c] (c < j) and hsum[j] = sqrt(nrm2[0])  -- assembles one Hessenberg column on the device
+int k_hess_column(lsa_ctx* ctx, int dtype, int j, const void* h1, const void* h2, const double* nrm2_dev, void* hout);
+// Out[:, 0:k] = V[:, 0:m] Q   (Q m x k column-major on the device, ldq)
+int k_basis_gemm(lsa_ctx* ctx, int dtype, int64_t n, int m, int k, const void* V, int64_t ldv, const void* Q, int ldq,
+                 void* Out, int64_t ldo);
+
+// ---- ILU (ilu.hip) -------------------------------------------------------------------------------------
+struct lsa_ilu {
+    lsa_ctx* ctx;
+    int32_t n;
+    int64_t nnz;
+    int dtype;  // scalar type of the factors
+    int32_t *rp, *ci, *diag;   // device pattern of the factors + position of the diagonal
+    void* val;                 // device factor values (L strictly lower, unit diagonal implied; U upper)
+    void* dinv;                // device 1/u_ii
+    int32_t *order_l, *order_u;  // device row lists sorted by dependency level
+    std::vector<int32_t> lvl_ptr_l, lvl_ptr_u;  // host level pointers into the row lists
+    std::vector<int32_t> h_rp, h_ci, h_diag;
+    int32_t nshift;
+    int32_t* flag;   // device int[4]: abort / error / shift count / spare
+    int sptrsv_blocks_l, sptrsv_blocks_u;  // workgroups used by the sync-free solves
+    int algo;                               // 0 = level-by-level launches, 1 = sync-free
+    void* tmp;                              // device vector (intermediate of L then U), sized on demand
+    int tmp_dtype;
+};
+
+int ilu_solve_dev(lsa_ctx* ctx, lsa_ilu* pc, int which, int vdtype, const void* b, void* x);

@@ -1,0 +1,595 @@
+// Device-resident Krylov loops: restarted GMRES (the ST's inner KSP), the shift-invert operator, and the
+// Arnoldi recurrences + basis updates that Krylov-Schur needs (EPS.solve of the reference, Solver/utils.py:270).
+// Only O(m) scalars per step cross PCIe (one Hessenberg column); vectors never leave HBM.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <complex>
+
+#include "lsa_internal.h"
+
+int ilu_check_abort(lsa_ctx* ctx, lsa_ilu* pc);
+
+namespace {
+
+using zc = std::complex<double>;
+inline size_t esize(int dtype) { return dtype == LSA_C128 ? 16 : 8; }
+inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// small device arrays used by the orthogonalisation (sized for `cap` basis vectors)
+struct OrthWork {
+    void *h1 = nullptr, *h2 = nullptr, *hcol = nullptr;
+    double* nrm2 = nullptr;
+    int cap = 0;
+    int alloc(lsa_ctx* ctx, int cap_, int dtype) {
+        cap = cap_;
+        const size_t b = (size_t)(cap + 2) * esize(dtype);
+        LSA_HIP_CHECK(ctx, hipMalloc(&h1, b));
+        LSA_HIP_CHECK(ctx, hipMalloc(&h2, b));
+        LSA_HIP_CHECK(ctx, hipMalloc(&hcol, b));
+        LSA_HIP_CHECK(ctx, hipMalloc((void**)&nrm2, 4 * sizeof(double)));
+        return LSA_OK;
+    }
+    void release() {
+        for (void* p : {h1, h2, hcol, (void*)nrm2})
+            if (p) (void)hipFree(p);
+        h1 = h2 = hcol = nullptr;
+        nrm2 = nullptr;
+    }
+};
+
+// CGS2: orthogonalise w against V[:, 0:j], normalise into vnext, and bring the j+1 Hessenberg entries to the
+// host as complex numbers (real dtype is widened).  One stream synchronisation.
+int orthonormalize(lsa_ctx* ctx, int dtype, int64_t n, const void* V, int64_t ldv, int j, void* w, void* vnext,
+                   OrthWork& ow, zc* h_host) {
+    LSA_CHECK(k_multi_dot(ctx, dtype, n, j, V, ldv, w, ow.h1));
+    LSA_CHECK(k_multi_axpy(ctx, dtype, n, j, V, ldv, ow.h1, w, nullptr));
+    LSA_CHECK(k_multi_dot(ctx, dtype, n, j, V, ldv, w, ow.h2));
+    LSA_CHECK(k_multi_axpy(ctx, dtype, n, j, V, ldv, ow.h2, w, ow.nrm2));
+    LSA_CHECK(k_hess_column(ctx, dtype, j, ow.h1, ow.h2, ow.nrm2, ow.hcol));
+    LSA_CHECK(k_scale_by_inv_norm(ctx, dtype, n, w, ow.nrm2, vnext));
+    const size_t bytes = (size_t)(j + 1) * esize(dtype);
+    LSA_CHECK(lsa_ensure_scratch(ctx, 0, bytes));
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pinned, ow.hcol, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (dtype == LSA_C128) {
+        const cplx* p = (const cplx*)ctx->pinned;
+        for (int c = 0; c <= j; ++c) h_host[c] = zc(p[c].re, p[c].im);
+    } else {
+        const double* p = (const double*)ctx->pinned;
+        for (int c = 0; c <= j; ++c) h_host[c] = zc(p[c], 0.0);
+    }
+    return LSA_OK;
+}
+
+int device_norm(lsa_ctx* ctx, int dtype, int64_t n, const void* x, double* nrm2_dev, double* out) {
+    LSA_CHECK(k_nrm2(ctx, dtype, n, x, nrm2_dev));
+    LSA_CHECK(lsa_ensure_scratch(ctx, 0, sizeof(double)));
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pinned, nrm2_dev, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = std::sqrt(*(const double*)ctx->pinned);
+    return LSA_OK;
+}
+
+// upload a small host array of complex numbers as `dtype`
+int upload_small(lsa_ctx* ctx, int dtype, const zc* src, size_t count, void* dst) {
+    LSA_CHECK(lsa_ensure_scratch(ctx, 0, count * 16));
+    if (dtype == LSA_C128) {
+        cplx* p = (cplx*)ctx->pinned;
+        for (size_t i = 0; i < count; ++i) p[i] = cplx{src[i].real(), src[i].imag()};
+    } else {
+        double* p = (double*)ctx->pinned;
+        for (size_t i = 0; i < count; ++i) p[i] = src[i].real();
+    }
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(dst, ctx->pinned, count * esize(dtype), hipMemcpyHostToDevice, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // pinned buffer is reused
+    return LSA_OK;
+}
+
+struct GmresWork {
+    int dtype = LSA_C128;
+    int64_t n = 0;
+    int restart = 0;
+    void *V = nullptr, *w = nullptr, *z = nullptr, *ydev = nullptr;
+    OrthWork ow;
+    std::vector<zc> H, cs, sn, g, y, hcol;
+    int alloc(lsa_ctx* ctx, int64_t n_, int restart_, int dtype_) {
+        n = n_;
+        restart = restart_;
+        dtype = dtype_;
+        const size_t vb = (size_t)std::max<int64_t>(n, 1) * esize(dtype);
+        LSA_HIP_CHECK(ctx, hipMalloc(&V, vb * (size_t)(restart + 1)));
+        LSA_HIP_CHECK(ctx, hipMalloc(&w, vb));
+        LSA_HIP_CHECK(ctx, hipMalloc(&z, vb));
+        LSA_HIP_CHECK(ctx, hipMalloc(&ydev, (size_t)(restart + 2) * esize(dtype)));
+        LSA_CHECK(ow.alloc(ctx, restart + 1, dtype));
+        H.assign((size_t)(restart + 1) * restart, zc(0));
+        cs.assign(restart + 1, zc(0));
+        sn.assign(restart + 1, zc(0));
+        g.assign(restart + 2, zc(0));
+        y.assign(restart + 1, zc(0));
+        hcol.assign(restart + 2, zc(0));
+        return LSA_OK;
+    }
+    void release() {
+        for (void* p : {V, w, z, ydev})
+            if (p) (void)hipFree(p);
+        V = w = z = ydev = nullptr;
+        ow.release();
+    }
+};
+
+// right-preconditioned restarted GMRES on the device; x0 = x when use_x0, else 0
+int gmres_run(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, int dtype, const void* b, void* x, bool use_x0, double rtol,
+              int maxit, GmresWork& W, int32_t* iters_out, double* relres_out, lsa_stats* st) {
+    const int64_t n = W.n;
+    const int m = W.restart;
+    const size_t vb = (size_t)n * esize(dtype);
+    auto col = [&](int j) { return (void*)((char*)W.V + (size_t)j * vb); };
+    double bnorm = 0.0;
+    LSA_CHECK(device_norm(ctx, dtype, n, b, W.ow.nrm2, &bnorm));
+    if (!std::isfinite(bnorm)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "GMRES: right-hand side is not finite");
+    if (!use_x0) LSA_CHECK(k_set_zero(ctx, dtype, n, x));
+    int total = 0;
+    double relres = 0.0;
+    if (bnorm == 0.0) {
+        LSA_CHECK(k_set_zero(ctx, dtype, n, x));
+        if (iters_out) *iters_out = 0;
+        if (relres_out) *relres_out = 0.0;
+        return LSA_OK;
+    }
+    bool converged = false;
+    bool first_cycle = true;
+    while (!converged && total < maxit) {
+        // r = b - C x  -> w
+        if (first_cycle && !use_x0) {
+            LSA_CHECK(k_copy(ctx, dtype, n, b, W.w));
+        } else {
+            LSA_CHECK(k_spmv(ctx, C, dtype, x, W.z));
+            if (st) ++st->spmv_calls;
+            LSA_CHECK(k_copy(ctx, dtype, n, b, W.w));
+            const double minus1[2] = {-1.0, 0.0};
+            LSA_CHECK(k_axpy(ctx, dtype, n, minus1, W.z, W.w));
+        }
+        first_cycle = false;
+        double beta = 0.0;
+        LSA_CHECK(device_norm(ctx, dtype, n, W.w, W.ow.nrm2, &beta));
+        if (!std::isfinite(beta)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "GMRES: residual is not finite");
+        relres = beta / bnorm;
+        if (relres <= rtol) {
+            converged = true;
+            break;
+        }
+        LSA_CHECK(k_scale_by_inv_norm(ctx, dtype, n, W.w, W.ow.nrm2, col(0)));
+        std::fill(W.g.begin(), W.g.end(), zc(0));
+        W.g[0] = zc(beta, 0);
+        int jj = 0;
+        for (int j = 0; j < m && total < maxit; ++j) {
+            const void* vj = col(j);
+            const void* src = vj;
+            if (pc) {
+                LSA_CHECK(ilu_solve_dev(ctx, pc, 2, dtype, vj, W.z));
+                if (st) st->sptrsv_calls += 2;
+                src = W.z;
+            }
+            LSA_CHECK(k_spmv(ctx, C, dtype, src, W.w));
+            if (st) ++st->spmv_calls;
+            LSA_CHECK(orthonormalize(ctx, dtype, n, W.V, n, j + 1, W.w, col(j + 1), W.ow, W.hcol.data()));
+            ++total;
+            zc* Hj = &W.H[(size_t)j * (m + 1)];
+            for (int i = 0; i <= j + 1; ++i) Hj[i] = W.hcol[i];
+            if (!std::isfinite(Hj[j + 1].real())) {
+                if (pc) LSA_CHECK(ilu_check_abort(ctx, pc));
+                return lsa_set_error(ctx, LSA_ERR_NONFINITE, "GMRES: non-finite Hessenberg entry at iteration %d", total);
+            }
+            for (int i = 0; i < j; ++i) {
+                const zc t = std::conj(W.cs[i]) * Hj[i] + std::conj(W.sn[i]) * Hj[i + 1];
+                Hj[i + 1] = -W.sn[i] * Hj[i] + W.cs[i] * Hj[i + 1];
+                Hj[i] = t;
+            }
+            // rotation that zeroes Hj[j+1]
+            const double a = std::abs(Hj[j]), bb = std::abs(Hj[j + 1]);
+            const double rr = std::hypot(a, bb);
+            if (rr == 0.0) {
+                W.cs[j] = zc(1);
+                W.sn[j] = zc(0);
+            } else {
+                W.cs[j] = Hj[j] / rr;
+                W.sn[j] = Hj[j + 1] / rr;
+            }
+            Hj[j] = std::conj(W.cs[j]) * Hj[j] + std::conj(W.sn[j]) * Hj[j + 1];
+            Hj[j + 1] = zc(0);
+            W.g[j + 1] = -W.sn[j] * W.g[j];
+            W.g[j] = std::conj(W.cs[j]) * W.g[j];
+            jj = j + 1;
+            relres = std::abs(W.g[j + 1]) / bnorm;
+            if (relres <= rtol) {
+                converged = true;
+                break;
+            }
+        }
+        // y = R^-1 g ;  x += P^-1 (V y)
+        for (int i = jj - 1; i >= 0; --i) {
+            zc s = W.g[i];
+            for (int k = i + 1; k < jj; ++k) s -= W.H[(size_t)k * (m + 1) + i] * W.y[k];
+            W.y[i] = s / W.H[(size_t)i * (m + 1) + i];
+        }
+        if (jj > 0) {
+            LSA_CHECK(upload_small(ctx, dtype, W.y.data(), (size_t)jj, W.ydev));
+            LSA_CHECK(k_basis_gemm(ctx, dtype, n, jj, 1, W.V, n, W.ydev, jj, W.w, n));
+            const double one[2] = {1.0, 0.0};
+            if (pc) {
+                LSA_CHECK(ilu_solve_dev(ctx, pc, 2, dtype, W.w, W.z));
+                if (st) st->sptrsv_calls += 2;
+                LSA_CHECK(k_axpy(ctx, dtype, n, one, W.z, x));
+            } else {
+                LSA_CHECK(k_axpy(ctx, dtype, n, one, W.w, x));
+            }
+        }
+    }
+    if (pc) LSA_CHECK(ilu_check_abort(ctx, pc));
+    if (iters_out) *iters_out = total;
+    if (relres_out) *relres_out = relres;
+    if (st) {
+        st->gmres_iters += total;
+        st->last_rel_res = relres;
+        st->max_rel_res = std::max(st->max_rel_res, relres);
+    }
+    if (!converged)
+        return lsa_set_error(ctx, LSA_ERR_DIVERGED, "GMRES did not reach rtol %.1e in %d iterations (relative residual %.3e)", rtol,
+                             total, relres);
+    return LSA_OK;
+}
+
+template <typename T>
+__global__ void shift_diag_kernel(int32_t n, int32_t row0, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                  T* __restrict__ val, cplx shift, int32_t* __restrict__ missing) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int32_t target = (int32_t)i + row0;
+        int32_t lo = rp[i], hi = rp[i + 1];
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (ci[mid] < target) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < rp[i + 1] && ci[lo] == target) {
+            cplx v = to_cplx(val[lo]);
+            s_from(val[lo], v.re - shift.re, v.im - shift.im);
+        } else {
+            atomicAdd(missing, 1);
+        }
+    }
+}
+
+}  // namespace
+
+// ---- objects ------------------------------------------------------------------------------------------------------
+struct lsa_op {
+    lsa_ctx* ctx;
+    int64_t n;
+    const lsa_mat* Kmul;  // y = Kfac^-1 (Kmul x); either may be null (identity)
+    const lsa_mat* Kfac;
+    lsa_mat* owned;       // the matrix built here (C = A - sigma M), destroyed with the operator
+    lsa_ilu* pc;
+    lsa_op_options opts;
+    GmresWork gw;
+    bool gw_ready;
+    void* t;  // device temp vector (complex)
+    lsa_stats st;
+};
+
+struct lsa_krylov {
+    lsa_ctx* ctx;
+    lsa_op* op;
+    int64_t n;
+    int32_t ncv;
+    void *V, *V2, *w, *qdev;
+    OrthWork ow;
+    std::vector<zc> hcol;
+};
+
+extern "C" {
+
+int lsa_gmres(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, const lsa_vec* b, lsa_vec* x, int use_x0, double rtol, int restart,
+              int maxit, int32_t* iters, double* rel_res) {
+    if (!ctx || !C || !b || !x) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_gmres: null argument");
+    if (C->n != C->ncols || b->n != C->n || x->n != C->n || b->dtype != x->dtype)
+        return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_gmres: shape/dtype mismatch");
+    if (C->dtype == LSA_C128 && b->dtype != LSA_C128) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_gmres: complex matrix needs complex vectors");
+    if (restart < 1 || maxit < 1 || !(rtol > 0.0)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_gmres: restart, maxit, rtol must be positive");
+    restart = std::min(restart, maxit);
+    GmresWork W;
+    int rc = W.alloc(ctx, C->n, restart, b->dtype);
+    if (rc == LSA_OK) rc = gmres_run(ctx, C, pc, b->dtype, b->d, x->d, use_x0 != 0, rtol, maxit, W, iters, rel_res, nullptr);
+    (void)hipStreamSynchronize(ctx->stream);
+    W.release();
+    return rc;
+}
+
+int lsa_op_create(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const double sigma[2], int mode, const lsa_op_options* opts,
+                  lsa_op** out) {
+    if (!ctx || !A || !sigma || !opts || !out) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: null argument");
+    if (A->n != A->ncols) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: A must be square (got %d x %d)", A->n, A->ncols);
+    if (M && (M->n != A->n || M->ncols != A->ncols)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: M does not match A's shape");
+    if (mode != 0 && mode != 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: mode must be 0 (sinvert) or 1 (shift)");
+    const double t0 = now_s();
+    lsa_op* op = new lsa_op();
+    op->ctx = ctx;
+    op->n = A->n;
+    op->Kmul = op->Kfac = nullptr;
+    op->owned = nullptr;
+    op->pc = nullptr;
+    op->opts = *opts;
+    op->gw_ready = false;
+    op->t = nullptr;
+    memset(&op->st, 0, sizeof op->st);
+    const bool zshift = sigma[0] == 0.0 && sigma[1] == 0.0;
+    const bool cdt = sigma[1] != 0.0 || A->dtype == LSA_C128 || (M && M->dtype == LSA_C128);
+    int rc = LSA_OK;
+    lsa_mat* C = nullptr;
+    if (!(mode == 1 && zshift)) {
+        // C = A - sigma M (or A - sigma I)
+        const double one[2] = {1.0, 0.0}, ms[2] = {-sigma[0], -sigma[1]}, zero[2] = {0.0, 0.0};
+        if (M) rc = lsa_csr_axpby(ctx, A, M, one, ms, cdt ? LSA_C128 : LSA_F64, &C);
+        else {
+            rc = lsa_csr_axpby(ctx, A, A, one, zero, cdt ? LSA_C128 : LSA_F64, &C);
+            if (rc == LSA_OK && !zshift) {
+                int32_t* miss = (int32_t*)ctx->dscratch;
+                (void)hipMemsetAsync(miss, 0, sizeof(int32_t), ctx->stream);
+                const int blocks = std::max(1, std::min((int)((C->n + 255) / 256), ctx->num_cu * 8));
+                if (cdt) hipLaunchKernelGGL((shift_diag_kernel<cplx>), dim3(blocks), dim3(256), 0, ctx->stream, C->n, C->row0, C->rp, C->ci, (cplx*)C->val, cplx{sigma[0], sigma[1]}, miss);
+                else hipLaunchKernelGGL((shift_diag_kernel<double>), dim3(blocks), dim3(256), 0, ctx->stream, C->n, C->row0, C->rp, C->ci, (double*)C->val, cplx{sigma[0], sigma[1]}, miss);
+                int32_t hm = 0;
+                (void)hipMemcpyAsync(&hm, miss, sizeof hm, hipMemcpyDeviceToHost, ctx->stream);
+                if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = lsa_set_error(ctx, LSA_ERR_HIP, "diagonal shift failed");
+                else if (hm != 0) rc = lsa_set_error(ctx, LSA_ERR_ARG, "A - sigma*I needs a structurally present diagonal (%d rows have none)", hm);
+            }
+        }
+        if (rc != LSA_OK) {
+            if (C) lsa_mat_destroy(C);
+            delete op;
+            return rc;
+        }
+        op->owned = C;
+    }
+    if (mode == 0) {
+        op->Kfac = C;
+        op->Kmul = M;
+    } else {
+        op->Kmul = C ? C : A;
+        op->Kfac = M;
+    }
+    if (op->Kfac && opts->pc_type == 1) {
+        rc = lsa_ilu_create(ctx, op->Kfac, opts->ilu_levels, opts->ilu_shift, &op->pc);
+        if (rc != LSA_OK) {
+            lsa_op_destroy(op);
+            return rc;
+        }
+    }
+    if (hipMalloc(&op->t, (size_t)std::max<int64_t>(op->n, 1) * 16) != hipSuccess) {
+        lsa_op_destroy(op);
+        return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_op_create: out of device memory");
+    }
+    op->st.seconds_factor = now_s() - t0;
+    *out = op;
+    return LSA_OK;
+}
+
+void lsa_op_destroy(lsa_op* op) {
+    if (!op) return;
+    if (op->ctx && op->ctx->stream) (void)hipStreamSynchronize(op->ctx->stream);
+    if (op->pc) lsa_ilu_destroy(op->pc);
+    if (op->owned) lsa_mat_destroy(op->owned);
+    if (op->gw_ready) op->gw.release();
+    if (op->t) (void)hipFree(op->t);
+    delete op;
+}
+
+// y = Kfac^-1 Kmul x on device pointers (complex vectors)
+static int op_apply_dev(lsa_ctx* ctx, lsa_op* op, const void* x, void* y) {
+    const int dtype = LSA_C128;
+    ++op->st.op_applies;
+    const void* rhs = x;
+    if (op->Kmul) {
+        void* dst = op->Kfac ? op->t : y;
+        LSA_CHECK(k_spmv(ctx, op->Kmul, dtype, x, dst));
+        ++op->st.spmv_calls;
+        rhs = dst;
+    }
+    if (!op->Kfac) {
+        if (!op->Kmul) LSA_CHECK(k_copy(ctx, dtype, op->n, x, y));
+        return LSA_OK;
+    }
+    if (!op->gw_ready) {
+        const int restart = std::max(1, std::min(op->opts.ksp_restart, op->opts.ksp_maxit));
+        LSA_CHECK(op->gw.alloc(ctx, op->n, restart, dtype));
+        op->gw_ready = true;
+    }
+    return gmres_run(ctx, op->Kfac, op->pc, dtype, rhs, y, false, op->opts.ksp_rtol, op->opts.ksp_maxit, op->gw, nullptr, nullptr,
+                     &op->st);
+}
+
+int lsa_op_apply(lsa_ctx* ctx, lsa_op* op, const lsa_vec* x, lsa_vec* y) {
+    if (!ctx || !op || !x || !y) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_apply: null argument");
+    if (x->n != op->n || y->n != op->n || x->dtype != LSA_C128 || y->dtype != LSA_C128 || x->d == y->d)
+        return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_apply: x and y must be distinct complex vectors of length n");
+    const double t0 = now_s();
+    int rc = op_apply_dev(ctx, op, x->d, y->d);
+    if (rc == LSA_OK) LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    op->st.seconds_solve += now_s() - t0;
+    return rc;
+}
+
+int lsa_op_stats(const lsa_op* op, lsa_stats* out) {
+    if (!op || !out) return LSA_ERR_ARG;
+    *out = op->st;
+    return LSA_OK;
+}
+
+// ---- Krylov basis ------------------------------------------------------------------------------------------------
+int lsa_krylov_create(lsa_ctx* ctx, lsa_op* op, int32_t ncv, lsa_krylov** out) {
+    if (!ctx || !op || !out || ncv < 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_create: bad argument");
+    lsa_krylov* k = new lsa_krylov();
+    k->ctx = ctx;
+    k->op = op;
+    k->n = op->n;
+    k->ncv = ncv;
+    k->V = k->V2 = k->w = k->qdev = nullptr;
+    const size_t vb = (size_t)std::max<int64_t>(k->n, 1) * 16;
+    bool ok = hipMalloc(&k->V, vb * (size_t)(ncv + 1)) == hipSuccess && hipMalloc(&k->V2, vb * (size_t)(ncv + 1)) == hipSuccess &&
+              hipMalloc(&k->w, vb) == hipSuccess && hipMalloc(&k->qdev, (size_t)(ncv + 1) * (size_t)(ncv + 1) * 16) == hipSuccess;
+    if (!ok || k->ow.alloc(ctx, ncv + 1, LSA_C128) != LSA_OK) {
+        lsa_krylov_destroy(k);
+        return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_krylov_create: out of device memory (n=%lld, ncv=%d)", (long long)op->n, ncv);
+    }
+    k->hcol.assign((size_t)ncv + 2, zc(0));
+    *out = k;
+    return LSA_OK;
+}
+
+void lsa_krylov_destroy(lsa_krylov* k) {
+    if (!k) return;
+    if (k->ctx && k->ctx->stream) (void)hipStreamSynchronize(k->ctx->stream);
+    for (void* p : {k->V, k->V2, k->w, k->qdev})
+        if (p) (void)hipFree(p);
+    k->ow.release();
+    delete k;
+}
+
+int lsa_krylov_set_start(lsa_ctx* ctx, lsa_krylov* k, const void* host_v) {
+    if (!ctx || !k || !host_v) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_set_start: null argument");
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(k->w, host_v, (size_t)k->n * 16, hipMemcpyHostToDevice, ctx->stream));
+    double nrm = 0.0;
+    LSA_CHECK(device_norm(ctx, LSA_C128, k->n, k->w, k->ow.nrm2, &nrm));
+    if (!(nrm > 0.0) || !std::isfinite(nrm)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_set_start: start vector is zero or not finite");
+    LSA_CHECK(k_scale_by_inv_norm(ctx, LSA_C128, k->n, k->w, k->ow.nrm2, k->V));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return LSA_OK;
+}
+
+int lsa_krylov_inject(lsa_ctx* ctx, lsa_krylov* k, int32_t j, const void* host_v) {
+    if (!ctx || !k || !host_v) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_inject: null argument");
+    if (j < 0 || j > k->ncv) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_inject: index %d out of range", j);
+    if (j == 0) return lsa_krylov_set_start(ctx, k, host_v);
+    const size_t vb = (size_t)k->n * 16;
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(k->w, host_v, vb, hipMemcpyHostToDevice, ctx->stream));
+    LSA_CHECK(orthonormalize(ctx, LSA_C128, k->n, k->V, k->n, j, k->w, (char*)k->V + (size_t)j * vb, k->ow, k->hcol.data()));
+    const double beta = k->hcol[j].real();
+    if (!(beta > 0.0) || !std::isfinite(beta)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_inject: vector lies in the span of the basis");
+    return LSA_OK;
+}
+
+int lsa_krylov_extend(lsa_ctx* ctx, lsa_krylov* k, int32_t j0, int32_t j1, void* H, int32_t ldh, int32_t* breakdown) {
+    if (!ctx || !k || !H) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_extend: null argument");
+    if (j0 < 0 || j1 < j0 || j1 > k->ncv || ldh < j1 + 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_extend: bad step range [%d, %d) for ncv %d", j0, j1, k->ncv);
+    const double t0 = now_s();
+    const size_t vb = (size_t)k->n * 16;
+    if (breakdown) *breakdown = -1;
+    cplx* Hh = (cplx*)H;
+    for (int32_t j = j0; j < j1; ++j) {
+        const void* vj = (char*)k->V + (size_t)j * vb;
+        void* vn = (char*)k->V + (size_t)(j + 1) * vb;
+        int rc = op_apply_dev(ctx, k->op, vj, k->w);
+        if (rc != LSA_OK) {
+            k->op->st.seconds_solve += now_s() - t0;
+            return rc;
+        }
+        LSA_CHECK(orthonormalize(ctx, LSA_C128, k->n, k->V, k->n, j + 1, k->w, vn, k->ow, k->hcol.data()));
+        for (int32_t i = 0; i < ldh; ++i) Hh[(size_t)j * ldh + i] = cplx{0.0, 0.0};
+        for (int32_t i = 0; i <= j + 1; ++i) Hh[(size_t)j * ldh + i] = cplx{k->hcol[i].real(), k->hcol[i].imag()};
+        const double beta = k->hcol[j + 1].real();
+        if (!std::isfinite(beta)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "Arnoldi: non-finite norm at step %d", j);
+        double colmax = 0.0;
+        for (int32_t i = 0; i <= j; ++i) colmax = std::max(colmax, std::abs(k->hcol[i]));
+        if (beta <= 1e-14 * std::max(colmax, 1e-300)) {
+            if (breakdown) *breakdown = j;
+            break;
+        }
+    }
+    k->op->st.seconds_solve += now_s() - t0;
+    return LSA_OK;
+}
+
+int lsa_krylov_restart(lsa_ctx* ctx, lsa_krylov* k, int32_t m, int32_t knew, const void* Q, int32_t ldq) {
+    if (!ctx || !k || !Q) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_restart: null argument");
+    if (m < 1 || m > k->ncv || knew < 0 || knew > m || ldq < m) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_restart: bad sizes m=%d knew=%d", m, knew);
+    const size_t vb = (size_t)k->n * 16;
+    if (knew > 0) {
+        // pack Q densely (m x knew) and upload
+        LSA_CHECK(lsa_ensure_scratch(ctx, 0, (size_t)m * knew * 16));
+        const cplx* Qh = (const cplx*)Q;
+        cplx* p = (cplx*)ctx->pinned;
+        for (int32_t c = 0; c < knew; ++c)
+            for (int32_t r = 0; r < m; ++r) p[(size_t)c * m + r] = Qh[(size_t)c * ldq + r];
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(k->qdev, p, (size_t)m * knew * 16, hipMemcpyHostToDevice, ctx->stream));
+        LSA_CHECK(k_basis_gemm(ctx, LSA_C128, k->n, m, knew, k->V, k->n, k->qdev, m, k->V2, k->n));
+    }
+    LSA_CHECK(k_copy(ctx, LSA_C128, k->n, (char*)k->V + (size_t)m * vb, (char*)k->V2 + (size_t)knew * vb));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    std::swap(k->V, k->V2);
+    return LSA_OK;
+}
+
+int lsa_krylov_ritz_vectors(lsa_ctx* ctx, lsa_krylov* k, int32_t m, int32_t nvec, const void* Y, int32_t ldy, int normalise,
+                            void* X) {
+    if (!ctx || !k || !Y || !X) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_ritz_vectors: null argument");
+    if (m < 1 || m > k->ncv + 1 || nvec < 0 || nvec > k->ncv + 1 || ldy < m) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_ritz_vectors: bad sizes");
+    if (nvec == 0) return LSA_OK;
+    const size_t vb = (size_t)k->n * 16;
+    LSA_CHECK(lsa_ensure_scratch(ctx, 0, (size_t)m * nvec * 16));
+    const cplx* Yh = (const cplx*)Y;
+    cplx* p = (cplx*)ctx->pinned;
+    for (int32_t c = 0; c < nvec; ++c)
+        for (int32_t r = 0; r < m; ++r) p[(size_t)c * m + r] = Yh[(size_t)c * ldy + r];
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(k->qdev, p, (size_t)m * nvec * 16, hipMemcpyHostToDevice, ctx->stream));
+    LSA_CHECK(k_basis_gemm(ctx, LSA_C128, k->n, m, nvec, k->V, k->n, k->qdev, m, k->V2, k->n));
+    if (normalise) {
+        for (int32_t c = 0; c < nvec; ++c) {
+            void* col = (char*)k->V2 + (size_t)c * vb;
+            LSA_CHECK(k_nrm2(ctx, LSA_C128, k->n, col, k->ow.nrm2));
+            LSA_CHECK(k_copy(ctx, LSA_C128, k->n, col, k->w));
+            LSA_CHECK(k_scale_by_inv_norm(ctx, LSA_C128, k->n, k->w, k->ow.nrm2, col));
+        }
+    }
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(X, k->V2, vb * (size_t)nvec, hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return LSA_OK;
+}
+
+int lsa_eig_residuals(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, int32_t nvec, const void* lam, const void* X, double* res) {
+    if (!ctx || !A || !lam || !X || !res || nvec < 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_eig_residuals: bad argument");
+    const int64_t n = A->n;
+    const size_t vb = (size_t)std::max<int64_t>(n, 1) * 16;
+    void *x = nullptr, *ax = nullptr, *mx = nullptr;
+    double* nr = nullptr;
+    int rc = LSA_OK;
+    if (hipMalloc(&x, vb) != hipSuccess || hipMalloc(&ax, vb) != hipSuccess || hipMalloc(&mx, vb) != hipSuccess ||
+        hipMalloc((void**)&nr, 4 * sizeof(double)) != hipSuccess)
+        rc = lsa_set_error(ctx, LSA_ERR_HIP, "lsa_eig_residuals: out of device memory");
+    const cplx* lamh = (const cplx*)lam;
+    for (int32_t c = 0; c < nvec && rc == LSA_OK; ++c) {
+        double nax = 0, nmx = 0, nrr = 0;
+        if (hipMemcpyAsync(x, (const char*)X + (size_t)c * (size_t)n * 16, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            rc = lsa_set_error(ctx, LSA_ERR_HIP, "lsa_eig_residuals: upload failed");
+            break;
+        }
+        rc = k_spmv(ctx, A, LSA_C128, x, ax);
+        if (rc == LSA_OK) rc = M ? k_spmv(ctx, M, LSA_C128, x, mx) : k_copy(ctx, LSA_C128, n, x, mx);
+        if (rc == LSA_OK) rc = device_norm(ctx, LSA_C128, n, ax, nr, &nax);
+        if (rc == LSA_OK) rc = device_norm(ctx, LSA_C128, n, mx, nr, &nmx);
+        const double ml[2] = {-lamh[c].re, -lamh[c].im};
+        if (rc == LSA_OK) rc = k_axpy(ctx, LSA_C128, n, ml, mx, ax);
+        if (rc == LSA_OK) rc = device_norm(ctx, LSA_C128, n, ax, nr, &nrr);
+        const double lmag = std::hypot(lamh[c].re, lamh[c].im);
+        res[c] = nrr / (nax + lmag * nmx + 1e-16);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : {x, ax, mx, (void*)nr})
+        if (p) (void)hipFree(p);
+    return rc;
+}
+
+}  // extern "C"

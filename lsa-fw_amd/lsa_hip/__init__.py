@@ -1,0 +1,439 @@
+"""ctypes binding of ``liblsa_hip.so`` (declared in ``include/lsa_hip.h``).
+
+This is the thin host layer the SLEPc-shaped API in ``Solver/eigen.py`` sits on.  There is no CPU fallback:
+importing works anywhere (so the symbol table can be checked without a GPU), but creating a
+:class:`Context` raises ``RuntimeError`` when the library or a GPU is missing.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from pathlib import Path
+
+import numpy as np
+
+LSA_F64, LSA_C128 = 0, 1
+
+_STATUS_NAMES = {
+    0: "LSA_OK",
+    -1: "LSA_ERR_ARG",
+    -2: "LSA_ERR_HIP",
+    -3: "LSA_ERR_ZERO_PIVOT",
+    -4: "LSA_ERR_DIVERGED",
+    -5: "LSA_ERR_NONFINITE",
+    -6: "LSA_ERR_TIMEOUT",
+    -7: "LSA_ERR_COMM",
+}
+
+LIB_PATH = Path(os.environ.get("LSA_HIP_LIB", Path(__file__).resolve().parent / "liblsa_hip.so"))
+
+
+class LsaError(RuntimeError):
+    """A device-side or numerical failure reported by the library (status < -1)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{_STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class lsa_stats(ctypes.Structure):
+    _fields_ = [
+        ("op_applies", ctypes.c_int64),
+        ("gmres_iters", ctypes.c_int64),
+        ("spmv_calls", ctypes.c_int64),
+        ("sptrsv_calls", ctypes.c_int64),
+        ("last_rel_res", ctypes.c_double),
+        ("max_rel_res", ctypes.c_double),
+        ("seconds_factor", ctypes.c_double),
+        ("seconds_solve", ctypes.c_double),
+    ]
+
+
+class lsa_op_options(ctypes.Structure):
+    _fields_ = [
+        ("ilu_levels", ctypes.c_int32),
+        ("ilu_shift", ctypes.c_double),
+        ("ksp_rtol", ctypes.c_double),
+        ("ksp_restart", ctypes.c_int32),
+        ("ksp_maxit", ctypes.c_int32),
+        ("pc_type", ctypes.c_int32),
+    ]
+
+
+_P = ctypes.c_void_p
+_I32, _I64, _DBL = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+_PP = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); kept in step with include/lsa_hip.h (tests/test_abi.py checks both directions)
+SIGNATURES = {
+    "lsa_ctx_create": (ctypes.c_int, [ctypes.c_int, _PP]),
+    "lsa_ctx_destroy": (None, [_P]),
+    "lsa_last_error": (ctypes.c_char_p, [_P]),
+    "lsa_ctx_synchronize": (ctypes.c_int, [_P]),
+    "lsa_ctx_arch": (ctypes.c_char_p, [_P]),
+    "lsa_vec_create": (ctypes.c_int, [_P, _I64, ctypes.c_int, _PP]),
+    "lsa_vec_destroy": (None, [_P]),
+    "lsa_vec_upload": (ctypes.c_int, [_P, _P, _P]),
+    "lsa_vec_download": (ctypes.c_int, [_P, _P, _P]),
+    "lsa_csr_upload": (ctypes.c_int, [_P, _I32, _I64, _P, _P, _P, ctypes.c_int, _PP]),
+    "lsa_mat_destroy": (None, [_P]),
+    "lsa_mat_download_values": (ctypes.c_int, [_P, _P, _P]),
+    "lsa_csr_axpby": (ctypes.c_int, [_P, _P, _P, _DBL * 2, _DBL * 2, ctypes.c_int, _PP]),
+    "lsa_spmv": (ctypes.c_int, [_P, _P, _P, _P]),
+    "lsa_spmv_transpose": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P]),
+    "lsa_spmv_time": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.POINTER(_DBL)]),
+    "lsa_ilu_create": (ctypes.c_int, [_P, _P, ctypes.c_int, _DBL, _PP]),
+    "lsa_ilu_destroy": (None, [_P]),
+    "lsa_ilu_solve": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P]),
+    "lsa_ilu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
+    "lsa_ilu_download": (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    "lsa_gmres": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, _DBL, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
+    "lsa_op_create": (ctypes.c_int, [_P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
+    "lsa_op_destroy": (None, [_P]),
+    "lsa_op_apply": (ctypes.c_int, [_P, _P, _P, _P]),
+    "lsa_op_stats": (ctypes.c_int, [_P, ctypes.POINTER(lsa_stats)]),
+    "lsa_krylov_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
+    "lsa_krylov_destroy": (None, [_P]),
+    "lsa_krylov_set_start": (ctypes.c_int, [_P, _P, _P]),
+    "lsa_krylov_inject": (ctypes.c_int, [_P, _P, _I32, _P]),
+    "lsa_krylov_extend": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32, ctypes.POINTER(_I32)]),
+    "lsa_krylov_restart": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32]),
+    "lsa_krylov_ritz_vectors": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32, ctypes.c_int, _P]),
+    "lsa_eig_residuals": (ctypes.c_int, [_P, _P, _P, _I32, _P, _P, _P]),
+    "lsa_comm_unique_id": (ctypes.c_int, [_P]),
+    "lsa_comm_init": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P]),
+    "lsa_csr_upload_shard": (ctypes.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, ctypes.c_int, _PP]),
+}
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """dlopen liblsa_hip.so and attach the signatures; raises RuntimeError (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `make -C lsa-fw_amd/csrc` (or __graft_entry__.build()). "
+            "There is no CPU fallback for the eigen path."
+        )
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the header and the library disagree
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt == np.float64:
+        return LSA_F64
+    if dt == np.complex128:
+        return LSA_C128
+    raise ValueError(f"unsupported dtype {dt}: use float64 or complex128")
+
+
+def _np_dtype(code: int):
+    return np.complex128 if code == LSA_C128 else np.float64
+
+
+class Context:
+    """One GPU + one HIP stream.  Not thread-safe (mirrors the single blocking ``eps.solve()`` of the reference)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.lsa_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise RuntimeError(
+                f"lsa_ctx_create(device={device}) failed with {_STATUS_NAMES.get(rc, rc)}: no usable AMD GPU. "
+                "The eigen path has no CPU fallback."
+            )
+        self.handle = h
+        self.device = device
+
+    @property
+    def arch(self) -> str:
+        return self._lib.lsa_ctx_arch(self.handle).decode()
+
+    def check(self, rc: int) -> None:
+        if rc == 0:
+            return
+        msg = self._lib.lsa_last_error(self.handle).decode(errors="replace")
+        if rc == -1:
+            raise ValueError(msg)
+        raise LsaError(rc, msg)
+
+    def synchronize(self) -> None:
+        self.check(self._lib.lsa_ctx_synchronize(self.handle))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self._lib.lsa_ctx_destroy(self.handle)
+            self.handle = None
+
+    # multi-GPU bootstrap -------------------------------------------------------------------------------
+    def unique_id(self) -> bytes:
+        buf = ctypes.create_string_buffer(128)
+        rc = self._lib.lsa_comm_unique_id(buf)
+        if rc != 0:
+            raise LsaError(rc, "RCCL unavailable")
+        return buf.raw
+
+    def comm_init(self, nranks: int, rank: int, uid: bytes) -> None:
+        buf = ctypes.create_string_buffer(uid, 128)
+        self.check(self._lib.lsa_comm_init(self.handle, nranks, rank, buf))
+
+
+class DeviceVector:
+    def __init__(self, ctx: Context, n: int, dtype=np.complex128):
+        self.ctx = ctx
+        self.n = int(n)
+        self.dtype = np.dtype(dtype)
+        h = ctypes.c_void_p()
+        ctx.check(ctx._lib.lsa_vec_create(ctx.handle, self.n, _dtype_code(dtype), ctypes.byref(h)))
+        self.handle = h
+
+    @classmethod
+    def from_numpy(cls, ctx: Context, a: np.ndarray) -> "DeviceVector":
+        a = np.ascontiguousarray(a)
+        if a.dtype not in (np.float64, np.complex128):
+            a = a.astype(np.complex128 if a.dtype.kind == "c" else np.float64)
+        v = cls(ctx, a.shape[0], a.dtype)
+        v.upload(a)
+        return v
+
+    def upload(self, a: np.ndarray) -> None:
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.shape != (self.n,):
+            raise ValueError(f"expected shape ({self.n},), got {a.shape}")
+        self.ctx.check(self.ctx._lib.lsa_vec_upload(self.ctx.handle, self.handle, _ptr(a)))
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=self.dtype)
+        self.ctx.check(self.ctx._lib.lsa_vec_download(self.ctx.handle, self.handle, _ptr(out)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx._lib.lsa_vec_destroy(self.handle)
+            self.handle = None
+
+
+class CsrMatrix:
+    """CSR matrix resident in HBM (int32 indices, float64 or complex128 values, sorted columns)."""
+
+    def __init__(self, ctx: Context, handle, shape, nnz: int, dtype, keep=()):
+        self.ctx, self.handle, self.shape, self.nnz, self.dtype = ctx, handle, shape, int(nnz), np.dtype(dtype)
+        self._keep = keep  # matrices whose index arrays this one shares
+
+    @classmethod
+    def from_scipy(cls, ctx: Context, A) -> "CsrMatrix":
+        import scipy.sparse as sp
+
+        A = sp.csr_matrix(A)
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("lsa_csr_upload handles square matrices; use from_scipy_shard for row blocks")
+        if not A.has_sorted_indices:
+            A = A.copy()
+            A.sort_indices()
+        dt = np.complex128 if A.dtype.kind == "c" else np.float64
+        rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        ci = np.ascontiguousarray(A.indices, dtype=np.int32)
+        val = np.ascontiguousarray(A.data, dtype=dt)
+        h = ctypes.c_void_p()
+        ctx.check(
+            ctx._lib.lsa_csr_upload(ctx.handle, A.shape[0], A.nnz, _ptr(rp), _ptr(ci), _ptr(val), _dtype_code(dt), ctypes.byref(h))
+        )
+        return cls(ctx, h, A.shape, A.nnz, dt)
+
+    @classmethod
+    def from_scipy_shard(cls, ctx: Context, A_rows, n_global: int, row0: int) -> "CsrMatrix":
+        import scipy.sparse as sp
+
+        A = sp.csr_matrix(A_rows)
+        A.sort_indices()
+        dt = np.complex128 if A.dtype.kind == "c" else np.float64
+        rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        ci = np.ascontiguousarray(A.indices, dtype=np.int32)
+        val = np.ascontiguousarray(A.data, dtype=dt)
+        h = ctypes.c_void_p()
+        ctx.check(
+            ctx._lib.lsa_csr_upload_shard(
+                ctx.handle, n_global, row0, row0 + A.shape[0], A.nnz, _ptr(rp), _ptr(ci), _ptr(val), _dtype_code(dt), ctypes.byref(h)
+            )
+        )
+        return cls(ctx, h, (A.shape[0], n_global), A.nnz, dt)
+
+    def axpby(self, other: "CsrMatrix", alpha: complex, beta: complex, dtype=None) -> "CsrMatrix":
+        """alpha*self + beta*other on the shared pattern (MatAXPY, Solver/eigen2.py:110-111)."""
+        alpha, beta = complex(alpha), complex(beta)
+        if dtype is None:
+            cplx = alpha.imag != 0 or beta.imag != 0 or self.dtype.kind == "c" or other.dtype.kind == "c"
+            dtype = np.complex128 if cplx else np.float64
+        h = ctypes.c_void_p()
+        self.ctx.check(
+            self.ctx._lib.lsa_csr_axpby(
+                self.ctx.handle, self.handle, other.handle, (_DBL * 2)(alpha.real, alpha.imag), (_DBL * 2)(beta.real, beta.imag),
+                _dtype_code(dtype), ctypes.byref(h),
+            )
+        )
+        return CsrMatrix(self.ctx, h, self.shape, self.nnz, dtype, keep=(self, other))
+
+    def values(self) -> np.ndarray:
+        out = np.empty(self.nnz, dtype=self.dtype)
+        self.ctx.check(self.ctx._lib.lsa_mat_download_values(self.ctx.handle, self.handle, _ptr(out)))
+        return out
+
+    def matvec(self, x: DeviceVector, y: DeviceVector) -> None:
+        self.ctx.check(self.ctx._lib.lsa_spmv(self.ctx.handle, self.handle, x.handle, y.handle))
+
+    def rmatvec(self, x: DeviceVector, y: DeviceVector, conj: bool = True) -> None:
+        self.ctx.check(self.ctx._lib.lsa_spmv_transpose(self.ctx.handle, self.handle, int(conj), x.handle, y.handle))
+
+    def time_matvec(self, x: DeviceVector, y: DeviceVector, iters: int) -> float:
+        """Mean milliseconds per SpMV launch over ``iters`` back-to-back launches (HIP events on the library's stream)."""
+        ms = _DBL(0.0)
+        self.ctx.check(self.ctx._lib.lsa_spmv_time(self.ctx.handle, self.handle, x.handle, y.handle, int(iters), ctypes.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx._lib.lsa_mat_destroy(self.handle)
+            self.handle = None
+
+
+class Ilu:
+    """ILU(k) factors + triangular-solve schedule on the device."""
+
+    def __init__(self, ctx: Context, C: CsrMatrix, levels: int = 0, shift_tol: float = 0.0):
+        self.ctx, self._C = ctx, C
+        h = ctypes.c_void_p()
+        ctx.check(ctx._lib.lsa_ilu_create(ctx.handle, C.handle, int(levels), float(shift_tol), ctypes.byref(h)))
+        self.handle = h
+        self.n = C.shape[0]
+        self.dtype = C.dtype
+
+    def info(self) -> dict:
+        nnz, ll, lu, ns = _I64(0), _I32(0), _I32(0), _I32(0)
+        self.ctx._lib.lsa_ilu_info(self.handle, ctypes.byref(nnz), ctypes.byref(ll), ctypes.byref(lu), ctypes.byref(ns))
+        return {"nnz": nnz.value, "levels_lower": ll.value, "levels_upper": lu.value, "nshift": ns.value}
+
+    def solve(self, b: DeviceVector, x: DeviceVector, which: int = 2) -> None:
+        self.ctx.check(self.ctx._lib.lsa_ilu_solve(self.ctx.handle, self.handle, int(which), b.handle, x.handle))
+
+    def factors(self):
+        """(rowptr, col, val) of the combined L\\U factor."""
+        nnz = self.info()["nnz"]
+        rp = np.empty(self.n + 1, dtype=np.int32)
+        ci = np.empty(nnz, dtype=np.int32)
+        val = np.empty(nnz, dtype=self.dtype)
+        self.ctx.check(self.ctx._lib.lsa_ilu_download(self.ctx.handle, self.handle, _ptr(rp), _ptr(ci), _ptr(val)))
+        return rp, ci, val
+
+    def __del__(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx._lib.lsa_ilu_destroy(self.handle)
+            self.handle = None
+
+
+def gmres(ctx: Context, C: CsrMatrix, pc: Ilu | None, b: DeviceVector, x: DeviceVector, *, rtol=1e-10, restart=200, maxit=2000,
+          use_x0=False):
+    """Right-preconditioned GMRES on the device; returns (iterations, relative residual)."""
+    its, rr = _I32(0), _DBL(0.0)
+    rc = ctx._lib.lsa_gmres(ctx.handle, C.handle, pc.handle if pc else None, b.handle, x.handle, int(use_x0), float(rtol), int(restart),
+                            int(maxit), ctypes.byref(its), ctypes.byref(rr))
+    ctx.check(rc)
+    return its.value, rr.value
+
+
+class ShiftInvertOperator:
+    """``y = (A - sigma M)^-1 M x`` (mode 0, iSTType.SINVERT) or ``y = M^-1 (A - sigma M) x`` (mode 1, iSTType.SHIFT)."""
+
+    def __init__(self, ctx: Context, A: CsrMatrix, M: CsrMatrix | None, sigma: complex, *, mode: int = 0, ilu_levels: int = 0,
+                 ilu_shift: float = 0.0, ksp_rtol: float = 1e-11, ksp_restart: int = 200, ksp_maxit: int = 2000, pc_type: int = 1):
+        self.ctx, self._A, self._M = ctx, A, M
+        sigma = complex(sigma)
+        opts = lsa_op_options(int(ilu_levels), float(ilu_shift), float(ksp_rtol), int(ksp_restart), int(ksp_maxit), int(pc_type))
+        h = ctypes.c_void_p()
+        ctx.check(
+            ctx._lib.lsa_op_create(ctx.handle, A.handle, M.handle if M is not None else None, (_DBL * 2)(sigma.real, sigma.imag),
+                                   int(mode), ctypes.byref(opts), ctypes.byref(h))
+        )
+        self.handle = h
+        self.n = A.shape[0]
+        self.sigma = sigma
+        self.mode = mode
+
+    def apply(self, x: DeviceVector, y: DeviceVector) -> None:
+        self.ctx.check(self.ctx._lib.lsa_op_apply(self.ctx.handle, self.handle, x.handle, y.handle))
+
+    def stats(self) -> dict:
+        st = lsa_stats()
+        self.ctx._lib.lsa_op_stats(self.handle, ctypes.byref(st))
+        return {name: getattr(st, name) for name, _ in lsa_stats._fields_}
+
+    def __del__(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx._lib.lsa_op_destroy(self.handle)
+            self.handle = None
+
+
+class KrylovBasis:
+    """Arnoldi basis in HBM + the recurrences Krylov-Schur needs.  Implements the backend protocol of
+    :func:`lsa_hip.krylov_schur.krylov_schur` (``n``, ``ncv``, ``inject``, ``extend``, ``restart``, ``ritz_vectors``)."""
+
+    def __init__(self, ctx: Context, op: ShiftInvertOperator, ncv: int):
+        self.ctx, self._op = ctx, op
+        self.n, self.ncv = op.n, int(ncv)
+        h = ctypes.c_void_p()
+        ctx.check(ctx._lib.lsa_krylov_create(ctx.handle, op.handle, self.ncv, ctypes.byref(h)))
+        self.handle = h
+
+    def inject(self, j: int, v: np.ndarray) -> None:
+        v = np.ascontiguousarray(v, dtype=np.complex128)
+        if v.shape != (self.n,):
+            raise ValueError(f"start vector must have shape ({self.n},)")
+        self.ctx.check(self.ctx._lib.lsa_krylov_inject(self.ctx.handle, self.handle, int(j), _ptr(v)))
+
+    def extend(self, j0: int, j1: int, H: np.ndarray) -> int:
+        """Arnoldi steps j0..j1-1 writing columns of the Fortran-ordered (ncv+1, ncv) complex H; returns the
+        breakdown step or -1."""
+        assert H.flags.f_contiguous and H.dtype == np.complex128
+        bd = _I32(-1)
+        self.ctx.check(self.ctx._lib.lsa_krylov_extend(self.ctx.handle, self.handle, int(j0), int(j1), _ptr(H), H.shape[0], ctypes.byref(bd)))
+        return bd.value
+
+    def restart(self, m: int, Q: np.ndarray) -> None:
+        Q = np.asfortranarray(Q, dtype=np.complex128)
+        self.ctx.check(self.ctx._lib.lsa_krylov_restart(self.ctx.handle, self.handle, int(m), Q.shape[1], _ptr(Q), Q.shape[0]))
+
+    def ritz_vectors(self, m: int, Y: np.ndarray, normalise: bool = True) -> np.ndarray:
+        Y = np.asfortranarray(Y, dtype=np.complex128)
+        X = np.empty((self.n, Y.shape[1]), dtype=np.complex128, order="F")
+        self.ctx.check(
+            self.ctx._lib.lsa_krylov_ritz_vectors(self.ctx.handle, self.handle, int(m), Y.shape[1], _ptr(Y), Y.shape[0], int(normalise), _ptr(X))
+        )
+        return X
+
+    def __del__(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx._lib.lsa_krylov_destroy(self.handle)
+            self.handle = None
+
+
+def eig_residuals(ctx: Context, A: CsrMatrix, M: CsrMatrix | None, lam: np.ndarray, X: np.ndarray) -> np.ndarray:
+    """Relative residuals of Solver/eigen2.py:48-56, evaluated on the device."""
+    lam = np.ascontiguousarray(lam, dtype=np.complex128)
+    X = np.asfortranarray(X, dtype=np.complex128)
+    res = np.empty(lam.shape[0], dtype=np.float64)
+    ctx.check(ctx._lib.lsa_eig_residuals(ctx.handle, A.handle, M.handle if M is not None else None, lam.shape[0], _ptr(lam), _ptr(X), _ptr(res)))
+    return res

@@ -275,7 +275,7 @@ class iEpsSolver:
 
     def __init__(self, A=None, M=None, comm=None, *, device: int = 0, ksp_type: KSPType = KSPType.GMRES,
                  ksp_rtol: float | None = None, restart: int = 200, ksp_max_it: int = 4000, ilu_levels: int | None = None,
-                 ilu_shift: float = 1e-12, ordering: str = "rcm", seed: int = 0) -> None:
+                 ilu_shift: float = 0.0, ordering: str = "rcm", seed: int = 0) -> None:
         if M is not None and A is None:
             raise ValueError("Cannot set right-hand operator M without left-hand operator A.")
         self._A = self._M = None

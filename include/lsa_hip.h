@@ -96,6 +96,11 @@ int lsa_spmv_time(lsa_ctx *ctx, const lsa_mat *A, const lsa_vec *x, lsa_vec *y, 
  * and the dependency schedule are computed on the host, the numeric factorisation on the device. */
 int lsa_ilu_create(lsa_ctx *ctx, const lsa_mat *C, int levels, double shift_tol, lsa_ilu **out);
 void lsa_ilu_destroy(lsa_ilu *pc);
+/* Triangular-solve algorithm: 0 = one launch per dependency level, 1 = sync-free (one launch, row hand-offs through
+ * the solution vector), 2 = blocked (diagonal blocks of block_size rows inverted into dense triangles on the device,
+ * 2 launches per block replayed from a hipGraph).  lsa_ilu_create picks 2 for narrow dependency DAGs (2D FEM) when
+ * the 2 * n * block_size scalars fit, else 1.  All three give the same solve up to summation order. */
+int lsa_ilu_set_algorithm(lsa_ctx *ctx, lsa_ilu *pc, int algo, int32_t block_size);
 /* which: 0 = x = L^-1 b (unit lower), 1 = x = U^-1 b, 2 = x = U^-1 L^-1 b (MatSolve) */
 int lsa_ilu_solve(lsa_ctx *ctx, lsa_ilu *pc, int which, const lsa_vec *b, lsa_vec *x);
 /* introspection for tests: nnz of the factor pattern, number of dependency levels (lower, upper),

@@ -178,9 +178,19 @@ struct lsa_ilu {
     int32_t nshift;
     int32_t* flag;   // device int[4]: abort / error / shift count / spare
     int sptrsv_blocks_l, sptrsv_blocks_u;  // workgroups used by the sync-free solves
-    int algo;                               // 0 = level-by-level launches, 1 = sync-free
+    int algo;                               // 0 = level-by-level launches, 1 = sync-free, 2 = blocked (inverted diagonal blocks)
     void* tmp;                              // device vector (intermediate of L then U), sized on demand
     int tmp_dtype;
+    // blocked form (sptrsv_block.hip)
+    int32_t blk_B = 0, blk_nb = 0;
+    int32_t *lsplit = nullptr, *usplit = nullptr;  // device: first in-block L entry / first out-of-block U entry per row
+    void *linv = nullptr, *uinv = nullptr;         // device: n x B row-major dense inverses of the diagonal blocks
+    void *blk_t[2] = {nullptr, nullptr}, *blk_y[2] = {nullptr, nullptr};      // per vector dtype: work vectors
+    void *blk_in[2] = {nullptr, nullptr}, *blk_out[2] = {nullptr, nullptr};  // fixed graph input / output
+    void* blk_graph[2] = {nullptr, nullptr};                                 // hipGraphExec_t of the full apply
 };
 
 int ilu_solve_dev(lsa_ctx* ctx, lsa_ilu* pc, int which, int vdtype, const void* b, void* x);
+int blk_setup(lsa_ctx* ctx, lsa_ilu* pc, int32_t B);
+int blk_solve(lsa_ctx* ctx, lsa_ilu* pc, int which, int vdtype, const void* b, void* x);
+void blk_release(lsa_ilu* pc);

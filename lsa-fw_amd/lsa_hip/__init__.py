@@ -85,6 +85,7 @@ SIGNATURES = {
     "lsa_spmv_time": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.POINTER(_DBL)]),
     "lsa_ilu_create": (ctypes.c_int, [_P, _P, ctypes.c_int, _DBL, _PP]),
     "lsa_ilu_destroy": (None, [_P]),
+    "lsa_ilu_set_algorithm": (ctypes.c_int, [_P, _P, ctypes.c_int, _I32]),
     "lsa_ilu_solve": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P]),
     "lsa_ilu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
     "lsa_ilu_download": (ctypes.c_int, [_P, _P, _P, _P, _P]),
@@ -326,6 +327,10 @@ class Ilu:
         nnz, ll, lu, ns = _I64(0), _I32(0), _I32(0), _I32(0)
         self.ctx._lib.lsa_ilu_info(self.handle, ctypes.byref(nnz), ctypes.byref(ll), ctypes.byref(lu), ctypes.byref(ns))
         return {"nnz": nnz.value, "levels_lower": ll.value, "levels_upper": lu.value, "nshift": ns.value}
+
+    def set_algorithm(self, algo: int, block_size: int = 0) -> None:
+        """0 = level launches, 1 = sync-free, 2 = blocked with inverted diagonal blocks (see include/lsa_hip.h)."""
+        self.ctx.check(self.ctx._lib.lsa_ilu_set_algorithm(self.ctx.handle, self.handle, int(algo), int(block_size)))
 
     def solve(self, b: DeviceVector, x: DeviceVector, which: int = 2) -> None:
         self.ctx.check(self.ctx._lib.lsa_ilu_solve(self.ctx.handle, self.handle, int(which), b.handle, x.handle))

@@ -134,19 +134,22 @@ def test_ilu_factor_matches_oracle(hip_ctx, shifted5k, levels):
     assert info["levels_lower"] > 1 and info["levels_upper"] > 1
 
 
-@pytest.mark.parametrize("vec_c", [True])
+@pytest.mark.parametrize("algo,block", [(0, 0), (1, 0), (2, 256), (2, 1024)])
 @pytest.mark.parametrize("which", [0, 1, 2])
-def test_sptrsv_matches_oracle(hip_ctx, shifted5k, which, vec_c):
+def test_sptrsv_matches_oracle(hip_ctx, shifted5k, which, algo, block):
     import lsa_hip
     from oracle import kernels
 
     Cp, _ = shifted5k
     ref = kernels.ILU0(kernels.iluk_pattern(Cp, 1), 0.0)
     pc = lsa_hip.Ilu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, Cp), levels=1)
-    b = _rng_vec(Cp.shape[0], 21, vec_c)
+    pc.set_algorithm(algo, block)
+    b = _rng_vec(Cp.shape[0], 21, True)
     db = lsa_hip.DeviceVector.from_numpy(hip_ctx, b)
     dx = lsa_hip.DeviceVector(hip_ctx, Cp.shape[0], np.complex128)
     pc.solve(db, dx, which)
+    if which == 2:  # a second apply replays the captured graph (blocked form)
+        pc.solve(db, dx, which)
     want = [ref.lower, ref.upper, ref.solve][which](b)
     got = dx.numpy()
     assert np.all(np.isfinite(got))

@@ -1,0 +1,246 @@
+"""Headline benchmark: converged eigenpairs/sec (k=20, shift-invert) + SpMV HBM GB/s vs roofline  (BASELINE.json).
+
+One "step" = one complete shift-invert eigensolve of the synthetic cylinder pair (A, M) that is already resident in
+HBM: build C = A - sigma M on the device, ILU(k) symbolic + numeric factorisation, Krylov-Schur (ncv = 80) with an
+ILU-preconditioned GMRES solve per Arnoldi step, until k = 20 pairs pass the relative-residual test.  A pair counts
+as converged iff ||A v - lam M v|| / (||A v|| + |lam| ||M v||) <= 1e-8 (formula of Solver/eigen2.py:48-56), checked on
+the device after the timed region.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+N > 1 (this round): every rank solves the same pair around its own shift of the reference's Re-sweep table
+(.examples/eigenvalues.py:37-49), the embarrassingly parallel "replicas" layout of SURVEY.md section 8e; no data-path
+collective.  The row-sharded single-problem layout is described in DESIGN.md.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured on the SpMV kernel (the kernel the metric names) on SROOF, a
+~1.5e8-nnz CSR with the cylinder-flow row pattern that does not fit the 256 MB Infinity Cache; `cpu_baseline` is the
+oracle (scipy ARPACK + SuperLU, the algorithm Solver/eigen2.py states) on the same S30k problem on the host cores.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path[:0] = [str(ROOT), str(ROOT / "lsa-fw_amd")]
+
+import numpy as np  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
+
+# Re = 40..90 shifts of the reference sweep; index 2 is Re = 50
+SWEEP_SIGMAS = (
+    -0.03 + 0.7197388769374216j, 0.7316769290210628j, 0.018 + 0.7379601143282424j, 0.03 + 0.742986662573986j,
+    0.05 + 0.744243299635422j, 0.061 + 0.7461282552275759j, 0.072 + 0.7461282552275759j, 0.085 + 0.744557458900781j,
+)
+RESIDUAL_TOL = 1e-8
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(msg: str) -> None:
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def build_solver(es, sigma, args, device):
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    cfg = EigensolverConfig(num_eig=args.k, atol=args.atol, ncv=args.ncv, max_it=500)
+    solver = EigenSolver(es.A, es.M, cfg, check_hermitian=False, ilu_levels=args.ilu_levels, restart=args.restart, device=device)
+    solver.solver.set_st_type(iSTType.SINVERT)
+    solver.solver.set_target(sigma)
+    solver.solver.set_st_pc_type(PreconditionerType.ILU)
+    return solver
+
+
+def spmv_roofline(args, device):
+    """SpMV on SROOF: achieved algorithmic GB/s from HIP-event time per launch (library stream)."""
+    import lsa_hip
+    from oracle import fem
+    from Solver.utils import pivot_safe_rcm
+
+    t0 = time.time()
+    es = fem.cylinder_case(args.roof_case)
+    C = sp.csr_matrix((es.A.data - fem.SIGMA_RE50 * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+    perm = pivot_safe_rcm(C)
+    C = C[perm][:, perm].tocsr()
+    C.sort_indices()
+    n1, nnz1, reps = C.shape[0], C.nnz, args.roof_reps
+    # block-diagonal replicas: same row-degree histogram and column locality, footprint beyond the Infinity Cache
+    rp = np.concatenate([[0], (C.indptr[1:][None, :] + (np.arange(reps) * nnz1)[:, None]).ravel()]).astype(np.int32)
+    ci = (C.indices[None, :] + (np.arange(reps, dtype=np.int64) * n1)[:, None]).ravel().astype(np.int32)
+    val = np.tile(C.data, reps)
+    big = sp.csr_matrix((val, ci, rp), shape=(n1 * reps, n1 * reps))
+    n, nnz = big.shape[0], big.nnz
+    log(f"SROOF = {reps} x {args.roof_case}: n={n} nnz={nnz} ({(20 * nnz + 36 * n) / 1e9:.2f} GB algorithmic, c128) built in {time.time() - t0:.1f}s")
+    ctx = lsa_hip.Context(device)
+    out = {}
+    try:
+        rng = np.random.default_rng(0)
+        x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+        dC = lsa_hip.CsrMatrix.from_scipy(ctx, big)
+        dx = lsa_hip.DeviceVector.from_numpy(ctx, x)
+        dy = lsa_hip.DeviceVector(ctx, n, np.complex128)
+        dC.time_matvec(dx, dy, 5)
+        ms = dC.time_matvec(dx, dy, args.roof_iters)
+        bytes_c = 20.0 * nnz + 36.0 * n  # 16 B value + 4 B column per entry; 4 B rowptr + 16 B x + 16 B y per row
+        out["c128"] = {"ms": ms, "bytes": bytes_c, "gbs": bytes_c / ms / 1e6}
+        # the f64 variant of the same pattern (real sigma path): 12 nnz + 20 n bytes
+        bigr = sp.csr_matrix((np.ascontiguousarray(val.real), ci, rp), shape=big.shape)
+        del dC
+        dR = lsa_hip.CsrMatrix.from_scipy(ctx, bigr)
+        dxr = lsa_hip.DeviceVector.from_numpy(ctx, x.real.copy())
+        dyr = lsa_hip.DeviceVector(ctx, n, np.float64)
+        dR.time_matvec(dxr, dyr, 5)
+        msr = dR.time_matvec(dxr, dyr, args.roof_iters)
+        bytes_r = 12.0 * nnz + 20.0 * n
+        out["f64"] = {"ms": msr, "bytes": bytes_r, "gbs": bytes_r / msr / 1e6}
+        out["n"], out["nnz"] = n, nnz
+        del dR, dx, dy, dxr, dyr
+    finally:
+        import gc
+
+        gc.collect()
+        ctx.close()
+    return out
+
+
+def cpu_baseline(es, sigma, args):
+    """The oracle (scipy ARPACK + SuperLU) on the same problem, same k / ncv / tolerance, on the host cores."""
+    from oracle import shift_invert
+
+    t0 = time.perf_counter()
+    lam, V, res, info = shift_invert.solve(es.A, es.M, sigma, k=args.k, tol=args.atol, ncv=args.ncv, return_info=True)
+    dt = time.perf_counter() - t0
+    nconv = int(np.sum(res <= RESIDUAL_TOL))
+    return {
+        "value": nconv / dt, "unit": "eigenpairs/s", "cores": 1, "kind": "port",
+        "sample": f"one full solve of the same {args.case} problem (k={args.k}, ncv={args.ncv}, tol={args.atol:g}): {dt:.1f} s "
+                  f"(SuperLU factor {info['seconds_factor']:.1f} s, {info['op_applies']} applies), scipy ARPACK+SuperLU, "
+                  f"single-threaded; host has {os.cpu_count()} cores; SLEPc itself is not installed",
+    }, lam
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--case", default="S30k")
+    ap.add_argument("--k", type=int, default=20)
+    ap.add_argument("--ncv", type=int, default=80)
+    ap.add_argument("--atol", type=float, default=1e-10)
+    ap.add_argument("--ilu-levels", type=int, default=2)
+    ap.add_argument("--restart", type=int, default=200)
+    ap.add_argument("--roof-case", default="S500k")
+    ap.add_argument("--roof-reps", type=int, default=10)
+    ap.add_argument("--roof-iters", type=int, default=50)
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+    device = local_rank if world > 1 else 0
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an AMD GPU (no CPU fallback)")
+
+    from oracle import fem
+
+    es = fem.cylinder_case(args.case)
+    sigma = SWEEP_SIGMAS[(2 + rank) % len(SWEEP_SIGMAS)]
+    log(f"rank {rank}/{world}: {args.case} n={es.n} nnz={es.A.nnz} sigma={sigma}")
+    solver = build_solver(es, sigma, args, device)
+    solver.solver.prepare()  # ordering + upload: (A, M) now resident in HBM
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.solve()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        solver.solve()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # count pairs that pass the true residual test (device evaluation, after the timed region)
+    res = solver.solver.residuals()
+    nconv = int(np.sum(res[: args.k] <= RESIDUAL_TOL))
+    stats = solver.solver.stats
+    total_pairs = float(nconv * args.steps)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        p = torch.tensor([total_pairs], dtype=torch.float64, device="cuda")
+        dist.all_reduce(p, op=dist.ReduceOp.SUM)
+        total_pairs = float(p.item())
+    lam_gpu = np.array([solver.solver.get_eigenvalue(i) for i in range(min(args.k, solver.solver.get_num_converged()))])
+    solver.solver.release()
+
+    if rank == 0:
+        out = {
+            "metric": "converged eigenpairs/sec (k=20, shift-invert)",
+            "value": total_pairs / elapsed,
+            "unit": "eigenpairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "c128",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.case}: synthetic 2D cylinder-flow Taylor-Hood pair, n={es.n}, nnz={es.A.nnz}, Re=50, "
+                            f"sigma={sigma.real:g}{sigma.imag:+g}j, k={args.k}, ncv={args.ncv}, outer tol {args.atol:g}, "
+                            f"ILU({args.ilu_levels})-GMRES({args.restart}) inner solves, blocked SpTRSV",
+                "layout": "replicas" if world > 1 else "single GPU",
+                "converged_per_solve": nconv,
+                "max_residual": float(res[: args.k].max()) if len(res) else None,
+                "op_applies_per_solve": stats.get("op_applies"),
+                "gmres_iters_per_solve": stats.get("gmres_iters"),
+                "seconds_factor": stats.get("seconds_factor"),
+            },
+        }
+        if not args.no_roofline:
+            roof = spmv_roofline(args, device)
+            out["roofline"] = {
+                "bound": "hbm", "achieved": roof["c128"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": roof["c128"]["gbs"] / HBM_PEAK_GBS, "traffic": None,
+                "kernel": "spmv_subwave_kernel<cplx,cplx> on SROOF", "ms_per_launch": roof["c128"]["ms"],
+                "algorithmic_bytes_per_launch": roof["c128"]["bytes"], "n": roof["n"], "nnz": roof["nnz"],
+                "f64": {"achieved": roof["f64"]["gbs"], "frac": roof["f64"]["gbs"] / HBM_PEAK_GBS, "ms_per_launch": roof["f64"]["ms"]},
+            }
+        if not args.no_cpu_baseline:
+            base, lam_cpu = cpu_baseline(es, sigma, args)
+            out["cpu_baseline"] = base
+            if len(lam_gpu):
+                out["config"]["max_rel_eig_diff_vs_cpu"] = float(max(np.min(np.abs(lam_gpu - r)) / abs(r) for r in lam_cpu[: len(lam_gpu)]))
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

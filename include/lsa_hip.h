@@ -103,6 +103,8 @@ void lsa_ilu_destroy(lsa_ilu *pc);
 int lsa_ilu_set_algorithm(lsa_ctx *ctx, lsa_ilu *pc, int algo, int32_t block_size);
 /* which: 0 = x = L^-1 b (unit lower), 1 = x = U^-1 b, 2 = x = U^-1 L^-1 b (MatSolve) */
 int lsa_ilu_solve(lsa_ctx *ctx, lsa_ilu *pc, int which, const lsa_vec *b, lsa_vec *x);
+/* `iters` back-to-back solves bracketed by HIP events on the context's stream; *avg_ms = mean per solve */
+int lsa_ilu_solve_time(lsa_ctx *ctx, lsa_ilu *pc, int which, const lsa_vec *b, lsa_vec *x, int iters, double *avg_ms);
 /* introspection for tests: nnz of the factor pattern, number of dependency levels (lower, upper),
  * number of shifted pivots */
 int lsa_ilu_info(const lsa_ilu *pc, int64_t *nnz, int32_t *levels_lower, int32_t *levels_upper, int32_t *nshift);

@@ -572,6 +572,20 @@ int lsa_ilu_solve(lsa_ctx* ctx, lsa_ilu* pc, int which, const lsa_vec* b, lsa_ve
     return ilu_check_abort(ctx, pc);
 }
 
+int lsa_ilu_solve_time(lsa_ctx* ctx, lsa_ilu* pc, int which, const lsa_vec* b, lsa_vec* x, int iters, double* avg_ms) {
+    if (!ctx || !pc || !b || !x || !avg_ms || iters <= 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ilu_solve_time: bad argument");
+    if (b->n != pc->n || x->n != pc->n || b->dtype != x->dtype) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ilu_solve_time: vector shape/dtype mismatch");
+    LSA_CHECK(ilu_solve_dev(ctx, pc, which, b->dtype, b->d, x->d));  // warm-up (captures the graph of the blocked form)
+    LSA_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < iters; ++i) LSA_CHECK(ilu_solve_dev(ctx, pc, which, b->dtype, b->d, x->d));
+    LSA_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    LSA_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_ms = (double)ms / iters;
+    return ilu_check_abort(ctx, pc);
+}
+
 int lsa_ilu_info(const lsa_ilu* pc, int64_t* nnz, int32_t* levels_lower, int32_t* levels_upper, int32_t* nshift) {
     if (!pc) return LSA_ERR_ARG;
     if (nnz) *nnz = pc->nnz;

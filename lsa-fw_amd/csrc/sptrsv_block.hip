@@ -159,8 +159,16 @@ int solve_blocked(lsa_ctx* ctx, lsa_ilu* pc, int which, const void* b, void* x) 
     if (which == 0) launch_factor<MT, VT, true>(ctx, pc, (const VT*)b, (VT*)x, t);
     else if (which == 1) launch_factor<MT, VT, false>(ctx, pc, (const VT*)b, (VT*)x, t);
     else {
-        // full apply through a captured graph on fixed buffers
         VT *in = (VT*)pc->blk_in[vd], *y = (VT*)pc->blk_y[vd], *out = (VT*)pc->blk_out[vd];
+        static const bool use_graph = !(getenv("LSA_SPTRSV_GRAPH") && atoi(getenv("LSA_SPTRSV_GRAPH")) == 0);
+        if (!use_graph) {  // plain launches (rocprofv3's kernel trace cannot follow graph replays on ROCm 7.2)
+            launch_factor<MT, VT, true>(ctx, pc, (const VT*)b, y, t);
+            launch_factor<MT, VT, false>(ctx, pc, y, (VT*)x, t);
+            hipError_t le = hipGetLastError();
+            if (le != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "blocked SpTRSV launch failed: %s", hipGetErrorString(le));
+            return LSA_OK;
+        }
+        // full apply through a captured graph on fixed buffers
         if (!pc->blk_graph[vd]) {
             hipGraph_t graph = nullptr;
             LSA_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));

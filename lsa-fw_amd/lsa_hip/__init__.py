@@ -87,6 +87,7 @@ SIGNATURES = {
     "lsa_ilu_destroy": (None, [_P]),
     "lsa_ilu_set_algorithm": (ctypes.c_int, [_P, _P, ctypes.c_int, _I32]),
     "lsa_ilu_solve": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P]),
+    "lsa_ilu_solve_time": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.POINTER(_DBL)]),
     "lsa_ilu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
     "lsa_ilu_download": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "lsa_gmres": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, _DBL, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
@@ -334,6 +335,12 @@ class Ilu:
 
     def solve(self, b: DeviceVector, x: DeviceVector, which: int = 2) -> None:
         self.ctx.check(self.ctx._lib.lsa_ilu_solve(self.ctx.handle, self.handle, int(which), b.handle, x.handle))
+
+    def time_solve(self, b: DeviceVector, x: DeviceVector, iters: int, which: int = 2) -> float:
+        """Mean milliseconds per triangular solve (HIP events on the library's stream)."""
+        ms = _DBL(0.0)
+        self.ctx.check(self.ctx._lib.lsa_ilu_solve_time(self.ctx.handle, self.handle, int(which), b.handle, x.handle, int(iters), ctypes.byref(ms)))
+        return ms.value
 
     def factors(self):
         """(rowptr, col, val) of the combined L\\U factor."""

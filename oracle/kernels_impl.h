@@ -45,7 +45,7 @@ int FN(orc_ilu0)(int n, const int *rp, const int *ci, SCALAR *v, int *diag, doub
             }
         }
         double mag = ABS(v[d]);
-        if (!(mag >= shift_tol)) {
+        if (!(mag >= shift_tol) || mag == 0.0) {
             if (shift_tol <= 0.0) { rc = -(i + 1); }
             else {
                 v[d] = (mag > 0.0) ? v[d] / mag * shift_tol : (SCALAR)shift_tol;

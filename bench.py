@@ -136,7 +136,7 @@ def main() -> None:
     ap.add_argument("--ncv", type=int, default=80)
     ap.add_argument("--atol", type=float, default=1e-10)
     ap.add_argument("--ilu-levels", type=int, default=2)
-    ap.add_argument("--restart", type=int, default=200)
+    ap.add_argument("--restart", type=int, default=1000)
     ap.add_argument("--roof-case", default="S500k")
     ap.add_argument("--roof-reps", type=int, default=10)
     ap.add_argument("--roof-iters", type=int, default=50)

@@ -168,9 +168,19 @@ int lsa_eig_residuals(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, int32_t 
 int lsa_comm_unique_id(void *id128);
 int lsa_comm_init(lsa_ctx *ctx, int nranks, int rank, const void *id128);
 /* Row-block shard of a global CSR: this rank owns rows [row0, row1); x and y of lsa_spmv stay global-length
- * and replicated, each rank computes its rows and the blocks are exchanged with ncclAllGather. */
+ * and replicated, each rank computes its rows and the blocks are exchanged with ncclAllGather.
+ * Padded block layout: the global index space is nranks equal blocks of B_pad = n_global / nranks slots, rank r owns
+ * [r*B_pad, r*B_pad + rows_r); the unused tail of a block is padding (zero in every vector, referenced by no column),
+ * so the all-gather moves equal counts.  Column indices are expressed in this padded space. */
 int lsa_csr_upload_shard(lsa_ctx *ctx, int32_t n_global, int32_t row0, int32_t row1, int64_t nnz_local,
                          const int32_t *rowptr_local, const int32_t *col, const void *val, int dtype, lsa_mat **out);
+/* Shift-invert operator on row shards (PETSc's parallel default bjacobi + ilu): A_rows / M_rows are this
+ * rank's shards (lsa_csr_upload_shard), A_diag / M_diag its square diagonal blocks in local numbering
+ * (lsa_csr_upload).  C's rows and the ILU(k) of C's diagonal block stay on the rank; every SpMV and every
+ * preconditioner apply ends with one in-place all-gather; the Krylov bases are replicated, so dot products need no
+ * collective and the Hessenberg matrices are bit-identical on every rank. */
+int lsa_op_create_sharded(lsa_ctx *ctx, const lsa_mat *A_rows, const lsa_mat *M_rows, const lsa_mat *A_diag,
+                          const lsa_mat *M_diag, const double sigma[2], int mode, const lsa_op_options *opts, lsa_op **out);
 
 #ifdef __cplusplus
 }

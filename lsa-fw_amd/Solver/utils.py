@@ -170,34 +170,47 @@ def _lambda_rank_key(which: iEpsWhich, target: complex):
     return keys[which]
 
 
+def delay_zero_diagonal_rows(C: sp.csr_matrix, block_starts: np.ndarray | None = None, fraction: float = 0.5) -> np.ndarray:
+    """Permutation (new -> old) that moves every zero-diagonal row (the pressure rows of the saddle-point operator)
+    behind ``fraction`` of the rows it couples to, so that its ILU pivot receives fill from enough velocity rows: one
+    preceding neighbour is not enough in general (two pressure rows that see the same two velocity rows leave a
+    singular leading minor).  Rows that already satisfy the rule stay where they are.  With ``block_starts`` the rule
+    is applied inside each contiguous row block separately (only couplings inside the block count): the form the
+    block-Jacobi factors of the sharded layout need.  Rows keep their block."""
+    n = C.shape[0]
+    zero_diag = np.flatnonzero(C.diagonal() == 0)
+    if zero_diag.size == 0:
+        return np.arange(n, dtype=np.int64)
+    blk = None if block_starts is None else np.searchsorted(block_starts, np.arange(n), side="right") - 1
+    key = np.arange(n, dtype=np.float64)
+    indptr, indices, data = C.indptr, C.indices, C.data
+    for z in zero_diag:
+        cols = indices[indptr[z] : indptr[z + 1]]
+        keep = (data[indptr[z] : indptr[z + 1]] != 0) & (cols != z)
+        if blk is not None:
+            keep &= blk[cols] == blk[z]
+        nb = np.sort(cols[keep])
+        if nb.size == 0:
+            continue
+        target = nb[max(int(np.ceil(fraction * nb.size)) - 1, 0)]
+        if target > z:
+            key[z] = target + 0.5
+    return np.argsort(key, kind="stable").astype(np.int64)
+
+
 def pivot_safe_rcm(C: sp.csr_matrix) -> np.ndarray:
     """Bandwidth-reducing symmetric permutation that keeps ILU pivots non-zero on saddle-point matrices.
 
     Reverse Cuthill-McKee on the pattern (the analogue of PETSc's ``-pc_factor_mat_ordering_type rcm``), then every
     row with a zero diagonal (the pressure rows: ``tests/unit/FEM/test_operators.py:209-210``) that RCM placed before
-    *all* rows it couples to is moved right behind the first of them, so its pivot receives fill.
+    *all* rows it couples to is moved right behind the first of them (:func:`delay_zero_diagonal_rows`).
     """
     from scipy.sparse.csgraph import reverse_cuthill_mckee
 
-    n = C.shape[0]
     pattern = sp.csr_matrix((np.ones(C.nnz, dtype=np.int8), C.indices, C.indptr), shape=C.shape)
     perm = np.asarray(reverse_cuthill_mckee(pattern, symmetric_mode=False), dtype=np.int64)
-    pos = np.empty(n, dtype=np.float64)
-    pos[perm] = np.arange(n)
-    zero_diag = np.flatnonzero(C.diagonal() == 0)
-    if zero_diag.size:
-        row_of = np.repeat(np.arange(n), np.diff(C.indptr))
-        coupled = (C.data != 0) & (C.indices != row_of)
-        nb_pos = np.where(coupled, pos[C.indices], np.inf)
-        lens = np.diff(C.indptr)
-        first = np.full(n, np.inf)
-        nz_rows = np.flatnonzero(lens > 0)
-        first[nz_rows] = np.minimum.reduceat(nb_pos, C.indptr[:-1][nz_rows])
-        late = zero_diag[(first[zero_diag] > pos[zero_diag]) & np.isfinite(first[zero_diag])]
-        key = pos.copy()
-        key[late] = first[late] + 0.5
-        perm = np.argsort(key, kind="stable")
-    return perm.astype(np.int64)
+    Cp = C[perm][:, perm].tocsr()
+    return perm[delay_zero_diagonal_rows(Cp)]
 
 
 class _RawPC:
@@ -274,8 +287,8 @@ class iEpsSolver:
     """
 
     def __init__(self, A=None, M=None, comm=None, *, device: int = 0, ksp_type: KSPType = KSPType.GMRES,
-                 ksp_rtol: float | None = None, restart: int = 200, ksp_max_it: int = 4000, ilu_levels: int | None = None,
-                 ilu_shift: float = 0.0, ordering: str = "rcm", seed: int = 0) -> None:
+                 ksp_rtol: float | None = None, restart: int = 1000, ksp_max_it: int = 4000, ilu_levels: int | None = None,
+                 ilu_shift: float = 0.0, ordering: str = "rcm", seed: int = 0, layout: str = "single") -> None:
         if M is not None and A is None:
             raise ValueError("Cannot set right-hand operator M without left-hand operator A.")
         self._A = self._M = None
@@ -292,6 +305,9 @@ class iEpsSolver:
         self._ilu_levels, self._ilu_shift = ilu_levels, ilu_shift
         self._ordering = ordering
         self._device, self._seed = device, seed
+        if layout not in ("single", "sharded"):
+            raise ValueError("layout must be 'single' or 'sharded'")
+        self._layout = layout  # 'sharded': rows of (A, M) and the ILU split over the ranks of torch.distributed
         self._eigenvalues = np.zeros(0, dtype=np.complex128)
         self._eigenvectors = np.zeros((0, 0), dtype=np.complex128)
         self._residual_estimates = np.zeros(0)
@@ -351,7 +367,8 @@ class iEpsSolver:
         return 1, 2
 
     def _signature(self):
-        return (id(self._A), id(self._M), self._st_type, self._target, self._pc_type, self._ilu_levels, self._ordering, self._device)
+        return (id(self._A), id(self._M), self._st_type, self._target, self._pc_type, self._ilu_levels, self._ordering, self._device,
+                self._layout)
 
     def prepare(self) -> None:
         """Host-side analysis + upload: shared pattern, fill-reducing / pivot-safe ordering, CSR -> HBM.
@@ -391,10 +408,30 @@ class iEpsSolver:
         Ap = _permute(A, perm)
         Mp = None if M is None else _permute(M, perm)
         ctx = lsa_hip.Context(self._device)
-        dA = lsa_hip.CsrMatrix.from_scipy(ctx, Ap)
-        dM = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, Mp)
-        self._prepared = {"sig": self._signature(), "ctx": ctx, "dA": dA, "dM": dM, "perm": perm, "n": n, "sinvert": sinvert,
-                          "sigma": sigma, "pc_code": pc_code, "levels": levels}
+        part = dAd = dMd = None
+        if self._layout == "sharded":
+            # one process per GPU: rows of the permuted pair go to the ranks of torch.distributed (RCCL bootstrap through it)
+            from lsa_hip import sharding
+
+            rank, world = _dist_rank_world()
+            part = sharding.partition_rows(Ap.indptr, world)
+            if pc_code == 1 and K is not None and world > 1:
+                # block-Jacobi factors see only their diagonal block: redo the zero-pivot rule inside each block
+                q = delay_zero_diagonal_rows(_permute(sp.csr_matrix(K), perm), part.starts)
+                perm = perm[q]
+                Ap = _permute(A, perm)
+                Mp = None if M is None else _permute(M, perm)
+            dA = lsa_hip.CsrMatrix.from_scipy_shard(ctx, sharding.shard_rows(Ap, part, rank), part.n_pad, rank * part.b_pad)
+            dM = None if Mp is None else lsa_hip.CsrMatrix.from_scipy_shard(ctx, sharding.shard_rows(Mp, part, rank), part.n_pad, rank * part.b_pad)
+            dAd = lsa_hip.CsrMatrix.from_scipy(ctx, sharding.diagonal_block(Ap, part, rank))
+            dMd = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, sharding.diagonal_block(Mp, part, rank))
+            if world > 1:
+                ctx.comm_init(world, rank, _dist_broadcast_bytes(ctx.unique_id() if rank == 0 else None))
+        else:
+            dA = lsa_hip.CsrMatrix.from_scipy(ctx, Ap)
+            dM = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, Mp)
+        self._prepared = {"sig": self._signature(), "ctx": ctx, "dA": dA, "dM": dM, "dAd": dAd, "dMd": dMd, "part": part, "perm": perm,
+                          "n": n, "sinvert": sinvert, "sigma": sigma, "pc_code": pc_code, "levels": levels}
 
     def release(self) -> None:
         """Free the device copies made by :meth:`prepare`."""
@@ -432,9 +469,12 @@ class iEpsSolver:
         try:
             op = lsa_hip.ShiftInvertOperator(
                 ctx, prep["dA"], prep["dM"], sigma, mode=0 if sinvert else 1, ilu_levels=prep["levels"], ilu_shift=self._ilu_shift,
-                ksp_rtol=ksp_rtol, ksp_restart=min(self._restart_len, max(n, 1)), ksp_maxit=self._ksp_max_it, pc_type=prep["pc_code"],
+                ksp_rtol=ksp_rtol, ksp_restart=_restart_length(self._restart_len, n), ksp_maxit=self._ksp_max_it, pc_type=prep["pc_code"],
+                A_diag=prep["dAd"], M_diag=prep["dMd"],
             )
-            basis = lsa_hip.KrylovBasis(ctx, op, ncv)
+            part = prep["part"]
+            mask = None if part is None else part.pad_vector(np.ones(n))
+            basis = lsa_hip.KrylovBasis(ctx, op, ncv, mask)
             if sinvert:
                 theta_key = lambda th: lam_key(sigma + 1.0 / np.where(th == 0, np.finfo(float).tiny, th))  # noqa: E731
             else:
@@ -442,8 +482,9 @@ class iEpsSolver:
             res = krylov_schur(basis, nev, self._tol, self._max_it, theta_key, rng_seed=self._seed)
             theta = res.theta
             lam = sigma + 1.0 / theta if sinvert else theta + sigma
-            X = np.empty_like(res.vectors)
-            X[perm, :] = res.vectors
+            vecs = res.vectors if part is None else part.unpad_vector(res.vectors)
+            X = np.empty_like(vecs)
+            X[perm, :] = vecs
             self._stats = op.stats()
             self._stats["krylov_restarts"] = res.restarts
         finally:
@@ -462,6 +503,13 @@ class iEpsSolver:
 
         self.prepare()
         prep = self._prepared
+        if prep["part"] is not None:  # sharded layout: no rank holds the whole matrix on its device
+            A = self._A.as_scipy_array()
+            M = None if self._M is None else self._M.as_scipy_array()
+            lam, V = self._eigenvalues, self._eigenvectors
+            Av, Mv = A @ V, (M @ V if M is not None else V)
+            num = np.linalg.norm(Av - Mv * lam[np.newaxis, :], axis=0)
+            return num / (np.linalg.norm(Av, axis=0) + np.abs(lam) * np.linalg.norm(Mv, axis=0) + 1e-16)
         Xp = self._eigenvectors[prep["perm"], :]
         return lsa_hip.eig_residuals(prep["ctx"], prep["dA"], prep["dM"], self._eigenvalues, Xp)
 
@@ -502,6 +550,34 @@ class iEpsSolver:
     def stats(self) -> dict:
         """Counters of the last solve (outer applies, inner iterations, kernel launches, factor/solve seconds)."""
         return dict(self._stats)
+
+
+def _restart_length(requested: int, n: int, budget_bytes: float = 48e9) -> int:
+    """GMRES restart length: as long as requested, but the complex basis n x (restart + 1) must fit the HBM budget.
+    Long recurrences are cheap in 288 GB and matter: a shift close to an eigenvalue leaves one tiny eigenvalue in the
+    preconditioned operator, which full GMRES resolves in a few extra steps and restarted GMRES never does."""
+    return int(max(1, min(requested, max(n, 1), budget_bytes // (16 * max(n, 1)) - 1)))
+
+
+def _dist_rank_world() -> tuple[int, int]:
+    """(rank, world size) of the torch.distributed job this process belongs to; (0, 1) outside one."""
+    try:
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+    except ImportError:
+        pass
+    return 0, 1
+
+
+def _dist_broadcast_bytes(payload: bytes | None) -> bytes:
+    """Broadcast rank 0's bytes (the 128-byte RCCL unique id) to every rank of the torch.distributed job."""
+    import torch.distributed as dist
+
+    box = [payload]
+    dist.broadcast_object_list(box, src=0)
+    return box[0]
 
 
 def _onto_pattern(A: sp.csr_matrix, pattern: sp.csr_matrix) -> sp.csr_matrix:

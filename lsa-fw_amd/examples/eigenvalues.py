@@ -1,0 +1,102 @@
+"""Cylinder flow: solve the EVP on pre-assembled (A, M) per Reynolds number and write sigma.
+
+Counterpart of ``/root/reference/.examples/eigenvalues.py:61-108`` on the HIP path:
+same Reynolds sweep and shift table (``:36-49``), same solver configuration (``num_eig = 5``, ``atol = 1e-3``,
+shift-invert at the tabulated target, LU-class inner solves, ``:95-100``), same output file
+``cases/cylinder/reynolds_<Re>/sigma_eig0.txt`` holding ``"{re} {im}\\n"`` (``:104-107``).
+
+The reference loads ``A.mtx`` / ``M.mtx`` written by its dolfinx assembly stage.  ``--synthesize`` writes the oracle's
+synthetic pair to the same place first, so the script runs end to end without dolfinx.
+"""
+
+from __future__ import annotations
+
+import argparse
+import logging
+import sys
+from pathlib import Path
+from typing import Final
+
+ROOT = Path(__file__).resolve().parents[2]
+sys.path[:0] = [str(ROOT / "lsa-fw_amd")]
+
+from FEM.utils import iPETScMatrix  # noqa: E402
+from Solver.eigen import EigenSolver, EigensolverConfig  # noqa: E402
+from Solver.utils import PreconditionerType, iSTType  # noqa: E402
+
+_SAVE_DIR: Final[Path] = Path("cases") / "cylinder"
+_NUM_EIG: Final[int] = 5
+_EIG_INDEX: Final[int] = 0
+_ATOL: Final[float] = 1e-3
+
+_REYNOLDS: Final[tuple[float, ...]] = tuple(range(40, 91, 5))
+_TARGETS: Final[tuple[complex, ...]] = (  # DOI:10.1115/1.4042737, as tabulated in the reference
+    (-0.03 + 0.7197388769374216j),
+    0.7316769290210628j,
+    (0.018 + 0.7379601143282424j),
+    (0.03 + 0.742986662573986j),
+    (0.05 + 0.744243299635422j),
+    (0.061 + 0.7461282552275759j),
+    (0.072 + 0.7461282552275759j),
+    (0.085 + 0.744557458900781j),
+    (0.09 + 0.742986662573986j),
+    (0.1 + 0.7398450699203962j),
+    (0.115 + 0.7351326809400116j),
+)
+
+logger = logging.getLogger(__name__)
+
+
+def synthesize(save_dir: Path, case: str) -> None:
+    """Write the synthetic (A, M) of oracle/fem.py for every Reynolds number of the sweep."""
+    sys.path.insert(0, str(ROOT))
+    from oracle import fem
+
+    for re in _REYNOLDS:
+        mat_dir = save_dir / f"reynolds_{re:.1f}" / "matrices"
+        mat_dir.mkdir(parents=True, exist_ok=True)
+        es = fem.cylinder_case(case, re=float(re))
+        iPETScMatrix(es.A).export(mat_dir / "A.mtx")
+        iPETScMatrix(es.M).export(mat_dir / "M.mtx")
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--save-dir", type=Path, default=_SAVE_DIR)
+    ap.add_argument("--synthesize", metavar="CASE", help="first write synthetic matrices (e.g. S5k)")
+    args = ap.parse_args()
+    logging.basicConfig(level=logging.INFO)
+    if args.synthesize:
+        synthesize(args.save_dir, args.synthesize)
+
+    for re, target in zip(_REYNOLDS, _TARGETS):
+        case_dir = args.save_dir / f"reynolds_{re:.1f}"
+        mat_dir = case_dir / "matrices"
+        A_path, M_path = mat_dir / "A.mtx", mat_dir / "M.mtx"
+        if not A_path.exists() or not M_path.exists():
+            logger.warning("Skipping Re = %.1f: missing matrices in '%s'", re, mat_dir)
+            continue
+        logger.info("[Re=%.1f] Loading matrices from '%s'", re, mat_dir)
+        A = iPETScMatrix.from_path(A_path)
+        A.assemble()
+        M = iPETScMatrix.from_path(M_path)
+        M.assemble()
+        logger.info("[Re=%.1f] A: shape=%s, nnz=%d, norm=%.3e", re, A.shape, A.nonzero_entries, A.norm)
+        logger.info("[Re=%.1f] M: shape=%s, nnz=%d, norm=%.3e", re, M.shape, M.nonzero_entries, M.norm)
+
+        cfg = EigensolverConfig(num_eig=_NUM_EIG, atol=_ATOL)
+        es = EigenSolver(A, M, cfg=cfg, check_hermitian=False)
+        es.solver.set_st_type(iSTType.SINVERT)
+        es.solver.set_target(target)
+        es.solver.set_st_pc_type(PreconditionerType.LU)
+        es.solver.solve()
+        sigma = es.solver.get_eigenvalue(_EIG_INDEX)
+        out_path = case_dir / f"sigma_eig{_EIG_INDEX}.txt"
+        out_path.write_text(f"{sigma.real} {sigma.imag}\n", encoding="utf-8")
+        logger.info("[Re=%.1f] Wrote sigma to '%s'", re, out_path)
+        es.solver.release()
+    logger.info("All cases processed.")
+
+
+if __name__ == "__main__":
+    main()

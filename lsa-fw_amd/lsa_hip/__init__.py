@@ -92,6 +92,7 @@ SIGNATURES = {
     "lsa_ilu_download": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "lsa_gmres": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, _DBL, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
     "lsa_op_create": (ctypes.c_int, [_P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
+    "lsa_op_create_sharded": (ctypes.c_int, [_P, _P, _P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
     "lsa_op_destroy": (None, [_P]),
     "lsa_op_apply": (ctypes.c_int, [_P, _P, _P, _P]),
     "lsa_op_stats": (ctypes.c_int, [_P, ctypes.POINTER(lsa_stats)]),
@@ -371,17 +372,24 @@ class ShiftInvertOperator:
     """``y = (A - sigma M)^-1 M x`` (mode 0, iSTType.SINVERT) or ``y = M^-1 (A - sigma M) x`` (mode 1, iSTType.SHIFT)."""
 
     def __init__(self, ctx: Context, A: CsrMatrix, M: CsrMatrix | None, sigma: complex, *, mode: int = 0, ilu_levels: int = 0,
-                 ilu_shift: float = 0.0, ksp_rtol: float = 1e-11, ksp_restart: int = 200, ksp_maxit: int = 2000, pc_type: int = 1):
-        self.ctx, self._A, self._M = ctx, A, M
+                 ilu_shift: float = 0.0, ksp_rtol: float = 1e-11, ksp_restart: int = 200, ksp_maxit: int = 2000, pc_type: int = 1,
+                 A_diag: CsrMatrix | None = None, M_diag: CsrMatrix | None = None):
+        """With ``A_diag`` (and ``M_diag``) given, ``A`` / ``M`` are this rank's row shards in the padded block layout
+        (:mod:`lsa_hip.sharding`) and the preconditioner is block-Jacobi ILU(k) over ranks."""
+        self.ctx, self._A, self._M, self._Ad, self._Md = ctx, A, M, A_diag, M_diag
         sigma = complex(sigma)
         opts = lsa_op_options(int(ilu_levels), float(ilu_shift), float(ksp_rtol), int(ksp_restart), int(ksp_maxit), int(pc_type))
         h = ctypes.c_void_p()
-        ctx.check(
-            ctx._lib.lsa_op_create(ctx.handle, A.handle, M.handle if M is not None else None, (_DBL * 2)(sigma.real, sigma.imag),
-                                   int(mode), ctypes.byref(opts), ctypes.byref(h))
-        )
+        sig = (_DBL * 2)(sigma.real, sigma.imag)
+        if A_diag is None:
+            ctx.check(ctx._lib.lsa_op_create(ctx.handle, A.handle, M.handle if M is not None else None, sig, int(mode), ctypes.byref(opts), ctypes.byref(h)))
+        else:
+            ctx.check(
+                ctx._lib.lsa_op_create_sharded(ctx.handle, A.handle, M.handle if M is not None else None, A_diag.handle,
+                                               M_diag.handle if M_diag is not None else None, sig, int(mode), ctypes.byref(opts), ctypes.byref(h))
+            )
         self.handle = h
-        self.n = A.shape[0]
+        self.n = A.shape[1]  # vector length (padded global length when sharded)
         self.sigma = sigma
         self.mode = mode
 
@@ -403,8 +411,9 @@ class KrylovBasis:
     """Arnoldi basis in HBM + the recurrences Krylov-Schur needs.  Implements the backend protocol of
     :func:`lsa_hip.krylov_schur.krylov_schur` (``n``, ``ncv``, ``inject``, ``extend``, ``restart``, ``ritz_vectors``)."""
 
-    def __init__(self, ctx: Context, op: ShiftInvertOperator, ncv: int):
-        self.ctx, self._op = ctx, op
+    def __init__(self, ctx: Context, op: ShiftInvertOperator, ncv: int, mask: np.ndarray | None = None):
+        """``mask`` (0/1 per slot) zeroes the padding slots of injected vectors in the sharded block layout."""
+        self.ctx, self._op, self._mask = ctx, op, mask
         self.n, self.ncv = op.n, int(ncv)
         h = ctypes.c_void_p()
         ctx.check(ctx._lib.lsa_krylov_create(ctx.handle, op.handle, self.ncv, ctypes.byref(h)))
@@ -414,6 +423,8 @@ class KrylovBasis:
         v = np.ascontiguousarray(v, dtype=np.complex128)
         if v.shape != (self.n,):
             raise ValueError(f"start vector must have shape ({self.n},)")
+        if self._mask is not None:
+            v = np.ascontiguousarray(v * self._mask)
         self.ctx.check(self.ctx._lib.lsa_krylov_inject(self.ctx.handle, self.handle, int(j), _ptr(v)))
 
     def extend(self, j0: int, j1: int, H: np.ndarray) -> int:

@@ -220,3 +220,51 @@ def test_real_shift_uses_real_factors():
     lam = np.array([p[0] for p in solver.solve()])
     for r in ref_lam:
         assert np.min(np.abs(lam - r)) <= 1e-8 * abs(r)
+
+
+# ---- callers of the path: sensitivity pair (H2) and the Reynolds sweep harness (H1) ------------------------------------------
+
+
+def test_direct_adjoint_pair():
+    """Sensitivity/__init__.py:158-311: lambda_adj = conj(lambda_dir) and a^H M v = 1."""
+    from oracle import fem, shift_invert
+    from Sensitivity import EigenSensitivitySolver
+
+    es = fem.cylinder_case("S2k")
+    sigma = fem.SIGMA_RE50
+    sens = EigenSensitivitySolver(es.A, es.M, target=sigma, tol_direct=1e-10, tol_adjoint=1e-10, ilu_levels=2)
+    lam, v = sens.solve_direct_mode()
+    ref, _, _ = shift_invert.solve(es.A, es.M, sigma, k=1, tol=1e-13)
+    assert abs(lam - ref[0]) <= 1e-8 * abs(ref[0])
+    a = sens.solve_adjoint_mode()
+    assert abs(sens._sigma_adj - np.conj(lam)) <= 1e-8 * abs(lam)
+    assert np.vdot(a, es.M @ v) == pytest.approx(1.0, abs=1e-10)
+    # a is a left eigenvector: a^H (A - lam M) = 0
+    r = (es.A.conj().T @ a) - np.conj(lam) * (es.M.conj().T @ a)
+    assert np.linalg.norm(r) <= 1e-7 * np.linalg.norm(es.A.conj().T @ a)
+    ux, uy = es.node_offset, es.node_offset + 1
+    sw = sens.compute_wavemaker(ux, uy)
+    assert sw.shape == ux.shape and np.all(sw >= 0) and np.isfinite(sw).all() and sw.max() > 0
+
+
+def test_reynolds_sweep_harness(tmp_path, monkeypatch):
+    """.examples/eigenvalues.py:61-108 end to end on synthetic matrices: one sigma file per Reynolds number."""
+    import importlib.util
+    from pathlib import Path
+
+    from oracle import fem, shift_invert
+
+    path = Path(__file__).resolve().parents[1] / "lsa-fw_amd" / "examples" / "eigenvalues.py"
+    spec = importlib.util.spec_from_file_location("lsa_examples_eigenvalues", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(mod, "_REYNOLDS", (50, 55))
+    monkeypatch.setattr(mod, "_TARGETS", mod._TARGETS[2:4])
+    monkeypatch.setattr("sys.argv", ["eigenvalues.py", "--save-dir", str(tmp_path), "--synthesize", "S2k"])
+    mod.main()
+    for re, target in zip((50, 55), mod._TARGETS):
+        txt = (tmp_path / f"reynolds_{re:.1f}" / "sigma_eig0.txt").read_text().split()
+        got = complex(float(txt[0]), float(txt[1]))
+        es = fem.cylinder_case("S2k", re=float(re))
+        ref, _, _ = shift_invert.solve(es.A, es.M, target, k=1, tol=1e-12)
+        assert abs(got - ref[0]) <= 1e-3 * abs(ref[0]) * 10  # the harness runs at the reference's atol = 1e-3

@@ -18,7 +18,7 @@ ap.add_argument("--case", default="S5k")
 ap.add_argument("--k", type=int, default=20)
 ap.add_argument("--levels", type=int, default=2)
 ap.add_argument("--atol", type=float, default=1e-10)
-ap.add_argument("--restart", type=int, default=200)
+ap.add_argument("--restart", type=int, default=1000)
 ap.add_argument("--sigma-real", action="store_true")
 args = ap.parse_args()
 

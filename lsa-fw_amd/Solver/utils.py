@@ -363,8 +363,11 @@ class iEpsSolver:
             return 1, int(self._ilu_levels)
         if self._pc_type in (PreconditionerType.ILU, PreconditionerType.ICC):
             return 1, 0  # PETSc's PCILU default: zero fill
-        # LU / CHOLESKY (exact solves in the reference) and every other name: stronger factors, tight GMRES
-        return 1, 2
+        if self._pc_type in (PreconditionerType.LU, PreconditionerType.CHOLESKY):
+            # exact solves in the reference: exact block-tridiagonal LU on the device (ILU(2) + GMRES if the band does
+            # not fit the memory budget, e.g. 3D meshes)
+            return 2, 2
+        return 1, 2  # every other PETSc name: ILU(2) + GMRES
 
     def _signature(self):
         return (id(self._A), id(self._M), self._st_type, self._target, self._pc_type, self._ilu_levels, self._ordering, self._device,
@@ -401,7 +404,7 @@ class iEpsSolver:
             K = _combine(A, M, sigma) if M is not None else A  # the matrix that gets factorised
         else:
             K = M
-        if self._ordering == "rcm" and n > 8 and pc_code == 1 and K is not None:
+        if self._ordering == "rcm" and n > 8 and pc_code >= 1 and K is not None:
             perm = pivot_safe_rcm(sp.csr_matrix(K))
         else:
             perm = np.arange(n)
@@ -415,7 +418,7 @@ class iEpsSolver:
 
             rank, world = _dist_rank_world()
             part = sharding.partition_rows(Ap.indptr, world)
-            if pc_code == 1 and K is not None and world > 1:
+            if pc_code >= 1 and K is not None and world > 1:
                 # block-Jacobi factors see only their diagonal block: redo the zero-pivot rule inside each block
                 q = delay_zero_diagonal_rows(_permute(sp.csr_matrix(K), perm), part.starts)
                 perm = perm[q]

@@ -1,0 +1,489 @@
+// Exact block-tridiagonal LU of the shifted operator: the device counterpart of PreconditionerType.LU, which is what
+// the reference's cylinder runs use for the ST's inner solve (.examples/eigenvalues.py:100, Sensitivity/__init__.py:182).
+//
+// In RCM order C = A - sigma M has bandwidth w (723 at S30k).  With a block size B > w the matrix is block tridiagonal,
+//
+//     C = [ C_00 C_01           ]         S_0 = C_00,   S_b = C_bb - C_{b,b-1} S_{b-1}^-1 C_{b-1,b}
+//         [ C_10 C_11 C_12      ]
+//         [      C_21 C_22 ...  ]         forward :  y_b = v_b - C_{b,b-1} (S_{b-1}^-1 y_{b-1})
+//                                         backward:  x_b = S_b^-1 (y_b - C_{b,b+1} x_{b+1})
+//
+// and only a w x w corner of every Schur complement differs from C_bb.  The Schur blocks are inverted ONCE per shift
+// into dense B x B matrices that stay in HBM (n*B scalars: 0.5 GB at S30k, 25 GB at S500k -- the 288 GB at work), by an
+// in-place Gauss-Jordan elimination with partial pivoting; the off-diagonal blocks stay the sparse rows of C.  A solve is
+// then 4 dependent launches per block (dense mat-vec + sparse update, forward and backward), replayed from a hipGraph,
+// and it is a *direct* solve (residual ~1e-15): the GMRES around it converges in one iteration and only guards accuracy.
+// Not usable when the band does not fit (3D meshes): lsa_blu_create then fails and the ILU(k) path is used.
+#include <algorithm>
+#include <chrono>
+
+#include "lsa_internal.h"
+
+struct lsa_blu {
+    lsa_ctx* ctx;
+    const lsa_mat* C;  // borrowed: the sparse off-diagonal blocks are read from C at every solve
+    int32_t n, B, nb, bandwidth;
+    int dtype;
+    int32_t *lsplit = nullptr, *usplit = nullptr;                 // device: per row, first entry with col >= block start / end
+    int32_t *cptr = nullptr, *crow = nullptr, *cpos = nullptr;    // device CSC view of C (setup only)
+    void* sinv = nullptr;                                         // device: n x B row-major, block b = rows [b*B, ...)
+    int32_t* ipiv = nullptr;
+    void* colbuf = nullptr;
+    int32_t* flag = nullptr;
+    void *t[2] = {nullptr, nullptr}, *y[2] = {nullptr, nullptr}, *z[2] = {nullptr, nullptr};
+    void *in[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr};
+    void* graph[2] = {nullptr, nullptr};
+    double seconds = 0.0;
+};
+
+namespace {
+
+inline double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// S[r - bs, c - bs] = C[r, c] for the entries of block row b that fall into the diagonal block
+template <typename T>
+__global__ void blu_scatter_kernel(int32_t bs, int32_t be, int32_t B, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                   const int32_t* __restrict__ lsplit, const int32_t* __restrict__ usplit,
+                                   const T* __restrict__ val, T* __restrict__ S) {
+    const int32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = gid & 15;
+    const int32_t r = bs + (gid >> 4);
+    if (r >= be) return;
+    for (int32_t p = lsplit[r] + lane; p < usplit[r]; p += 16) S[(size_t)(r - bs) * B + (ci[p] - bs)] = val[p];
+}
+
+// S[r, :] -= (C[r, prev block] * Sinv_prev) * C[prev block, this block]   (only rows with entries left of the block)
+template <typename T>
+__global__ __launch_bounds__(256) void blu_corner_kernel(int32_t ps, int32_t bs, int32_t be, int32_t B, const int32_t* __restrict__ rp,
+                                                         const int32_t* __restrict__ ci, const int32_t* __restrict__ lsplit,
+                                                         const T* __restrict__ val, const int32_t* __restrict__ cptr,
+                                                         const int32_t* __restrict__ crow, const int32_t* __restrict__ cpos,
+                                                         const T* __restrict__ sinv_prev, T* __restrict__ S) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    T* X = (T*)dyn;  // row r of C_{b,b-1} * Sinv_{b-1}: m1 entries
+    const int32_t r = bs + blockIdx.x;
+    const int32_t g0 = rp[r], g1 = lsplit[r];
+    if (g0 == g1) return;  // no coupling to the previous block
+    const int32_t m1 = bs - ps;
+    for (int32_t k = threadIdx.x; k < m1; k += 256) {
+        T acc = scalar_traits<T>::zero();
+        for (int32_t p = g0; p < g1; ++p) fma_acc(acc, val[p], sinv_prev[(size_t)(ci[p] - ps) * B + k]);
+        X[k] = acc;
+    }
+    __syncthreads();
+    const int32_t m = be - bs;
+    for (int32_t j = threadIdx.x; j < m; j += 256) {
+        const int32_t q0 = cptr[bs + j], q1 = cptr[bs + j + 1];
+        T acc = scalar_traits<T>::zero();
+        bool any = false;
+        for (int32_t q = q0; q < q1; ++q) {
+            const int32_t k = crow[q];
+            if (k >= bs) break;  // rows are sorted inside a column
+            if (k >= ps) {
+                fma_acc(acc, X[k - ps], val[cpos[q]]);
+                any = true;
+            }
+        }
+        if (any) {
+            T* out = S + (size_t)(r - bs) * B + j;
+            *out = s_sub(*out, acc);
+        }
+    }
+}
+
+// ---- in-place Gauss-Jordan inversion with partial pivoting: two launches per pivot column -----------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void gj_pivot_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k, int32_t* __restrict__ ipiv,
+                                                        T* __restrict__ colbuf, int32_t* __restrict__ flag) {
+    __shared__ double smag[16];
+    __shared__ int32_t sidx[16];
+    __shared__ int32_t spiv;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double best = -1.0;
+    int32_t bi = k;
+    for (int32_t i = k + tid; i < m; i += 1024) {
+        const double mag = s_abs2(a[(size_t)i * ld + k]);
+        if (mag > best) {
+            best = mag;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const double ob = __shfl_xor(best, s, 64);
+        const int32_t oi = __shfl_xor(bi, s, 64);
+        if (ob > best || (ob == best && oi < bi)) {
+            best = ob;
+            bi = oi;
+        }
+    }
+    if (lane == 0) {
+        smag[wave] = best;
+        sidx[wave] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double b = smag[0];
+        int32_t i0 = sidx[0];
+        for (int w = 1; w < 16; ++w)
+            if (smag[w] > b || (smag[w] == b && sidx[w] < i0)) {
+                b = smag[w];
+                i0 = sidx[w];
+            }
+        spiv = i0;
+        ipiv[k] = i0;
+        if (!(b > 0.0)) atomicCAS(&flag[1], 0, k + 1);  // singular block
+    }
+    __syncthreads();
+    const int32_t p = spiv;
+    T* rk = a + (size_t)k * ld;
+    T* rpv = a + (size_t)p * ld;
+    if (p != k) {
+        for (int32_t j = tid; j < m; j += 1024) {
+            const T tmp = rk[j];
+            rk[j] = rpv[j];
+            rpv[j] = tmp;
+        }
+    }
+    __syncthreads();
+    T piv = rk[k];
+    if (s_abs2(piv) == 0.0) s_from(piv, 1.0, 0.0);
+    const T pinv = s_inv(piv);
+    __syncthreads();
+    for (int32_t j = tid; j < m; j += 1024) rk[j] = (j == k) ? pinv : s_mul(pinv, rk[j]);
+    // multipliers: column k of the other rows, which is then cleared
+    for (int32_t i = tid; i < m; i += 1024) {
+        if (i == k) {
+            colbuf[i] = scalar_traits<T>::zero();
+        } else {
+            colbuf[i] = a[(size_t)i * ld + k];
+            a[(size_t)i * ld + k] = scalar_traits<T>::zero();
+        }
+    }
+}
+
+// a[i, :] -= colbuf[i] * a[k, :] for every row i != k; one wavefront per row, rows with a zero multiplier are skipped
+template <typename T>
+__global__ __launch_bounds__(256) void gj_update_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k, const T* __restrict__ colbuf) {
+    const int lane = threadIdx.x & 63;
+    const int32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m || i == k) return;
+    const T f = colbuf[i];
+    if (s_abs2(f) == 0.0) return;
+    const T* rk = a + (size_t)k * ld;
+    T* ri = a + (size_t)i * ld;
+    for (int32_t j = lane; j < m; j += 64) {
+        T v = ri[j];
+        const T prod = s_mul(f, rk[j]);
+        ri[j] = s_sub(v, prod);
+    }
+}
+
+// undo the row interchanges on the columns of the inverse: thread per row, swaps in reverse order
+template <typename T>
+__global__ void gj_unpivot_kernel(T* __restrict__ a, int32_t ld, int32_t m, const int32_t* __restrict__ ipiv) {
+    const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    T* ri = a + (size_t)i * ld;
+    for (int32_t k = m - 1; k >= 0; --k) {
+        const int32_t p = ipiv[k];
+        if (p != k) {
+            const T tmp = ri[k];
+            ri[k] = ri[p];
+            ri[p] = tmp;
+        }
+    }
+}
+
+// ---- solve kernels ------------------------------------------------------------------------------------------------------
+// out[r] = rhs[r] - sum over the entries of row r left of (LEFT) / right of its diagonal block of val * x[col]
+template <typename MT, typename VT, bool LEFT>
+__global__ __launch_bounds__(256) void blu_sparse_kernel(int32_t bs, int32_t be, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                         const int32_t* __restrict__ lsplit, const int32_t* __restrict__ usplit,
+                                                         const MT* __restrict__ val, const VT* __restrict__ rhs, const VT* __restrict__ x,
+                                                         VT* __restrict__ out) {
+    const int32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = gid & 15;
+    const int32_t r = bs + (gid >> 4);
+    if (r >= be) return;
+    const int32_t p0 = LEFT ? rp[r] : usplit[r];
+    const int32_t p1 = LEFT ? lsplit[r] : rp[r + 1];
+    VT acc = scalar_traits<VT>::zero();
+    for (int32_t p = p0 + lane; p < p1; p += 16) fma_acc(acc, val[p], x[ci[p]]);
+#pragma unroll
+    for (int s = 8; s > 0; s >>= 1) {
+        if constexpr (sizeof(VT) == 16) {
+            acc.re += __shfl_xor(acc.re, s, 64);
+            acc.im += __shfl_xor(acc.im, s, 64);
+        } else {
+            acc += __shfl_xor(acc, s, 64);
+        }
+    }
+    if (lane == 0) out[r] = s_sub(rhs[r], acc);
+}
+
+// out[r] = sum_s Sinv[r, s] in[s] over the whole diagonal block; one wavefront per row, 8 loads in flight per lane
+template <typename MT, typename VT>
+__global__ __launch_bounds__(256) void blu_dense_kernel(int32_t bs, int32_t be, int32_t B, const MT* __restrict__ sinv,
+                                                        const VT* __restrict__ in, VT* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int32_t r = bs + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= be) return;
+    const MT* row = sinv + (size_t)r * B - bs;
+    VT acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = scalar_traits<VT>::zero();
+    int32_t s = bs + lane;
+    for (; s + 7 * 64 < be; s += 8 * 64) {
+        MT a[8];
+        VT tv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a[k] = row[s + k * 64];
+            tv[k] = in[s + k * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fma_acc(acc[k & 3], a[k], tv[k]);
+    }
+    for (; s < be; s += 64) fma_acc(acc[0], row[s], in[s]);
+    VT v = s_add(s_add(acc[0], acc[1]), s_add(acc[2], acc[3]));
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        if constexpr (sizeof(VT) == 16) {
+            v.re += __shfl_xor(v.re, m, 64);
+            v.im += __shfl_xor(v.im, m, 64);
+        } else {
+            v += __shfl_xor(v, m, 64);
+        }
+    }
+    if (lane == 0) out[r] = v;
+}
+
+template <typename T>
+int factorize(lsa_ctx* ctx, lsa_blu* f) {
+    const int32_t B = f->B, n = f->n;
+    const lsa_mat* C = f->C;
+    const size_t inv_bytes = (size_t)n * B * sizeof(T);
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->sinv, 0, inv_bytes, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->flag, 0, 4 * sizeof(int32_t), ctx->stream));
+    const size_t lds = (size_t)B * sizeof(T);
+    if (lds > 64 * 1024) LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int32_t b = 0; b < f->nb; ++b) {
+        const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
+        T* S = (T*)f->sinv + (size_t)bs * B;
+        hipLaunchKernelGGL((blu_scatter_kernel<T>), dim3((m * 16 + 255) / 256), dim3(256), 0, ctx->stream, bs, be, B, C->rp, C->ci, f->lsplit,
+                           f->usplit, (const T*)C->val, S);
+        if (b > 0) {
+            const int32_t ps = bs - B;
+            hipLaunchKernelGGL((blu_corner_kernel<T>), dim3(m), dim3(256), lds, ctx->stream, ps, bs, be, B, C->rp, C->ci, f->lsplit,
+                               (const T*)C->val, f->cptr, f->crow, f->cpos, (const T*)f->sinv + (size_t)ps * B, S);
+        }
+        for (int32_t k = 0; k < m; ++k) {
+            hipLaunchKernelGGL((gj_pivot_kernel<T>), dim3(1), dim3(1024), 0, ctx->stream, S, B, m, k, f->ipiv, (T*)f->colbuf, f->flag);
+            hipLaunchKernelGGL((gj_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, S, B, m, k, (const T*)f->colbuf);
+        }
+        hipLaunchKernelGGL((gj_unpivot_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, ctx->stream, S, B, m, f->ipiv);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "block LU launch failed: %s", hipGetErrorString(e));
+    int32_t hflag[4];
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(hflag, f->flag, sizeof hflag, hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (hflag[1] != 0) return lsa_set_error(ctx, LSA_ERR_ZERO_PIVOT, "block LU: a Schur block is singular (pivot column %d)", hflag[1] - 1);
+    return LSA_OK;
+}
+
+template <typename MT, typename VT>
+void launch_apply(lsa_ctx* ctx, lsa_blu* f, const VT* v, VT* x, VT* y, VT* z, VT* t) {
+    const int32_t B = f->B, nb = f->nb, n = f->n;
+    const lsa_mat* C = f->C;
+    // forward: y_b = v_b - C_{b,b-1} z_{b-1},  z_b = Sinv_b y_b
+    for (int32_t b = 0; b < nb; ++b) {
+        const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
+        hipLaunchKernelGGL((blu_sparse_kernel<MT, VT, true>), dim3((m * 16 + 255) / 256), dim3(256), 0, ctx->stream, bs, be, C->rp, C->ci,
+                           f->lsplit, f->usplit, (const MT*)C->val, v, (const VT*)z, y);
+        if (b + 1 < nb)
+            hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, bs, be, B, (const MT*)f->sinv,
+                               (const VT*)y, z);
+    }
+    // backward: x_b = Sinv_b (y_b - C_{b,b+1} x_{b+1})
+    for (int32_t b = nb - 1; b >= 0; --b) {
+        const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
+        hipLaunchKernelGGL((blu_sparse_kernel<MT, VT, false>), dim3((m * 16 + 255) / 256), dim3(256), 0, ctx->stream, bs, be, C->rp, C->ci,
+                           f->lsplit, f->usplit, (const MT*)C->val, (const VT*)y, (const VT*)x, t);
+        hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, bs, be, B, (const MT*)f->sinv,
+                           (const VT*)t, x);
+    }
+}
+
+template <typename MT, typename VT>
+int apply_typed(lsa_ctx* ctx, lsa_blu* f, const void* b, void* x) {
+    const int vd = scalar_traits<VT>::dtype;
+    const size_t vb = (size_t)std::max<int32_t>(f->n, 1) * sizeof(VT);
+    if (!f->t[vd]) {
+        LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        for (void** p : {&f->t[vd], &f->y[vd], &f->z[vd], &f->in[vd], &f->out[vd]}) {
+            LSA_HIP_CHECK(ctx, hipMalloc(p, vb));
+            LSA_HIP_CHECK(ctx, hipMemsetAsync(*p, 0, vb, ctx->stream));
+        }
+    }
+    VT *t = (VT*)f->t[vd], *y = (VT*)f->y[vd], *z = (VT*)f->z[vd], *in = (VT*)f->in[vd], *out = (VT*)f->out[vd];
+    static const bool use_graph = !(getenv("LSA_SPTRSV_GRAPH") && atoi(getenv("LSA_SPTRSV_GRAPH")) == 0);
+    if (!use_graph) {
+        launch_apply<MT, VT>(ctx, f, (const VT*)b, (VT*)x, y, z, t);
+        hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "block LU solve launch failed: %s", hipGetErrorString(le));
+        return LSA_OK;
+    }
+    if (!f->graph[vd]) {
+        hipGraph_t graph = nullptr;
+        LSA_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+        launch_apply<MT, VT>(ctx, f, in, out, y, z, t);
+        hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+        if (e != hipSuccess || !graph) return lsa_set_error(ctx, LSA_ERR_HIP, "block LU: graph capture failed: %s", hipGetErrorString(e));
+        hipGraphExec_t exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (e != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "block LU: graph instantiate failed: %s", hipGetErrorString(e));
+        f->graph[vd] = (void*)exec;
+    }
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(in, b, (size_t)f->n * sizeof(VT), hipMemcpyDeviceToDevice, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipGraphLaunch((hipGraphExec_t)f->graph[vd], ctx->stream));
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(x, out, (size_t)f->n * sizeof(VT), hipMemcpyDeviceToDevice, ctx->stream));
+    return LSA_OK;
+}
+
+}  // namespace
+
+int blu_solve_dev(lsa_ctx* ctx, lsa_blu* f, int vdtype, const void* b, void* x) {
+    if (b == x) return lsa_set_error(ctx, LSA_ERR_ARG, "blu_solve: b and x must not alias");
+    if (f->dtype == LSA_F64 && vdtype == LSA_F64) return apply_typed<double, double>(ctx, f, b, x);
+    if (f->dtype == LSA_F64 && vdtype == LSA_C128) return apply_typed<double, cplx>(ctx, f, b, x);
+    if (f->dtype == LSA_C128 && vdtype == LSA_C128) return apply_typed<cplx, cplx>(ctx, f, b, x);
+    return lsa_set_error(ctx, LSA_ERR_ARG, "blu_solve: complex factors need complex vectors");
+}
+
+extern "C" {
+
+void lsa_blu_destroy(lsa_blu* f) {
+    if (!f) return;
+    if (f->ctx && f->ctx->stream) (void)hipStreamSynchronize(f->ctx->stream);
+    for (int vd = 0; vd < 2; ++vd) {
+        if (f->graph[vd]) (void)hipGraphExecDestroy((hipGraphExec_t)f->graph[vd]);
+        for (void* p : {f->t[vd], f->y[vd], f->z[vd], f->in[vd], f->out[vd]})
+            if (p) (void)hipFree(p);
+    }
+    for (void* p : {(void*)f->lsplit, (void*)f->usplit, (void*)f->cptr, (void*)f->crow, (void*)f->cpos, f->sinv, (void*)f->ipiv, f->colbuf, (void*)f->flag})
+        if (p) (void)hipFree(p);
+    delete f;
+}
+
+int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu** out) {
+    if (!ctx || !C || !out) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_blu_create: null argument");
+    if (C->n != C->ncols) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_blu_create: the matrix must be square");
+    const double t0 = now_s();
+    const int32_t n = C->n;
+    int32_t bw = 0;
+    for (int32_t i = 0; i < n; ++i)
+        for (int32_t p = C->h_rp[i]; p < C->h_rp[i + 1]; ++p) bw = std::max(bw, std::abs(C->h_ci[p] - i));
+    int32_t B = std::max(block_size > 0 ? block_size : 1024, bw + 1);
+    B = ((B + 255) / 256) * 256;
+    const size_t esz = C->dtype == LSA_C128 ? 16 : 8;
+    const size_t inv_bytes = (size_t)std::max(n, 1) * B * esz;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    if (inv_bytes > free_b / 2)
+        return lsa_set_error(ctx, LSA_ERR_HIP, "block LU: bandwidth %d needs %.1f GB of inverted Schur blocks (%.1f GB free); use ILU(k)", bw,
+                             inv_bytes / 1e9, free_b / 1e9);
+    lsa_blu* f = new lsa_blu();
+    f->ctx = ctx;
+    f->C = C;
+    f->n = n;
+    f->B = B;
+    f->nb = n > 0 ? (n + B - 1) / B : 0;
+    f->bandwidth = bw;
+    f->dtype = C->dtype;
+    // splits on C's pattern and a CSC view (positions into C's value array) for the corner update
+    std::vector<int32_t> ls((size_t)n), us((size_t)n), cptr((size_t)n + 1, 0), crow((size_t)C->nnz), cpos((size_t)C->nnz);
+    const int32_t* c = C->h_ci.data();
+    for (int32_t r = 0; r < n; ++r) {
+        const int32_t bs = (r / B) * B, be = std::min(n, bs + B);
+        ls[r] = (int32_t)(std::lower_bound(c + C->h_rp[r], c + C->h_rp[r + 1], bs) - c);
+        us[r] = (int32_t)(std::lower_bound(c + C->h_rp[r], c + C->h_rp[r + 1], be) - c);
+        for (int32_t p = C->h_rp[r]; p < C->h_rp[r + 1]; ++p) ++cptr[(size_t)c[p] + 1];
+    }
+    for (int32_t j = 0; j < n; ++j) cptr[(size_t)j + 1] += cptr[j];
+    {
+        std::vector<int32_t> cur(cptr.begin(), cptr.end() - 1);
+        for (int32_t r = 0; r < n; ++r)
+            for (int32_t p = C->h_rp[r]; p < C->h_rp[r + 1]; ++p) {
+                const int32_t q = cur[c[p]]++;
+                crow[q] = r;
+                cpos[q] = p;
+            }
+    }
+    const size_t n1 = (size_t)std::max(n, 1), z1 = (size_t)std::max<int64_t>(C->nnz, 1);
+    bool ok = hipMalloc((void**)&f->lsplit, 4 * n1) == hipSuccess && hipMalloc((void**)&f->usplit, 4 * n1) == hipSuccess &&
+              hipMalloc((void**)&f->cptr, 4 * (n1 + 1)) == hipSuccess && hipMalloc((void**)&f->crow, 4 * z1) == hipSuccess &&
+              hipMalloc((void**)&f->cpos, 4 * z1) == hipSuccess && hipMalloc(&f->sinv, inv_bytes) == hipSuccess &&
+              hipMalloc((void**)&f->ipiv, 4 * (size_t)B) == hipSuccess && hipMalloc(&f->colbuf, esz * (size_t)B) == hipSuccess &&
+              hipMalloc((void**)&f->flag, 16) == hipSuccess;
+    hipStream_t s = ctx->stream;
+    ok = ok && hipMemcpyAsync(f->lsplit, ls.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(f->usplit, us.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(f->cptr, cptr.data(), 4 * ((size_t)n + 1), hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(f->crow, crow.data(), 4 * (size_t)C->nnz, hipMemcpyHostToDevice, s) == hipSuccess &&
+         hipMemcpyAsync(f->cpos, cpos.data(), 4 * (size_t)C->nnz, hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
+    if (!ok) {
+        lsa_blu_destroy(f);
+        return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_blu_create: out of device memory");
+    }
+    int rc = f->dtype == LSA_C128 ? factorize<cplx>(ctx, f) : factorize<double>(ctx, f);
+    if (rc != LSA_OK) {
+        lsa_blu_destroy(f);
+        return rc;
+    }
+    // the CSC view is only needed by the factorisation
+    for (int32_t** p : {&f->cptr, &f->crow, &f->cpos}) {
+        (void)hipFree(*p);
+        *p = nullptr;
+    }
+    f->seconds = now_s() - t0;
+    *out = f;
+    return LSA_OK;
+}
+
+int lsa_blu_solve(lsa_ctx* ctx, lsa_blu* f, const lsa_vec* b, lsa_vec* x) {
+    if (!ctx || !f || !b || !x) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_blu_solve: null argument");
+    if (b->n != f->n || x->n != f->n || b->dtype != x->dtype) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_blu_solve: vector shape/dtype mismatch");
+    LSA_CHECK(blu_solve_dev(ctx, f, b->dtype, b->d, x->d));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return LSA_OK;
+}
+
+int lsa_blu_solve_time(lsa_ctx* ctx, lsa_blu* f, const lsa_vec* b, lsa_vec* x, int iters, double* avg_ms) {
+    if (!ctx || !f || !b || !x || !avg_ms || iters <= 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_blu_solve_time: bad argument");
+    if (b->n != f->n || x->n != f->n || b->dtype != x->dtype) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_blu_solve_time: vector shape/dtype mismatch");
+    LSA_CHECK(blu_solve_dev(ctx, f, b->dtype, b->d, x->d));
+    LSA_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < iters; ++i) LSA_CHECK(blu_solve_dev(ctx, f, b->dtype, b->d, x->d));
+    LSA_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    LSA_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_ms = (double)ms / iters;
+    return LSA_OK;
+}
+
+int lsa_blu_info(const lsa_blu* f, int32_t* block_size, int32_t* nblocks, int32_t* bandwidth, double* seconds) {
+    if (!f) return LSA_ERR_ARG;
+    if (block_size) *block_size = f->B;
+    if (nblocks) *nblocks = f->nb;
+    if (bandwidth) *bandwidth = f->bandwidth;
+    if (seconds) *seconds = f->seconds;
+    return LSA_OK;
+}
+
+}  // extern "C"

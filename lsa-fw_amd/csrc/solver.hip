@@ -10,6 +10,8 @@
 
 int ilu_check_abort(lsa_ctx* ctx, lsa_ilu* pc);
 int k_allgather_inplace(lsa_ctx* ctx, void* vec, size_t bytes_per_rank);  // comm.hip
+struct lsa_blu;
+int blu_solve_dev(lsa_ctx* ctx, lsa_blu* f, int vdtype, const void* b, void* x);  // blocklu.hip
 
 namespace {
 
@@ -99,9 +101,18 @@ int spmv_global(lsa_ctx* ctx, const lsa_mat* A, int dtype, const void* x, void* 
 }
 
 // x = P^-1 b: block-Jacobi over ranks (each rank holds the ILU(k) of its diagonal block), then all-gather
-int pc_global(lsa_ctx* ctx, lsa_ilu* pc, int32_t row0, int64_t nglobal, int dtype, const void* b, void* x) {
+struct PcRef {
+    lsa_ilu* ilu = nullptr;  // ILU(k) + triangular solves
+    lsa_blu* blu = nullptr;  // exact block-tridiagonal LU
+    explicit operator bool() const { return ilu || blu; }
+};
+
+int pc_global(lsa_ctx* ctx, PcRef pc, int32_t row0, int64_t nglobal, int dtype, const void* b, void* x) {
     const size_t es = esize(dtype);
-    LSA_CHECK(ilu_solve_dev(ctx, pc, 2, dtype, (const char*)b + (size_t)row0 * es, (char*)x + (size_t)row0 * es));
+    const char* bl = (const char*)b + (size_t)row0 * es;
+    char* xl = (char*)x + (size_t)row0 * es;
+    if (pc.blu) LSA_CHECK(blu_solve_dev(ctx, pc.blu, dtype, bl, xl));
+    else LSA_CHECK(ilu_solve_dev(ctx, pc.ilu, 2, dtype, bl, xl));
     if (ctx->nranks > 1) LSA_CHECK(k_allgather_inplace(ctx, x, (size_t)(nglobal / ctx->nranks) * es));
     return LSA_OK;
 }
@@ -143,7 +154,7 @@ struct GmresWork {
 };
 
 // right-preconditioned restarted GMRES on the device; x0 = x when use_x0, else 0
-int gmres_run(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, int dtype, const void* b, void* x, bool use_x0, double rtol,
+int gmres_run(lsa_ctx* ctx, const lsa_mat* C, PcRef pc, int dtype, const void* b, void* x, bool use_x0, double rtol,
               int maxit, GmresWork& W, int32_t* iters_out, double* relres_out, lsa_stats* st) {
     const int64_t n = W.n;
     const int m = W.restart;
@@ -160,6 +171,13 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, int dtype, const void
         if (iters_out) *iters_out = 0;
         if (relres_out) *relres_out = 0.0;
         return LSA_OK;
+    }
+    if (pc.blu && !use_x0) {
+        // exact (block LU) preconditioner: x = P^-1 b is already the solution on one GPU; the loop below then only
+        // checks b - C x and iterates on the residual when the factors are block-Jacobi over ranks
+        LSA_CHECK(pc_global(ctx, pc, C->row0, n, dtype, b, x));
+        if (st) st->sptrsv_calls += 2;
+        use_x0 = true;
     }
     bool converged = false;
     bool first_cycle = true;
@@ -215,7 +233,7 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, int dtype, const void
             zc* Hj = &W.H[(size_t)j * (m + 1)];
             for (int i = 0; i <= j + 1; ++i) Hj[i] = W.hcol[i];
             if (!std::isfinite(Hj[j + 1].real())) {
-                if (pc) LSA_CHECK(ilu_check_abort(ctx, pc));
+                if (pc.ilu) LSA_CHECK(ilu_check_abort(ctx, pc.ilu));
                 return lsa_set_error(ctx, LSA_ERR_NONFINITE, "GMRES: non-finite Hessenberg entry at iteration %d", total);
             }
             for (int i = 0; i < j; ++i) {
@@ -264,7 +282,7 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, int dtype, const void
             }
         }
     }
-    if (pc) LSA_CHECK(ilu_check_abort(ctx, pc));
+    if (pc.ilu) LSA_CHECK(ilu_check_abort(ctx, pc.ilu));
     if (iters_out) *iters_out = total;
     if (relres_out) *relres_out = relres;
     if (st) {
@@ -310,6 +328,7 @@ struct lsa_op {
     lsa_mat* owned;       // the matrix built here (C = A - sigma M), destroyed with the operator
     lsa_mat* owned_diag;  // sharded layout: this rank's diagonal block of C (input of the block-Jacobi ILU)
     lsa_ilu* pc;
+    lsa_blu* blu;         // exact block LU (opts.pc_type == 2)
     lsa_op_options opts;
     GmresWork gw;
     bool gw_ready;
@@ -339,7 +358,9 @@ int lsa_gmres(lsa_ctx* ctx, const lsa_mat* C, lsa_ilu* pc, const lsa_vec* b, lsa
     restart = std::min(restart, maxit);
     GmresWork W;
     int rc = W.alloc(ctx, C->n, restart, b->dtype);
-    if (rc == LSA_OK) rc = gmres_run(ctx, C, pc, b->dtype, b->d, x->d, use_x0 != 0, rtol, maxit, W, iters, rel_res, nullptr);
+    PcRef pcr;
+    pcr.ilu = pc;
+    if (rc == LSA_OK) rc = gmres_run(ctx, C, pcr, b->dtype, b->d, x->d, use_x0 != 0, rtol, maxit, W, iters, rel_res, nullptr);
     (void)hipStreamSynchronize(ctx->stream);
     W.release();
     return rc;
@@ -396,6 +417,7 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
     op->Kmul = op->Kfac = nullptr;
     op->owned = op->owned_diag = nullptr;
     op->pc = nullptr;
+    op->blu = nullptr;
     op->opts = *opts;
     op->gw_ready = false;
     op->t = nullptr;
@@ -429,7 +451,15 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
         op->Kfac = M;
         fac_src = sharded ? Md : M;
     }
-    if (op->Kfac && fac_src && opts->pc_type == 1) {
+    if (op->Kfac && fac_src && opts->pc_type == 2) {
+        // exact block-tridiagonal LU; when the band does not fit the memory budget fall back to ILU(k) + GMRES
+        rc = lsa_blu_create(ctx, fac_src, 0, &op->blu);
+        if (rc != LSA_OK && rc != LSA_ERR_HIP) {
+            lsa_op_destroy(op);
+            return rc;
+        }
+    }
+    if (op->Kfac && fac_src && (opts->pc_type == 1 || (opts->pc_type == 2 && !op->blu))) {
         rc = lsa_ilu_create(ctx, fac_src, opts->ilu_levels, opts->ilu_shift, &op->pc);
         if (rc != LSA_OK) {
             lsa_op_destroy(op);
@@ -461,6 +491,7 @@ void lsa_op_destroy(lsa_op* op) {
     if (!op) return;
     if (op->ctx && op->ctx->stream) (void)hipStreamSynchronize(op->ctx->stream);
     if (op->pc) lsa_ilu_destroy(op->pc);
+    if (op->blu) lsa_blu_destroy(op->blu);
     if (op->owned) lsa_mat_destroy(op->owned);
     if (op->owned_diag) lsa_mat_destroy(op->owned_diag);
     if (op->gw_ready) op->gw.release();
@@ -488,7 +519,10 @@ static int op_apply_dev(lsa_ctx* ctx, lsa_op* op, const void* x, void* y) {
         LSA_CHECK(op->gw.alloc(ctx, op->n, restart, dtype));
         op->gw_ready = true;
     }
-    return gmres_run(ctx, op->Kfac, op->pc, dtype, rhs, y, false, op->opts.ksp_rtol, op->opts.ksp_maxit, op->gw, nullptr, nullptr,
+    PcRef pcr;
+    pcr.ilu = op->pc;
+    pcr.blu = op->blu;
+    return gmres_run(ctx, op->Kfac, pcr, dtype, rhs, y, false, op->opts.ksp_rtol, op->opts.ksp_maxit, op->gw, nullptr, nullptr,
                      &op->st);
 }
 

@@ -100,34 +100,46 @@ __global__ __launch_bounds__(256) void blk_sparse_kernel(int32_t bs, int32_t be,
     if (lane == 0) t[r] = s_sub(rhs[r], acc);
 }
 
-// x[r] = sum_s inv[r, s] t[s] over the triangle of the diagonal block; one wavefront per row
+// x[r] = sum_s inv[r, s] t[s] over the triangle of the diagonal block; one wavefront per row, 1 KiB contiguous per
+// load instruction, eight independent loads in flight per lane (a row of 1024 entries is two sweeps), because a block
+// step moves only a few MB and is bound by memory latency, not bandwidth.
+constexpr int kDenseRows = 4;  // rows (= wavefronts) per 256-thread workgroup
 template <typename MT, typename VT, bool LOWER>
 __global__ __launch_bounds__(256) void blk_dense_kernel(int32_t bs, int32_t be, int32_t B, const MT* __restrict__ inv,
                                                         const VT* __restrict__ t, VT* __restrict__ x) {
     const int lane = threadIdx.x & 63;
-    const int32_t r = bs + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int32_t r = bs + blockIdx.x * kDenseRows + (threadIdx.x >> 6);
     if (r >= be) return;
     const int32_t s0 = LOWER ? bs : r;
     const int32_t s1 = LOWER ? r + 1 : be;
     const MT* row = inv + (size_t)r * B - bs;  // row[s] for global s
-    VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
+    VT acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = scalar_traits<VT>::zero();
     int32_t s = s0 + lane;
-    for (; s + 64 < s1; s += 128) {
-        fma_acc(acc0, row[s], t[s]);
-        fma_acc(acc1, row[s + 64], t[s + 64]);
+    for (; s + 7 * 64 < s1; s += 8 * 64) {
+        MT a[8];
+        VT tv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a[k] = row[s + k * 64];
+            tv[k] = t[s + k * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fma_acc(acc[k & 3], a[k], tv[k]);
     }
-    if (s < s1) fma_acc(acc0, row[s], t[s]);
-    VT acc = s_add(acc0, acc1);
+    for (; s < s1; s += 64) fma_acc(acc[0], row[s], t[s]);
+    VT v = s_add(s_add(acc[0], acc[1]), s_add(acc[2], acc[3]));
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
         if constexpr (sizeof(VT) == 16) {
-            acc.re += __shfl_xor(acc.re, m, 64);
-            acc.im += __shfl_xor(acc.im, m, 64);
+            v.re += __shfl_xor(v.re, m, 64);
+            v.im += __shfl_xor(v.im, m, 64);
         } else {
-            acc += __shfl_xor(acc, m, 64);
+            v += __shfl_xor(v, m, 64);
         }
     }
-    if (lane == 0) x[r] = acc;
+    if (lane == 0) x[r] = v;
 }
 
 template <typename MT, typename VT, bool LOWER>
@@ -139,7 +151,7 @@ void launch_factor(lsa_ctx* ctx, lsa_ilu* pc, const VT* rhs, VT* x, VT* t) {
         const int rows = be - bs;
         hipLaunchKernelGGL((blk_sparse_kernel<MT, VT, LOWER>), dim3((rows * 16 + 255) / 256), dim3(256), 0, ctx->stream, bs, be, pc->rp,
                            pc->ci, LOWER ? pc->lsplit : pc->usplit, (const MT*)pc->val, rhs, (const VT*)x, t);
-        hipLaunchKernelGGL((blk_dense_kernel<MT, VT, LOWER>), dim3((rows + 3) / 4), dim3(256), 0, ctx->stream, bs, be, B,
+        hipLaunchKernelGGL((blk_dense_kernel<MT, VT, LOWER>), dim3((rows + kDenseRows - 1) / kDenseRows), dim3(256), 0, ctx->stream, bs, be, B,
                            (const MT*)(LOWER ? pc->linv : pc->uinv), (const VT*)t, x);
     }
 }

@@ -18,7 +18,25 @@ __device__ __forceinline__ cplx shfl_xor_t<cplx>(cplx v, int mask) {
     return cplx{__shfl_xor(v.re, mask, 64), __shfl_xor(v.im, mask, 64)};
 }
 
-template <typename MT, typename VT, int LPR>
+template <bool NT, typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+    // matrix entries are read exactly once: a non-temporal load keeps them from evicting x out of L2 / Infinity Cache
+    if constexpr (NT) {
+        if constexpr (sizeof(T) == 16) {
+            typedef double v2d __attribute__((ext_vector_type(2)));
+            const v2d v = __builtin_nontemporal_load((const v2d*)p);  // one 16-byte load
+            T out;
+            s_from(out, v.x, v.y);
+            return out;
+        } else {
+            return __builtin_nontemporal_load(p);
+        }
+    } else {
+        return *p;
+    }
+}
+
+template <typename MT, typename VT, int LPR, bool NT>
 __global__ __launch_bounds__(256) void spmv_subwave_kernel(int32_t n, const int32_t* __restrict__ rp,
                                                            const int32_t* __restrict__ ci, const MT* __restrict__ val,
                                                            const VT* __restrict__ x, VT* __restrict__ y) {
@@ -29,31 +47,126 @@ __global__ __launch_bounds__(256) void spmv_subwave_kernel(int32_t n, const int3
     for (; row < n; row += row_stride) {
         const int32_t p0 = rp[row], p1 = rp[row + 1];
         VT acc = scalar_traits<VT>::zero();
-        for (int32_t p = p0 + lane; p < p1; p += LPR) fma_acc(acc, val[p], x[ci[p]]);
+        for (int32_t p = p0 + lane; p < p1; p += LPR) fma_acc(acc, stream_load<NT>(val + p), x[stream_load<NT>(ci + p)]);
 #pragma unroll
         for (int m = LPR / 2; m > 0; m >>= 1) acc = s_add(acc, shfl_xor_t<VT>(acc, m));
         if (lane == 0) y[row] = acc;
     }
 }
 
-template <typename MT, typename VT, int LPR>
-static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y) {
+// Two rows per sub-wave in flight (more independent loads per lane): rows r and r + stride/2 are processed together.
+template <typename MT, typename VT, int LPR, bool NT>
+__global__ __launch_bounds__(256) void spmv_subwave2_kernel(int32_t n, const int32_t* __restrict__ rp,
+                                                            const int32_t* __restrict__ ci, const MT* __restrict__ val,
+                                                            const VT* __restrict__ x, VT* __restrict__ y) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t lane = (int32_t)(gid % LPR);
+    const int64_t half = ((int64_t)gridDim.x * blockDim.x) / LPR;
+    for (int64_t row = gid / LPR; row < n; row += 2 * half) {
+        const int64_t row2 = row + half;
+        const bool has2 = row2 < n;
+        const int32_t p0 = rp[row], p1 = rp[row + 1];
+        const int32_t q0 = has2 ? rp[row2] : 0, q1 = has2 ? rp[row2 + 1] : 0;
+        VT acc = scalar_traits<VT>::zero(), acc2 = scalar_traits<VT>::zero();
+        int32_t p = p0 + lane, q = q0 + lane;
+        for (; p < p1 && q < q1; p += LPR, q += LPR) {
+            const int32_t c1 = stream_load<NT>(ci + p), c2 = stream_load<NT>(ci + q);
+            const MT a1 = stream_load<NT>(val + p), a2 = stream_load<NT>(val + q);
+            fma_acc(acc, a1, x[c1]);
+            fma_acc(acc2, a2, x[c2]);
+        }
+        for (; p < p1; p += LPR) fma_acc(acc, stream_load<NT>(val + p), x[stream_load<NT>(ci + p)]);
+        for (; q < q1; q += LPR) fma_acc(acc2, stream_load<NT>(val + q), x[stream_load<NT>(ci + q)]);
+#pragma unroll
+        for (int m = LPR / 2; m > 0; m >>= 1) {
+            acc = s_add(acc, shfl_xor_t<VT>(acc, m));
+            acc2 = s_add(acc2, shfl_xor_t<VT>(acc2, m));
+        }
+        if (lane == 0) {
+            y[row] = acc;
+            if (has2) y[row2] = acc2;
+        }
+    }
+}
+
+// XCD-aware form: workgroup b is dealt to XCD (b % 8) by the dispatcher, and each XCD has its own 4 MB L2.  With rows
+// interleaved over workgroups every XCD ends up gathering the WHOLE of x (8x the vector in L2 misses: measured 0.63 GB
+// of extra fetch on SROOF = 8 x 80 MB).  Here workgroup b works on the contiguous row chunk
+// (b % 8) * (G / 8) + b / 8, so an XCD walks one eighth of the rows and touches one eighth of x (plus the band).
+template <typename MT, typename VT, int LPR, bool NT>
+__global__ __launch_bounds__(256) void spmv_xcd_kernel(int32_t n, int32_t rows_per_wg, const int32_t* __restrict__ rp,
+                                                       const int32_t* __restrict__ ci, const MT* __restrict__ val,
+                                                       const VT* __restrict__ x, VT* __restrict__ y) {
+    const int32_t G = gridDim.x;  // multiple of 8
+    const int32_t chunk = (int32_t)(blockIdx.x & 7) * (G >> 3) + (int32_t)(blockIdx.x >> 3);
+    const int32_t lane = threadIdx.x % LPR;
+    const int64_t r0 = (int64_t)chunk * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < n) ? r0 + rows_per_wg : n;
+    for (int64_t row = r0 + threadIdx.x / LPR; row < r1; row += 256 / LPR) {
+        const int32_t p0 = rp[row], p1 = rp[row + 1];
+        VT acc = scalar_traits<VT>::zero();
+        for (int32_t p = p0 + lane; p < p1; p += LPR) fma_acc(acc, stream_load<NT>(val + p), x[stream_load<NT>(ci + p)]);
+#pragma unroll
+        for (int m = LPR / 2; m > 0; m >>= 1) acc = s_add(acc, shfl_xor_t<VT>(acc, m));
+        if (lane == 0) y[row] = acc;
+    }
+}
+
+// variant word: bits 0-7 lanes per row (0 = from the mean row length), bit 8 non-temporal matrix loads,
+// bit 9 XCD-contiguous row chunks, bits 16-31 workgroups per CU (0 = 64)
+template <typename MT, typename VT, int LPR, bool NT>
+static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, int variant) {
     const int threads = 256;
     int64_t want = ((int64_t)A->n * LPR + threads - 1) / threads;
-    int64_t cap = (int64_t)ctx->num_cu * 64;  // grid-stride beyond this
+    const int per_cu = (variant >> 16) > 0 ? (variant >> 16) : 64;
+    int64_t cap = (int64_t)ctx->num_cu * per_cu;  // grid-stride beyond this
     int blocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
-    hipLaunchKernelGGL((spmv_subwave_kernel<MT, VT, LPR>), dim3(blocks), dim3(threads), 0, ctx->stream, A->n, A->rp, A->ci,
+    if ((variant & 0x200) && A->n >= 8 * (256 / LPR)) {
+        const int rows_per_pass = 256 / LPR;
+        int G = (int)(((blocks + 7) / 8) * 8);
+        int64_t rows_per_wg = ((int64_t)A->n + G - 1) / G;
+        rows_per_wg = ((rows_per_wg + rows_per_pass - 1) / rows_per_pass) * rows_per_pass;
+        hipLaunchKernelGGL((spmv_xcd_kernel<MT, VT, LPR, NT>), dim3(G), dim3(threads), 0, ctx->stream, A->n, (int32_t)rows_per_wg, A->rp,
+                           A->ci, (const MT*)A->val, (const VT*)x, (VT*)y);
+        return;
+    }
+    if (variant & 0x400) {
+        blocks = (blocks + 1) / 2;
+        hipLaunchKernelGGL((spmv_subwave2_kernel<MT, VT, LPR, NT>), dim3(blocks), dim3(threads), 0, ctx->stream, A->n, A->rp, A->ci,
+                           (const MT*)A->val, (const VT*)x, (VT*)y);
+        return;
+    }
+    hipLaunchKernelGGL((spmv_subwave_kernel<MT, VT, LPR, NT>), dim3(blocks), dim3(threads), 0, ctx->stream, A->n, A->rp, A->ci,
                        (const MT*)A->val, (const VT*)x, (VT*)y);
+}
+
+template <typename MT, typename VT, bool NT>
+static void dispatch_lpr(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, int variant) {
+    int lpr = variant & 0xff;
+    if (lpr == 0) {
+        const double mean = A->n > 0 ? (double)A->nnz / (double)A->n : 0.0;
+        lpr = mean <= 6.0 ? 4 : mean <= 12.0 ? 8 : mean <= 48.0 ? 16 : mean <= 96.0 ? 32 : 64;
+    }
+    switch (lpr) {
+        case 4: launch_spmv<MT, VT, 4, NT>(ctx, A, x, y, variant); break;
+        case 8: launch_spmv<MT, VT, 8, NT>(ctx, A, x, y, variant); break;
+        case 32: launch_spmv<MT, VT, 32, NT>(ctx, A, x, y, variant); break;
+        case 64: launch_spmv<MT, VT, 64, NT>(ctx, A, x, y, variant); break;
+        default: launch_spmv<MT, VT, 16, NT>(ctx, A, x, y, variant); break;
+    }
+}
+
+static int spmv_variant() {
+    // development knob (A/B runs of tools/spmv_only.py); unset = the tuned default
+    const char* e = getenv("LSA_SPMV_VARIANT");
+    return e ? (int)strtol(e, nullptr, 0) : 0;
 }
 
 template <typename MT, typename VT>
 static void dispatch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y) {
-    const double mean = A->n > 0 ? (double)A->nnz / (double)A->n : 0.0;
-    if (mean <= 6.0) launch_spmv<MT, VT, 4>(ctx, A, x, y);
-    else if (mean <= 12.0) launch_spmv<MT, VT, 8>(ctx, A, x, y);
-    else if (mean <= 48.0) launch_spmv<MT, VT, 16>(ctx, A, x, y);
-    else if (mean <= 96.0) launch_spmv<MT, VT, 32>(ctx, A, x, y);
-    else launch_spmv<MT, VT, 64>(ctx, A, x, y);
+    const int variant = spmv_variant();
+    if (variant & 0x100) dispatch_lpr<MT, VT, true>(ctx, A, x, y, variant);
+    else dispatch_lpr<MT, VT, false>(ctx, A, x, y, variant);
 }
 
 int k_spmv(lsa_ctx* ctx, const lsa_mat* A, int xdtype, const void* x, void* y) {

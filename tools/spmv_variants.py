@@ -1,0 +1,47 @@
+"""A/B the SpMV kernel variants on SROOF in one process (development aid; LSA_SPMV_VARIANT is read at every launch)."""
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "lsa-fw_amd")]
+import numpy as np  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
+
+import lsa_hip  # noqa: E402
+from oracle import fem  # noqa: E402
+from Solver.utils import pivot_safe_rcm  # noqa: E402
+
+case, reps = (sys.argv[1] if len(sys.argv) > 1 else "S500k"), int(sys.argv[2]) if len(sys.argv) > 2 else 10
+es = fem.cylinder_case(case)
+C = sp.csr_matrix((es.A.data - fem.SIGMA_RE50 * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+perm = pivot_safe_rcm(C)
+C = C[perm][:, perm].tocsr()
+C.sort_indices()
+n1, nnz1 = C.shape[0], C.nnz
+rp = np.concatenate([[0], (C.indptr[1:][None, :] + (np.arange(reps) * nnz1)[:, None]).ravel()]).astype(np.int32)
+ci = (C.indices[None, :] + (np.arange(reps, dtype=np.int64) * n1)[:, None]).ravel().astype(np.int32)
+big = sp.csr_matrix((np.tile(C.data, reps), ci, rp), shape=(n1 * reps, n1 * reps))
+n, nnz = big.shape[0], big.nnz
+ctx = lsa_hip.Context(0)
+x = np.random.default_rng(0).standard_normal(n) + 1j * np.random.default_rng(1).standard_normal(n)
+dC = lsa_hip.CsrMatrix.from_scipy(ctx, big)
+dx = lsa_hip.DeviceVector.from_numpy(ctx, x)
+dy = lsa_hip.DeviceVector(ctx, n, np.complex128)
+bytes_c = 20.0 * nnz + 36.0 * n
+variants = {}
+for lpr in (8, 16):
+    for nt in (0, 1):
+        for two in (0, 1):
+            for per_cu in (16, 256):
+                variants[f"lpr{lpr} nt{nt} two{two} wg/cu{per_cu}"] = lpr | (nt << 8) | (two << 10) | (per_cu << 16)
+best = {}
+for rnd in range(3):
+    for name, v in variants.items():
+        os.environ["LSA_SPMV_VARIANT"] = str(v)
+        dC.time_matvec(dx, dy, 3)
+        ms = dC.time_matvec(dx, dy, 20)
+        best.setdefault(name, []).append(ms)
+ref = None
+for name, ms in sorted(best.items(), key=lambda kv: np.median(kv[1])):
+    print(f"{name:24s} median {np.median(ms) * 1e3:7.1f} us  min {min(ms) * 1e3:7.1f} us  -> {bytes_c / np.median(ms) / 1e6:7.1f} GB/s", flush=True)

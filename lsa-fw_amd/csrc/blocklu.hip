@@ -181,6 +181,141 @@ __global__ __launch_bounds__(256) void gj_update_kernel(T* __restrict__ a, int32
     }
 }
 
+// ---- blocked form: a panel of w pivot columns is eliminated by ONE workgroup with the panel held in LDS (column-major,
+// m x w), then the other columns get the accumulated rank-w update in one grid-wide launch:
+//     A[:, J] <- (P A)[:, J] with the pivot rows zeroed  +  W * (P A)[K, J]
+// where W (m x w) is what the in-place elimination leaves in the panel columns and K are the panel's pivot rows.
+// 2 launches per w pivots instead of 2 per pivot; the arithmetic is the same elimination in the same order.
+template <typename T>
+__global__ __launch_bounds__(1024) void gj_panel_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k0, int32_t w,
+                                                        int32_t* __restrict__ ipiv, T* __restrict__ Y, int32_t* __restrict__ flag) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    T* Pt = (T*)dyn;                      // Pt[j * m + i] = a[i, k0 + j]
+    T* prow = Pt + (size_t)w * m;         // w entries
+    __shared__ double smag[16];
+    __shared__ int32_t sidx[16];
+    __shared__ int32_t spiv[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int32_t idx = tid; idx < m * w; idx += 1024) {
+        const int32_t i = idx / w, j = idx - i * w;
+        Pt[(size_t)j * m + i] = a[(size_t)i * ld + k0 + j];
+    }
+    __syncthreads();
+    for (int32_t jj = 0; jj < w; ++jj) {
+        const int32_t k = k0 + jj;
+        T* col = Pt + (size_t)jj * m;
+        double best = -1.0;
+        int32_t bi = k;
+        for (int32_t i = k + tid; i < m; i += 1024) {
+            const double mag = s_abs2(col[i]);
+            if (mag > best) {
+                best = mag;
+                bi = i;
+            }
+        }
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) {
+            const double ob = __shfl_xor(best, s, 64);
+            const int32_t oi = __shfl_xor(bi, s, 64);
+            if (ob > best || (ob == best && oi < bi)) {
+                best = ob;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            smag[wave] = best;
+            sidx[wave] = bi;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double b = smag[0];
+            int32_t i0 = sidx[0];
+            for (int q = 1; q < 16; ++q)
+                if (smag[q] > b || (smag[q] == b && sidx[q] < i0)) {
+                    b = smag[q];
+                    i0 = sidx[q];
+                }
+            spiv[jj] = i0;
+            ipiv[k] = i0;
+            if (!(b > 0.0)) atomicCAS(&flag[1], 0, k + 1);
+        }
+        __syncthreads();
+        const int32_t p = spiv[jj];
+        if (p != k && tid < w) {
+            const T tmp = Pt[(size_t)tid * m + k];
+            Pt[(size_t)tid * m + k] = Pt[(size_t)tid * m + p];
+            Pt[(size_t)tid * m + p] = tmp;
+        }
+        __syncthreads();
+        T piv = col[k];
+        if (s_abs2(piv) == 0.0) s_from(piv, 1.0, 0.0);
+        const T pinv = s_inv(piv);
+        __syncthreads();
+        if (tid < w) {
+            const T v = (tid == jj) ? pinv : s_mul(pinv, Pt[(size_t)tid * m + k]);
+            prow[tid] = v;
+            Pt[(size_t)tid * m + k] = v;
+        }
+        __syncthreads();
+        for (int32_t i = tid; i < m; i += 1024) {
+            if (i == k) continue;
+            const T fm = col[i];
+            if (s_abs2(fm) == 0.0) continue;
+            for (int32_t j = 0; j < w; ++j) {
+                T* e = Pt + (size_t)j * m + i;
+                const T base = (j == jj) ? scalar_traits<T>::zero() : *e;
+                *e = s_sub(base, s_mul(fm, prow[j]));
+            }
+        }
+        __syncthreads();
+    }
+    // row interchanges on the columns outside the panel, in pivot order
+    for (int32_t jj = 0; jj < w; ++jj) {
+        const int32_t k = k0 + jj, p = spiv[jj];
+        if (p != k) {
+            for (int32_t c = tid; c < m; c += 1024) {
+                if (c >= k0 && c < k0 + w) continue;
+                const T tmp = a[(size_t)k * ld + c];
+                a[(size_t)k * ld + c] = a[(size_t)p * ld + c];
+                a[(size_t)p * ld + c] = tmp;
+            }
+        }
+        __syncthreads();
+    }
+    // the pivot rows of the other columns, as they are before this panel's elimination touches them
+    for (int32_t idx = tid; idx < m * w; idx += 1024) {
+        const int32_t jj = idx / m, c = idx - jj * m;
+        Y[(size_t)jj * m + c] = a[(size_t)(k0 + jj) * ld + c];
+    }
+    // panel back to global memory
+    for (int32_t idx = tid; idx < m * w; idx += 1024) {
+        const int32_t i = idx / w, j = idx - i * w;
+        a[(size_t)i * ld + k0 + j] = Pt[(size_t)j * m + i];
+    }
+}
+
+// a[i, c] = (i in panel rows ? 0 : a[i, c]) + sum_j W[i, j] Y[j, c] for the columns c outside the panel; wavefront per row
+template <typename T>
+__global__ __launch_bounds__(256) void gj_panel_update_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k0, int32_t w,
+                                                              const T* __restrict__ Y) {
+    const int lane = threadIdx.x & 63;
+    const int32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= m) return;
+    T* ri = a + (size_t)i * ld;
+    T wv[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wv[j] = (j < w) ? ri[k0 + j] : scalar_traits<T>::zero();
+    const bool pivot_row = i >= k0 && i < k0 + w;
+    for (int32_t c = lane; c < m; c += 64) {
+        if (c >= k0 && c < k0 + w) continue;
+        T acc = pivot_row ? scalar_traits<T>::zero() : ri[c];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < w) fma_acc(acc, wv[j], Y[(size_t)j * m + c]);
+        ri[c] = acc;
+    }
+}
+
 // undo the row interchanges on the columns of the inverse: thread per row, swaps in reverse order
 template <typename T>
 __global__ void gj_unpivot_kernel(T* __restrict__ a, int32_t ld, int32_t m, const int32_t* __restrict__ ipiv) {
@@ -270,6 +405,14 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
     LSA_HIP_CHECK(ctx, hipMemsetAsync(f->flag, 0, 4 * sizeof(int32_t), ctx->stream));
     const size_t lds = (size_t)B * sizeof(T);
     if (lds > 64 * 1024) LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // panel width of the blocked Gauss-Jordan: the m x w panel must fit LDS (w = 8 for complex B = 1024); w < 2 or
+    // LSA_GJ_PANEL=1 selects the unblocked form (two launches per pivot)
+    int32_t panel_w = (int32_t)std::min<size_t>(16, (144 * 1024) / ((size_t)B * sizeof(T)));
+    if (const char* e = getenv("LSA_GJ_PANEL")) panel_w = std::min(panel_w, atoi(e));
+    if (panel_w >= 2) {
+        const size_t plds = ((size_t)panel_w * B + panel_w) * sizeof(T);
+        LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gj_panel_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+    }
     for (int32_t b = 0; b < f->nb; ++b) {
         const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
         T* S = (T*)f->sinv + (size_t)bs * B;
@@ -280,9 +423,18 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
             hipLaunchKernelGGL((blu_corner_kernel<T>), dim3(m), dim3(256), lds, ctx->stream, ps, bs, be, B, C->rp, C->ci, f->lsplit,
                                (const T*)C->val, f->cptr, f->crow, f->cpos, (const T*)f->sinv + (size_t)ps * B, S);
         }
-        for (int32_t k = 0; k < m; ++k) {
-            hipLaunchKernelGGL((gj_pivot_kernel<T>), dim3(1), dim3(1024), 0, ctx->stream, S, B, m, k, f->ipiv, (T*)f->colbuf, f->flag);
-            hipLaunchKernelGGL((gj_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, S, B, m, k, (const T*)f->colbuf);
+        if (panel_w >= 2) {
+            for (int32_t k0 = 0; k0 < m; k0 += panel_w) {
+                const int32_t w = std::min(panel_w, m - k0);
+                const size_t plds = ((size_t)w * m + w) * sizeof(T);
+                hipLaunchKernelGGL((gj_panel_kernel<T>), dim3(1), dim3(1024), plds, ctx->stream, S, B, m, k0, w, f->ipiv, (T*)f->colbuf, f->flag);
+                hipLaunchKernelGGL((gj_panel_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, S, B, m, k0, w, (const T*)f->colbuf);
+            }
+        } else {
+            for (int32_t k = 0; k < m; ++k) {
+                hipLaunchKernelGGL((gj_pivot_kernel<T>), dim3(1), dim3(1024), 0, ctx->stream, S, B, m, k, f->ipiv, (T*)f->colbuf, f->flag);
+                hipLaunchKernelGGL((gj_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, S, B, m, k, (const T*)f->colbuf);
+            }
         }
         hipLaunchKernelGGL((gj_unpivot_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, ctx->stream, S, B, m, f->ipiv);
     }
@@ -428,7 +580,7 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     bool ok = hipMalloc((void**)&f->lsplit, 4 * n1) == hipSuccess && hipMalloc((void**)&f->usplit, 4 * n1) == hipSuccess &&
               hipMalloc((void**)&f->cptr, 4 * (n1 + 1)) == hipSuccess && hipMalloc((void**)&f->crow, 4 * z1) == hipSuccess &&
               hipMalloc((void**)&f->cpos, 4 * z1) == hipSuccess && hipMalloc(&f->sinv, inv_bytes) == hipSuccess &&
-              hipMalloc((void**)&f->ipiv, 4 * (size_t)B) == hipSuccess && hipMalloc(&f->colbuf, esz * (size_t)B) == hipSuccess &&
+              hipMalloc((void**)&f->ipiv, 4 * (size_t)B) == hipSuccess && hipMalloc(&f->colbuf, esz * (size_t)B * 16) == hipSuccess &&
               hipMalloc((void**)&f->flag, 16) == hipSuccess;
     hipStream_t s = ctx->stream;
     ok = ok && hipMemcpyAsync(f->lsplit, ls.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s) == hipSuccess &&

@@ -27,9 +27,12 @@ struct lsa_blu {
     int32_t *lsplit = nullptr, *usplit = nullptr;                 // device: per row, first entry with col >= block start / end
     int32_t *cptr = nullptr, *crow = nullptr, *cpos = nullptr;    // device CSC view of C (setup only)
     void* sinv = nullptr;                                         // device: n x B row-major, block b = rows [b*B, ...)
-    int32_t* ipiv = nullptr;
-    void* colbuf = nullptr;
+    int32_t* ipiv[2] = {nullptr, nullptr};   // Gauss-Jordan workspaces, one per chain
+    void* colbuf[2] = {nullptr, nullptr};
     int32_t* flag = nullptr;
+    hipStream_t stream2 = nullptr;          // second chain of the twisted factorisation / solve
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int32_t mid = 0;                        // middle block: chains run 0 .. mid-1 and nb-1 .. mid+1
     void *t[2] = {nullptr, nullptr}, *y[2] = {nullptr, nullptr}, *z[2] = {nullptr, nullptr};
     void *in[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr};
     void* graph[2] = {nullptr, nullptr};
@@ -54,22 +57,25 @@ __global__ void blu_scatter_kernel(int32_t bs, int32_t be, int32_t B, const int3
     for (int32_t p = lsplit[r] + lane; p < usplit[r]; p += 16) S[(size_t)(r - bs) * B + (ci[p] - bs)] = val[p];
 }
 
-// S[r, :] -= (C[r, prev block] * Sinv_prev) * C[prev block, this block]   (only rows with entries left of the block)
-template <typename T>
-__global__ __launch_bounds__(256) void blu_corner_kernel(int32_t ps, int32_t bs, int32_t be, int32_t B, const int32_t* __restrict__ rp,
-                                                         const int32_t* __restrict__ ci, const int32_t* __restrict__ lsplit,
+// S[r, :] -= (C[r, nbr block] * Sinv_nbr) * C[nbr block, this block] for the neighbour block [ns, ne) on the left
+// (RIGHT = false) or on the right (RIGHT = true) of block [bs, be); only rows with entries in that neighbour do work
+template <typename T, bool RIGHT>
+__global__ __launch_bounds__(256) void blu_corner_kernel(int32_t ns, int32_t ne, int32_t bs, int32_t be, int32_t B,
+                                                         const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                         const int32_t* __restrict__ lsplit, const int32_t* __restrict__ usplit,
                                                          const T* __restrict__ val, const int32_t* __restrict__ cptr,
                                                          const int32_t* __restrict__ crow, const int32_t* __restrict__ cpos,
-                                                         const T* __restrict__ sinv_prev, T* __restrict__ S) {
+                                                         const T* __restrict__ sinv_nbr, T* __restrict__ S) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
-    T* X = (T*)dyn;  // row r of C_{b,b-1} * Sinv_{b-1}: m1 entries
+    T* X = (T*)dyn;  // row r of C_{b,nbr} * Sinv_nbr
     const int32_t r = bs + blockIdx.x;
-    const int32_t g0 = rp[r], g1 = lsplit[r];
-    if (g0 == g1) return;  // no coupling to the previous block
-    const int32_t m1 = bs - ps;
+    const int32_t g0 = RIGHT ? usplit[r] : rp[r];
+    const int32_t g1 = RIGHT ? rp[r + 1] : lsplit[r];
+    if (g0 == g1) return;  // no coupling to that neighbour
+    const int32_t m1 = ne - ns;
     for (int32_t k = threadIdx.x; k < m1; k += 256) {
         T acc = scalar_traits<T>::zero();
-        for (int32_t p = g0; p < g1; ++p) fma_acc(acc, val[p], sinv_prev[(size_t)(ci[p] - ps) * B + k]);
+        for (int32_t p = g0; p < g1; ++p) fma_acc(acc, val[p], sinv_nbr[(size_t)(ci[p] - ns) * B + k]);
         X[k] = acc;
     }
     __syncthreads();
@@ -80,9 +86,8 @@ __global__ __launch_bounds__(256) void blu_corner_kernel(int32_t ps, int32_t bs,
         bool any = false;
         for (int32_t q = q0; q < q1; ++q) {
             const int32_t k = crow[q];
-            if (k >= bs) break;  // rows are sorted inside a column
-            if (k >= ps) {
-                fma_acc(acc, X[k - ps], val[cpos[q]]);
+            if (k >= ns && k < ne) {
+                fma_acc(acc, X[k - ns], val[cpos[q]]);
                 any = true;
             }
         }
@@ -359,6 +364,31 @@ __global__ __launch_bounds__(256) void blu_sparse_kernel(int32_t bs, int32_t be,
     if (lane == 0) out[r] = s_sub(rhs[r], acc);
 }
 
+// middle block of the twisted sweep: out[r] = rhs[r] - (entries left AND right of the diagonal block) * x
+template <typename MT, typename VT>
+__global__ __launch_bounds__(256) void blu_sparse_both_kernel(int32_t bs, int32_t be, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                              const int32_t* __restrict__ lsplit, const int32_t* __restrict__ usplit,
+                                                              const MT* __restrict__ val, const VT* __restrict__ rhs, const VT* __restrict__ x,
+                                                              VT* __restrict__ out) {
+    const int32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = gid & 15;
+    const int32_t r = bs + (gid >> 4);
+    if (r >= be) return;
+    VT acc = scalar_traits<VT>::zero();
+    for (int32_t p = rp[r] + lane; p < lsplit[r]; p += 16) fma_acc(acc, val[p], x[ci[p]]);
+    for (int32_t p = usplit[r] + lane; p < rp[r + 1]; p += 16) fma_acc(acc, val[p], x[ci[p]]);
+#pragma unroll
+    for (int s = 8; s > 0; s >>= 1) {
+        if constexpr (sizeof(VT) == 16) {
+            acc.re += __shfl_xor(acc.re, s, 64);
+            acc.im += __shfl_xor(acc.im, s, 64);
+        } else {
+            acc += __shfl_xor(acc, s, 64);
+        }
+    }
+    if (lane == 0) out[r] = s_sub(rhs[r], acc);
+}
+
 // out[r] = sum_s Sinv[r, s] in[s] over the whole diagonal block; one wavefront per row, 8 loads in flight per lane
 template <typename MT, typename VT>
 __global__ __launch_bounds__(256) void blu_dense_kernel(int32_t bs, int32_t be, int32_t B, const MT* __restrict__ sinv,
@@ -404,7 +434,10 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
     LSA_HIP_CHECK(ctx, hipMemsetAsync(f->sinv, 0, inv_bytes, ctx->stream));
     LSA_HIP_CHECK(ctx, hipMemsetAsync(f->flag, 0, 4 * sizeof(int32_t), ctx->stream));
     const size_t lds = (size_t)B * sizeof(T);
-    if (lds > 64 * 1024) LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) {
+        LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     // panel width of the blocked Gauss-Jordan: the m x w panel must fit LDS (w = 8 for complex B = 1024); w < 2 or
     // LSA_GJ_PANEL=1 selects the unblocked form (two launches per pivot)
     int32_t panel_w = (int32_t)std::min<size_t>(16, (144 * 1024) / ((size_t)B * sizeof(T)));
@@ -413,31 +446,49 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
         const size_t plds = ((size_t)panel_w * B + panel_w) * sizeof(T);
         LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gj_panel_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
     }
-    for (int32_t b = 0; b < f->nb; ++b) {
+    // one block: scatter C_bb, subtract the Schur corrections of the already inverted neighbours, invert in place
+    auto factor_block = [&](hipStream_t st, int chain, int32_t b, bool corr_left, bool corr_right) {
         const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
         T* S = (T*)f->sinv + (size_t)bs * B;
-        hipLaunchKernelGGL((blu_scatter_kernel<T>), dim3((m * 16 + 255) / 256), dim3(256), 0, ctx->stream, bs, be, B, C->rp, C->ci, f->lsplit,
-                           f->usplit, (const T*)C->val, S);
-        if (b > 0) {
-            const int32_t ps = bs - B;
-            hipLaunchKernelGGL((blu_corner_kernel<T>), dim3(m), dim3(256), lds, ctx->stream, ps, bs, be, B, C->rp, C->ci, f->lsplit,
-                               (const T*)C->val, f->cptr, f->crow, f->cpos, (const T*)f->sinv + (size_t)ps * B, S);
+        hipLaunchKernelGGL((blu_scatter_kernel<T>), dim3((m * 16 + 255) / 256), dim3(256), 0, st, bs, be, B, C->rp, C->ci, f->lsplit, f->usplit,
+                           (const T*)C->val, S);
+        if (corr_left) {
+            const int32_t ns = bs - B;
+            hipLaunchKernelGGL((blu_corner_kernel<T, false>), dim3(m), dim3(256), lds, st, ns, bs, bs, be, B, C->rp, C->ci, f->lsplit, f->usplit,
+                               (const T*)C->val, f->cptr, f->crow, f->cpos, (const T*)f->sinv + (size_t)ns * B, S);
         }
+        if (corr_right) {
+            const int32_t ns = be, ne = std::min(n, be + B);
+            hipLaunchKernelGGL((blu_corner_kernel<T, true>), dim3(m), dim3(256), lds, st, ns, ne, bs, be, B, C->rp, C->ci, f->lsplit, f->usplit,
+                               (const T*)C->val, f->cptr, f->crow, f->cpos, (const T*)f->sinv + (size_t)ns * B, S);
+        }
+        int32_t* ipiv = f->ipiv[chain];
+        T* ws = (T*)f->colbuf[chain];
         if (panel_w >= 2) {
             for (int32_t k0 = 0; k0 < m; k0 += panel_w) {
                 const int32_t w = std::min(panel_w, m - k0);
                 const size_t plds = ((size_t)w * m + w) * sizeof(T);
-                hipLaunchKernelGGL((gj_panel_kernel<T>), dim3(1), dim3(1024), plds, ctx->stream, S, B, m, k0, w, f->ipiv, (T*)f->colbuf, f->flag);
-                hipLaunchKernelGGL((gj_panel_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, S, B, m, k0, w, (const T*)f->colbuf);
+                hipLaunchKernelGGL((gj_panel_kernel<T>), dim3(1), dim3(1024), plds, st, S, B, m, k0, w, ipiv, ws, f->flag);
+                hipLaunchKernelGGL((gj_panel_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, st, S, B, m, k0, w, (const T*)ws);
             }
         } else {
             for (int32_t k = 0; k < m; ++k) {
-                hipLaunchKernelGGL((gj_pivot_kernel<T>), dim3(1), dim3(1024), 0, ctx->stream, S, B, m, k, f->ipiv, (T*)f->colbuf, f->flag);
-                hipLaunchKernelGGL((gj_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, S, B, m, k, (const T*)f->colbuf);
+                hipLaunchKernelGGL((gj_pivot_kernel<T>), dim3(1), dim3(1024), 0, st, S, B, m, k, ipiv, ws, f->flag);
+                hipLaunchKernelGGL((gj_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, st, S, B, m, k, (const T*)ws);
             }
         }
-        hipLaunchKernelGGL((gj_unpivot_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, ctx->stream, S, B, m, f->ipiv);
-    }
+        hipLaunchKernelGGL((gj_unpivot_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, st, S, B, m, ipiv);
+    };
+    // twisted order: chain 0 eliminates downwards from block 0, chain 1 upwards from the last block, on two streams;
+    // they meet at the middle block, which receives both corrections
+    const int32_t nb = f->nb, mid = f->mid;
+    LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_fork, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipStreamWaitEvent(f->stream2, f->ev_fork, 0));
+    for (int32_t b = 0; b < mid; ++b) factor_block(ctx->stream, 0, b, b > 0, false);
+    for (int32_t b = nb - 1; b > mid; --b) factor_block(f->stream2, 1, b, false, b < nb - 1);
+    LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_join, f->stream2));
+    LSA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, f->ev_join, 0));
+    if (nb > 0) factor_block(ctx->stream, 0, mid, mid > 0, mid < nb - 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "block LU launch failed: %s", hipGetErrorString(e));
     int32_t hflag[4];
@@ -448,26 +499,68 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
 }
 
 template <typename MT, typename VT>
-void launch_apply(lsa_ctx* ctx, lsa_blu* f, const VT* v, VT* x, VT* y, VT* z, VT* t) {
-    const int32_t B = f->B, nb = f->nb, n = f->n;
+int launch_apply(lsa_ctx* ctx, lsa_blu* f, const VT* v, VT* x, VT* y, VT* z, VT* t) {
+    const int32_t B = f->B, nb = f->nb, n = f->n, mid = f->mid;
     const lsa_mat* C = f->C;
-    // forward: y_b = v_b - C_{b,b-1} z_{b-1},  z_b = Sinv_b y_b
-    for (int32_t b = 0; b < nb; ++b) {
+    // The sweeps' kernels are a few microseconds each: measured at S30k, running the two chains on two queues costs
+    // 796 us per apply against 538 us for the same twisted order on one queue (graph replay), so the solve stays on
+    // one stream; the factorisation, whose panel kernels occupy one CU for ~50 us, does gain from two (0.35 -> 0.21 s).
+    static const bool two_streams = getenv("LSA_BLU_SOLVE_STREAMS") && atoi(getenv("LSA_BLU_SOLVE_STREAMS")) == 2;
+    hipStream_t s0 = ctx->stream, s1 = two_streams ? f->stream2 : ctx->stream;
+    auto sparse = [&](hipStream_t st, bool left, int32_t b, const VT* rhs, const VT* xin, VT* out) {
         const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
-        hipLaunchKernelGGL((blu_sparse_kernel<MT, VT, true>), dim3((m * 16 + 255) / 256), dim3(256), 0, ctx->stream, bs, be, C->rp, C->ci,
-                           f->lsplit, f->usplit, (const MT*)C->val, v, (const VT*)z, y);
-        if (b + 1 < nb)
-            hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, bs, be, B, (const MT*)f->sinv,
-                               (const VT*)y, z);
-    }
-    // backward: x_b = Sinv_b (y_b - C_{b,b+1} x_{b+1})
-    for (int32_t b = nb - 1; b >= 0; --b) {
+        if (left)
+            hipLaunchKernelGGL((blu_sparse_kernel<MT, VT, true>), dim3((m * 16 + 255) / 256), dim3(256), 0, st, bs, be, C->rp, C->ci, f->lsplit,
+                               f->usplit, (const MT*)C->val, rhs, xin, out);
+        else
+            hipLaunchKernelGGL((blu_sparse_kernel<MT, VT, false>), dim3((m * 16 + 255) / 256), dim3(256), 0, st, bs, be, C->rp, C->ci, f->lsplit,
+                               f->usplit, (const MT*)C->val, rhs, xin, out);
+    };
+    auto dense = [&](hipStream_t st, int32_t b, const VT* in, VT* out) {
         const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
-        hipLaunchKernelGGL((blu_sparse_kernel<MT, VT, false>), dim3((m * 16 + 255) / 256), dim3(256), 0, ctx->stream, bs, be, C->rp, C->ci,
-                           f->lsplit, f->usplit, (const MT*)C->val, (const VT*)y, (const VT*)x, t);
-        hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3((m + 3) / 4), dim3(256), 0, ctx->stream, bs, be, B, (const MT*)f->sinv,
-                           (const VT*)t, x);
+        hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3((m + 3) / 4), dim3(256), 0, st, bs, be, B, (const MT*)f->sinv, in, out);
+    };
+    // elimination towards the middle, two chains in parallel:  y_b = v_b - C_{b,b-+1} z_{b-+1},  z_b = Sinv_b y_b
+    LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_fork, s0));
+    LSA_HIP_CHECK(ctx, hipStreamWaitEvent(s1, f->ev_fork, 0));
+    // (the two chains are enqueued alternately so that neither queue waits for the host)
+    for (int32_t k = 0; k < std::max(mid, nb - 1 - mid); ++k) {
+        const int32_t bt = k, bb = nb - 1 - k;
+        if (bt < mid) {
+            sparse(s0, true, bt, v, (const VT*)z, y);
+            dense(s0, bt, (const VT*)y, z);
+        }
+        if (bb > mid) {
+            sparse(s1, false, bb, v, (const VT*)z, y);
+            dense(s1, bb, (const VT*)y, z);
+        }
     }
+    LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_join, s1));
+    LSA_HIP_CHECK(ctx, hipStreamWaitEvent(s0, f->ev_join, 0));
+    // middle block: x_m = Sinv_m (v_m - C_{m,m-1} z_{m-1} - C_{m,m+1} z_{m+1})
+    {
+        const int32_t bs = mid * B, be = std::min(n, bs + B), m = be - bs;
+        hipLaunchKernelGGL((blu_sparse_both_kernel<MT, VT>), dim3((m * 16 + 255) / 256), dim3(256), 0, s0, bs, be, C->rp, C->ci, f->lsplit,
+                           f->usplit, (const MT*)C->val, v, (const VT*)z, t);
+        dense(s0, mid, (const VT*)t, x);
+    }
+    // substitution outwards, two chains in parallel:  x_b = Sinv_b (y_b - C_{b,b+-1} x_{b+-1})
+    LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_fork, s0));
+    LSA_HIP_CHECK(ctx, hipStreamWaitEvent(s1, f->ev_fork, 0));
+    for (int32_t k = 1; k <= std::max(mid, nb - 1 - mid); ++k) {
+        const int32_t bt = mid - k, bb = mid + k;
+        if (bt >= 0) {
+            sparse(s0, false, bt, (const VT*)y, (const VT*)x, t);
+            dense(s0, bt, (const VT*)t, x);
+        }
+        if (bb < nb) {
+            sparse(s1, true, bb, (const VT*)y, (const VT*)x, t);
+            dense(s1, bb, (const VT*)t, x);
+        }
+    }
+    LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_join, s1));
+    LSA_HIP_CHECK(ctx, hipStreamWaitEvent(s0, f->ev_join, 0));
+    return LSA_OK;
 }
 
 template <typename MT, typename VT>
@@ -484,7 +577,7 @@ int apply_typed(lsa_ctx* ctx, lsa_blu* f, const void* b, void* x) {
     VT *t = (VT*)f->t[vd], *y = (VT*)f->y[vd], *z = (VT*)f->z[vd], *in = (VT*)f->in[vd], *out = (VT*)f->out[vd];
     static const bool use_graph = !(getenv("LSA_SPTRSV_GRAPH") && atoi(getenv("LSA_SPTRSV_GRAPH")) == 0);
     if (!use_graph) {
-        launch_apply<MT, VT>(ctx, f, (const VT*)b, (VT*)x, y, z, t);
+        LSA_CHECK((launch_apply<MT, VT>(ctx, f, (const VT*)b, (VT*)x, y, z, t)));
         hipError_t le = hipGetLastError();
         if (le != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "block LU solve launch failed: %s", hipGetErrorString(le));
         return LSA_OK;
@@ -492,8 +585,9 @@ int apply_typed(lsa_ctx* ctx, lsa_blu* f, const void* b, void* x) {
     if (!f->graph[vd]) {
         hipGraph_t graph = nullptr;
         LSA_HIP_CHECK(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
-        launch_apply<MT, VT>(ctx, f, in, out, y, z, t);
+        const int crc = launch_apply<MT, VT>(ctx, f, in, out, y, z, t);
         hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+        if (crc != LSA_OK) return crc;
         if (e != hipSuccess || !graph) return lsa_set_error(ctx, LSA_ERR_HIP, "block LU: graph capture failed: %s", hipGetErrorString(e));
         hipGraphExec_t exec = nullptr;
         e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
@@ -527,8 +621,13 @@ void lsa_blu_destroy(lsa_blu* f) {
         for (void* p : {f->t[vd], f->y[vd], f->z[vd], f->in[vd], f->out[vd]})
             if (p) (void)hipFree(p);
     }
-    for (void* p : {(void*)f->lsplit, (void*)f->usplit, (void*)f->cptr, (void*)f->crow, (void*)f->cpos, f->sinv, (void*)f->ipiv, f->colbuf, (void*)f->flag})
+    if (f->stream2) (void)hipStreamSynchronize(f->stream2);
+    for (void* p : {(void*)f->lsplit, (void*)f->usplit, (void*)f->cptr, (void*)f->crow, (void*)f->cpos, f->sinv, (void*)f->ipiv[0], (void*)f->ipiv[1],
+                    f->colbuf[0], f->colbuf[1], (void*)f->flag})
         if (p) (void)hipFree(p);
+    if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
+    if (f->ev_join) (void)hipEventDestroy(f->ev_join);
+    if (f->stream2) (void)hipStreamDestroy(f->stream2);
     delete f;
 }
 
@@ -555,6 +654,7 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     f->n = n;
     f->B = B;
     f->nb = n > 0 ? (n + B - 1) / B : 0;
+    f->mid = f->nb / 2;
     f->bandwidth = bw;
     f->dtype = C->dtype;
     // splits on C's pattern and a CSC view (positions into C's value array) for the corner update
@@ -580,8 +680,11 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     bool ok = hipMalloc((void**)&f->lsplit, 4 * n1) == hipSuccess && hipMalloc((void**)&f->usplit, 4 * n1) == hipSuccess &&
               hipMalloc((void**)&f->cptr, 4 * (n1 + 1)) == hipSuccess && hipMalloc((void**)&f->crow, 4 * z1) == hipSuccess &&
               hipMalloc((void**)&f->cpos, 4 * z1) == hipSuccess && hipMalloc(&f->sinv, inv_bytes) == hipSuccess &&
-              hipMalloc((void**)&f->ipiv, 4 * (size_t)B) == hipSuccess && hipMalloc(&f->colbuf, esz * (size_t)B * 16) == hipSuccess &&
-              hipMalloc((void**)&f->flag, 16) == hipSuccess;
+              hipMalloc((void**)&f->ipiv[0], 4 * (size_t)B) == hipSuccess && hipMalloc((void**)&f->ipiv[1], 4 * (size_t)B) == hipSuccess &&
+              hipMalloc(&f->colbuf[0], esz * (size_t)B * 16) == hipSuccess && hipMalloc(&f->colbuf[1], esz * (size_t)B * 16) == hipSuccess &&
+              hipMalloc((void**)&f->flag, 16) == hipSuccess && hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming) == hipSuccess;
     hipStream_t s = ctx->stream;
     ok = ok && hipMemcpyAsync(f->lsplit, ls.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(f->usplit, us.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s) == hipSuccess &&

@@ -45,6 +45,17 @@ inline double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// out[0] = max |v|^2 (bit pattern of a non-negative double orders like an unsigned integer)
+template <typename T>
+__global__ void maxabs2_kernel(int64_t nnz, const T* __restrict__ v, unsigned long long* __restrict__ out) {
+    double best = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nnz; p += stride) best = fmax(best, s_abs2(v[p]));
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) best = fmax(best, __shfl_xor(best, s, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(best));
+}
+
 // S[r - bs, c - bs] = C[r, c] for the entries of block row b that fall into the diagonal block
 template <typename T>
 __global__ void blu_scatter_kernel(int32_t bs, int32_t be, int32_t B, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
@@ -101,7 +112,7 @@ __global__ __launch_bounds__(256) void blu_corner_kernel(int32_t ns, int32_t ne,
 // ---- in-place Gauss-Jordan inversion with partial pivoting: two launches per pivot column -----------------------------
 template <typename T>
 __global__ __launch_bounds__(1024) void gj_pivot_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k, int32_t* __restrict__ ipiv,
-                                                        T* __restrict__ colbuf, int32_t* __restrict__ flag) {
+                                                        T* __restrict__ colbuf, int32_t* __restrict__ flag, double tiny2) {
     __shared__ double smag[16];
     __shared__ int32_t sidx[16];
     __shared__ int32_t spiv;
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(1024) void gj_pivot_kernel(T* __restrict__ a, int32
             }
         spiv = i0;
         ipiv[k] = i0;
-        if (!(b > 0.0)) atomicCAS(&flag[1], 0, k + 1);  // singular block
+        if (!(b > tiny2)) atomicCAS(&flag[1], 0, k + 1);  // (numerically) singular block
     }
     __syncthreads();
     const int32_t p = spiv;
@@ -193,7 +204,7 @@ __global__ __launch_bounds__(256) void gj_update_kernel(T* __restrict__ a, int32
 // 2 launches per w pivots instead of 2 per pivot; the arithmetic is the same elimination in the same order.
 template <typename T>
 __global__ __launch_bounds__(1024) void gj_panel_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k0, int32_t w,
-                                                        int32_t* __restrict__ ipiv, T* __restrict__ Y, int32_t* __restrict__ flag) {
+                                                        int32_t* __restrict__ ipiv, T* __restrict__ Y, int32_t* __restrict__ flag, double tiny2) {
     extern __shared__ __attribute__((aligned(16))) char dyn[];
     T* Pt = (T*)dyn;                      // Pt[j * m + i] = a[i, k0 + j]
     T* prow = Pt + (size_t)w * m;         // w entries
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(1024) void gj_panel_kernel(T* __restrict__ a, int32
                 }
             spiv[jj] = i0;
             ipiv[k] = i0;
-            if (!(b > 0.0)) atomicCAS(&flag[1], 0, k + 1);
+            if (!(b > tiny2)) atomicCAS(&flag[1], 0, k + 1);
         }
         __syncthreads();
         const int32_t p = spiv[jj];
@@ -433,6 +444,21 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
     const size_t inv_bytes = (size_t)n * B * sizeof(T);
     LSA_HIP_CHECK(ctx, hipMemsetAsync(f->sinv, 0, inv_bytes, ctx->stream));
     LSA_HIP_CHECK(ctx, hipMemsetAsync(f->flag, 0, 4 * sizeof(int32_t), ctx->stream));
+    // pivots below 1e-12 of the largest entry of C mean a singular Schur block (a singular leading block of C): block
+    // elimination without pivoting across blocks cannot continue; the caller then falls back to ILU(k) + GMRES
+    double tiny2 = 0.0;
+    {
+        unsigned long long* dmax = (unsigned long long*)ctx->dscratch;
+        LSA_HIP_CHECK(ctx, hipMemsetAsync(dmax, 0, sizeof(unsigned long long), ctx->stream));
+        hipLaunchKernelGGL((maxabs2_kernel<T>), dim3(std::max(1, std::min(ctx->num_cu * 4, (int)((C->nnz + 255) / 256)))), dim3(256), 0, ctx->stream,
+                           C->nnz, (const T*)C->val, dmax);
+        unsigned long long hmax = 0;
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(&hmax, dmax, sizeof hmax, hipMemcpyDeviceToHost, ctx->stream));
+        LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        double m2;
+        memcpy(&m2, &hmax, sizeof m2);
+        tiny2 = 1e-24 * m2;
+    }
     const size_t lds = (size_t)B * sizeof(T);
     if (lds > 64 * 1024) {
         LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -468,12 +494,12 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
             for (int32_t k0 = 0; k0 < m; k0 += panel_w) {
                 const int32_t w = std::min(panel_w, m - k0);
                 const size_t plds = ((size_t)w * m + w) * sizeof(T);
-                hipLaunchKernelGGL((gj_panel_kernel<T>), dim3(1), dim3(1024), plds, st, S, B, m, k0, w, ipiv, ws, f->flag);
+                hipLaunchKernelGGL((gj_panel_kernel<T>), dim3(1), dim3(1024), plds, st, S, B, m, k0, w, ipiv, ws, f->flag, tiny2);
                 hipLaunchKernelGGL((gj_panel_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, st, S, B, m, k0, w, (const T*)ws);
             }
         } else {
             for (int32_t k = 0; k < m; ++k) {
-                hipLaunchKernelGGL((gj_pivot_kernel<T>), dim3(1), dim3(1024), 0, st, S, B, m, k, ipiv, ws, f->flag);
+                hipLaunchKernelGGL((gj_pivot_kernel<T>), dim3(1), dim3(1024), 0, st, S, B, m, k, ipiv, ws, f->flag, tiny2);
                 hipLaunchKernelGGL((gj_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, st, S, B, m, k, (const T*)ws);
             }
         }
@@ -655,6 +681,8 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     f->B = B;
     f->nb = n > 0 ? (n + B - 1) / B : 0;
     f->mid = f->nb / 2;
+    if (const char* e = getenv("LSA_BLU_TWIST"))  // 0: one chain from the first block (the middle block is the last one)
+        if (atoi(e) == 0) f->mid = f->nb > 0 ? f->nb - 1 : 0;
     f->bandwidth = bw;
     f->dtype = C->dtype;
     // splits on C's pattern and a CSC view (positions into C's value array) for the corner update

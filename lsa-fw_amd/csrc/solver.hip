@@ -452,9 +452,10 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
         fac_src = sharded ? Md : M;
     }
     if (op->Kfac && fac_src && opts->pc_type == 2) {
-        // exact block-tridiagonal LU; when the band does not fit the memory budget fall back to ILU(k) + GMRES
+        // exact block-tridiagonal LU; when the band does not fit the memory budget, or a Schur block is singular (block
+        // elimination has no pivoting across blocks), fall back to ILU(k) + GMRES
         rc = lsa_blu_create(ctx, fac_src, 0, &op->blu);
-        if (rc != LSA_OK && rc != LSA_ERR_HIP) {
+        if (rc != LSA_OK && rc != LSA_ERR_HIP && rc != LSA_ERR_ZERO_PIVOT) {
             lsa_op_destroy(op);
             return rc;
         }

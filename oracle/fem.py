@@ -271,13 +271,16 @@ def assemble_linearized_ns(
     # Dirichlet velocity: inlet (marker 1) + cylinder wall (marker 5), bcs_perturbation.toml:1-10
     dnodes = np.flatnonzero((np.isclose(X, mesh.xs[0])) | inside)
     ddofs = np.sort(np.concatenate([node_offset[dnodes], node_offset[dnodes] + 1]))
-    # pressure dofs whose every velocity neighbour is pinned (vertices buried in the cylinder mask) would
-    # leave an all-zero row in A and M; a body-fitted mesh has no such dofs, so they are pinned as well.
+    # Pressure dofs of the masked ("solid") region.  A body-fitted mesh has no dofs inside the cylinder; on this
+    # structured mesh the pressure dofs at masked vertices, and any other pressure dof whose every velocity neighbour
+    # is pinned, would be left with an all-zero or nearly all-zero row (a handful of couplings shared by several such
+    # dofs), which makes leading blocks of A - sigma M singular.  They are pinned like the velocity dofs.
     dofs_p = node_offset[isv] + 2
     dflag = np.zeros(n, dtype=bool)
     dflag[ddofs] = True
     live = np.add.reduceat((~dflag[A.indices]) & (A.data != 0.0), A.indptr[:-1]) > 0
-    dead_p = dofs_p[~live[dofs_p]]
+    masked_vertex_p = node_offset[np.flatnonzero(inside & isv)] + 2
+    dead_p = np.union1d(dofs_p[~live[dofs_p]], masked_vertex_p)
     ddofs = np.sort(np.concatenate([ddofs, dead_p]))
     A = _apply_dirichlet(A, ddofs)
     M = _apply_dirichlet(M, ddofs)

@@ -135,7 +135,7 @@ def cpu_baseline(es, sigma, args):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--case", default="S30k")
     ap.add_argument("--k", type=int, default=20)
@@ -161,10 +161,18 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist_mod
 
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # LSA_BENCH_DEVICE / LSA_BENCH_BACKEND exist only to rehearse the multi-rank code path on a one-GPU box
+        # (all ranks on device 0, gloo for the barrier); the driver's runs use one GPU per rank and RCCL.
+        dev = int(os.environ.get("LSA_BENCH_DEVICE", local_rank))
+        backend = os.environ.get("LSA_BENCH_BACKEND", "nccl")
+        torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", dev))
+        else:
+            dist_mod.init_process_group(backend)
         dist = dist_mod
-    device = local_rank if world > 1 else 0
+        reduce_device = "cuda" if backend == "nccl" else "cpu"
+    device = int(os.environ.get("LSA_BENCH_DEVICE", local_rank)) if world > 1 else 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback)")
 
@@ -195,10 +203,10 @@ def main() -> None:
     stats = solver.solver.stats
     total_pairs = float(nconv * args.steps)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        p = torch.tensor([total_pairs], dtype=torch.float64, device="cuda")
+        p = torch.tensor([total_pairs], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(p, op=dist.ReduceOp.SUM)
         total_pairs = float(p.item())
     lam_gpu = np.array([solver.solver.get_eigenvalue(i) for i in range(min(args.k, solver.solver.get_num_converged()))])

@@ -176,6 +176,16 @@ int lsa_krylov_ritz_vectors(lsa_ctx *ctx, lsa_krylov *k, int32_t m, int32_t nvec
 int lsa_eig_residuals(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, int32_t nvec, const void *lam, const void *X,
                       double *res);
 
+/* ---- MatrixMarket reader (host only): the A.mtx / M.mtx stage boundary --------------------------------------------
+ * Stands in for scipy.io.mmread + the per-entry setValue loop of iPETScMatrix.from_path / from_matrix
+ * (FEM/utils.py:143-147,208-215).  Coordinate format; general / symmetric / hermitian / skew-symmetric; real / integer /
+ * complex / pattern; explicit zeros kept, duplicates summed, columns sorted.  Needs no GPU. */
+typedef struct lsa_mm lsa_mm;
+int lsa_mm_open(const char *path, lsa_mm **out, int32_t *nrows, int32_t *ncols, int64_t *nnz, int *is_complex);
+int lsa_mm_read_csr(const lsa_mm *h, int32_t *rowptr, int32_t *col, void *val);
+const char *lsa_mm_error(const lsa_mm *h);
+void lsa_mm_close(lsa_mm *h);
+
 /* ---- multi-GPU (one process per GPU; rows of C, M and the factors are sharded, the basis replicated) ---- */
 /* RCCL bootstrap: rank 0 calls lsa_comm_unique_id, the launcher broadcasts the 128 bytes (e.g. with
  * torch.distributed), every rank then calls lsa_comm_init. */

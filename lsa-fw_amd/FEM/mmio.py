@@ -15,6 +15,18 @@ import scipy.sparse as sp
 
 
 def read_matrix_market(path: Path) -> sp.csr_matrix:
+    """CSR of a MatrixMarket coordinate file.  Uses the native one-pass reader of liblsa_hip.so (``lsa_mm_open``, host
+    code, no GPU needed); the pure-numpy reader below is the same algorithm for machines where the library has not been
+    built yet (file I/O is not part of the eigen path's arithmetic)."""
+    try:
+        import lsa_hip
+
+        return lsa_hip.read_matrix_market(path)
+    except (ImportError, RuntimeError, OSError):
+        return _read_matrix_market_numpy(path)
+
+
+def _read_matrix_market_numpy(path: Path) -> sp.csr_matrix:
     with open(path, "rb") as fh:
         header = fh.readline().decode().strip().lower().split()
         if len(header) < 5 or header[0] != "%%matrixmarket" or header[1] != "matrix":

@@ -516,7 +516,9 @@ static int op_apply_dev(lsa_ctx* ctx, lsa_op* op, const void* x, void* y) {
         return LSA_OK;
     }
     if (!op->gw_ready) {
-        const int restart = std::max(1, std::min(op->opts.ksp_restart, op->opts.ksp_maxit));
+        int restart = std::max(1, std::min(op->opts.ksp_restart, op->opts.ksp_maxit));
+        // with an exact factorisation on one GPU GMRES only polishes (0-2 iterations): keep its basis small
+        if (op->blu && ctx->nranks == 1) restart = std::min(restart, 40);
         LSA_CHECK(op->gw.alloc(ctx, op->n, restart, dtype));
         op->gw_ready = true;
     }

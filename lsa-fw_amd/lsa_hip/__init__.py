@@ -109,6 +109,10 @@ SIGNATURES = {
     "lsa_krylov_restart": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32]),
     "lsa_krylov_ritz_vectors": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32, ctypes.c_int, _P]),
     "lsa_eig_residuals": (ctypes.c_int, [_P, _P, _P, _I32, _P, _P, _P]),
+    "lsa_mm_open": (ctypes.c_int, [ctypes.c_char_p, _PP, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_int)]),
+    "lsa_mm_read_csr": (ctypes.c_int, [_P, _P, _P, _P]),
+    "lsa_mm_error": (ctypes.c_char_p, [_P]),
+    "lsa_mm_close": (None, [_P]),
     "lsa_comm_unique_id": (ctypes.c_int, [_P]),
     "lsa_comm_init": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P]),
     "lsa_csr_upload_shard": (ctypes.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, ctypes.c_int, _PP]),
@@ -485,6 +489,26 @@ class KrylovBasis:
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self.ctx._lib.lsa_krylov_destroy(self.handle)
             self.handle = None
+
+
+def read_matrix_market(path) -> "scipy.sparse.csr_matrix":  # noqa: F821
+    """Parse a MatrixMarket coordinate file with the native reader (host only, no GPU needed)."""
+    import scipy.sparse as sp
+
+    lib = load_library()
+    h = ctypes.c_void_p()
+    nr, nc, nnz, cx = _I32(0), _I32(0), _I64(0), ctypes.c_int(0)
+    rc = lib.lsa_mm_open(str(path).encode(), ctypes.byref(h), ctypes.byref(nr), ctypes.byref(nc), ctypes.byref(nnz), ctypes.byref(cx))
+    try:
+        if rc != 0:
+            raise ValueError(f"{path}: {lib.lsa_mm_error(h).decode(errors='replace')}")
+        rp = np.empty(nr.value + 1, dtype=np.int32)
+        ci = np.empty(nnz.value, dtype=np.int32)
+        val = np.empty(nnz.value, dtype=np.complex128 if cx.value else np.float64)
+        lib.lsa_mm_read_csr(h, _ptr(rp), _ptr(ci), _ptr(val))
+    finally:
+        lib.lsa_mm_close(h)
+    return sp.csr_matrix((val, ci, rp), shape=(nr.value, nc.value))
 
 
 def eig_residuals(ctx: Context, A: CsrMatrix, M: CsrMatrix | None, lam: np.ndarray, X: np.ndarray) -> np.ndarray:

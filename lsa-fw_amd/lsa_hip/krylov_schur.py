@@ -35,16 +35,16 @@ class KrylovSchurResult:
     history: list = field(default_factory=list)
 
 
-def _schur_wanted_first(H: np.ndarray, rank_key, k: int):
+def _schur_wanted_first(H: np.ndarray, rank_key, k: int, eigenvalues: np.ndarray):
     """Complex Schur form H = Q T Q^H with (at least) the k best-ranked eigenvalues in the leading block.
 
-    Returns (T, Q, sdim) where sdim is the size of the leading block LAPACK actually selected."""
+    ``eigenvalues`` are H's eigenvalues (any order; used only to place the selection threshold between the k-th and
+    the (k+1)-th key).  Returns (T, Q, sdim) where sdim is the size of the leading block LAPACK actually selected."""
     m = H.shape[0]
     if k <= 0 or k >= m:
         T, Q = sla.schur(H, output="complex")
         return T, Q, m if k >= m else 0
-    T0, _ = sla.schur(H, output="complex")
-    keys = np.sort(rank_key(np.diag(T0)))
+    keys = np.sort(rank_key(eigenvalues))
     thr = 0.5 * (keys[k - 1] + keys[k]) if keys[k] > keys[k - 1] else keys[k - 1]
     T, Q, sdim = sla.schur(H, output="complex", sort=lambda z: bool(rank_key(np.array([z]))[0] <= thr))
     return T, Q, int(sdim)
@@ -126,7 +126,7 @@ def krylov_schur(
         # ---- truncate to the wanted part of the Schur form and restart -----------------------------------------------
         knew = nconv + int((m_eff - nconv) * keep_fraction)
         knew = max(min(knew, m_eff - 1), 1)
-        T, Q, sdim = _schur_wanted_first(Hm, rank_key, knew)
+        T, Q, sdim = _schur_wanted_first(Hm, rank_key, knew, w)
         knew = max(min(sdim, m_eff - 1), 1)
         bt = b @ Q
         backend.restart(m_eff, Q[:, :knew])

@@ -199,6 +199,23 @@ def test_matrix_shim_and_matrix_market_round_trip(tmp_path, s2k):
     Z = (s2k.A.astype(complex) * (1 + 2j)).tocsr()
     iPETScMatrix(Z).export(tmp_path / "Z.mtx")
     assert abs(iPETScMatrix.from_path(tmp_path / "Z.mtx").as_scipy_array() - Z).max() < 1e-15
+    # the native reader and the numpy reader agree entry for entry, hermitian / skew / pattern files included
+    import lsa_hip
+    from FEM import mmio
+
+    H = sp.csr_matrix(np.array([[2.0, 1 + 1j, 0], [1 - 1j, 3.0, 4j], [0, -4j, 5.0]]))
+    scipy.io.mmwrite(str(tmp_path / "H.mtx"), H, symmetry="hermitian")
+    K = sp.csr_matrix(np.array([[0.0, 2.0, -1.0], [-2.0, 0.0, 3.0], [1.0, -3.0, 0.0]]))
+    scipy.io.mmwrite(str(tmp_path / "K.mtx"), K, symmetry="skew-symmetric")
+    (tmp_path / "P.mtx").write_text("%%MatrixMarket matrix coordinate pattern general\n% comment\n3 3 3\n1 1\n2 3\n3 1\n")
+    for name, want in (("A", a), ("S", S), ("Z", Z), ("H", H), ("K", K), ("P", sp.csr_matrix(([1.0, 1.0, 1.0], ([0, 1, 2], [0, 2, 0])), shape=(3, 3)))):
+        nat = lsa_hip.read_matrix_market(tmp_path / f"{name}.mtx")
+        ref = mmio._read_matrix_market_numpy(tmp_path / f"{name}.mtx")
+        assert nat.shape == ref.shape and np.array_equal(nat.indptr, ref.indptr) and np.array_equal(nat.indices, ref.indices)
+        assert np.array_equal(nat.data, ref.data) and abs(nat - want).max() < 1e-15
+    (tmp_path / "bad.mtx").write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+    with pytest.raises(ValueError):
+        lsa_hip.read_matrix_market(tmp_path / "bad.mtx")
 
 
 def test_complex_vector_shim():

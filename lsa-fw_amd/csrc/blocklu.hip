@@ -23,6 +23,8 @@ struct lsa_blu {
     lsa_ctx* ctx;
     const lsa_mat* C;  // borrowed: the sparse off-diagonal blocks are read from C at every solve
     int32_t n, B, nb, bandwidth;
+    int32_t ld = 0;  // row stride of the dense Schur inverses: B + 16, NOT a power of two (column sweeps of the
+                     // Gauss-Jordan panels would otherwise hit one memory channel: 1024 rows x 16 KiB apart)
     int dtype;
     int32_t *lsplit = nullptr, *usplit = nullptr;                 // device: per row, first entry with col >= block start / end
     int32_t *cptr = nullptr, *crow = nullptr, *cpos = nullptr;    // device CSC view of C (setup only)
@@ -58,20 +60,20 @@ __global__ void maxabs2_kernel(int64_t nnz, const T* __restrict__ v, unsigned lo
 
 // S[r - bs, c - bs] = C[r, c] for the entries of block row b that fall into the diagonal block
 template <typename T>
-__global__ void blu_scatter_kernel(int32_t bs, int32_t be, int32_t B, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+__global__ void blu_scatter_kernel(int32_t bs, int32_t be, int32_t ld, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                    const int32_t* __restrict__ lsplit, const int32_t* __restrict__ usplit,
                                    const T* __restrict__ val, T* __restrict__ S) {
     const int32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = gid & 15;
     const int32_t r = bs + (gid >> 4);
     if (r >= be) return;
-    for (int32_t p = lsplit[r] + lane; p < usplit[r]; p += 16) S[(size_t)(r - bs) * B + (ci[p] - bs)] = val[p];
+    for (int32_t p = lsplit[r] + lane; p < usplit[r]; p += 16) S[(size_t)(r - bs) * ld + (ci[p] - bs)] = val[p];
 }
 
 // S[r, :] -= (C[r, nbr block] * Sinv_nbr) * C[nbr block, this block] for the neighbour block [ns, ne) on the left
 // (RIGHT = false) or on the right (RIGHT = true) of block [bs, be); only rows with entries in that neighbour do work
 template <typename T, bool RIGHT>
-__global__ __launch_bounds__(256) void blu_corner_kernel(int32_t ns, int32_t ne, int32_t bs, int32_t be, int32_t B,
+__global__ __launch_bounds__(256) void blu_corner_kernel(int32_t ns, int32_t ne, int32_t bs, int32_t be, int32_t ld,
                                                          const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                          const int32_t* __restrict__ lsplit, const int32_t* __restrict__ usplit,
                                                          const T* __restrict__ val, const int32_t* __restrict__ cptr,
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void blu_corner_kernel(int32_t ns, int32_t ne,
     const int32_t m1 = ne - ns;
     for (int32_t k = threadIdx.x; k < m1; k += 256) {
         T acc = scalar_traits<T>::zero();
-        for (int32_t p = g0; p < g1; ++p) fma_acc(acc, val[p], sinv_nbr[(size_t)(ci[p] - ns) * B + k]);
+        for (int32_t p = g0; p < g1; ++p) fma_acc(acc, val[p], sinv_nbr[(size_t)(ci[p] - ns) * ld + k]);
         X[k] = acc;
     }
     __syncthreads();
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void blu_corner_kernel(int32_t ns, int32_t ne,
             }
         }
         if (any) {
-            T* out = S + (size_t)(r - bs) * B + j;
+            T* out = S + (size_t)(r - bs) * ld + j;
             *out = s_sub(*out, acc);
         }
     }
@@ -197,34 +199,47 @@ __global__ __launch_bounds__(256) void gj_update_kernel(T* __restrict__ a, int32
     }
 }
 
-// ---- blocked form: a panel of w pivot columns is eliminated by ONE workgroup with the panel held in LDS (column-major,
-// m x w), then the other columns get the accumulated rank-w update in one grid-wide launch:
+// ---- blocked form: a panel of w <= kPanelW pivot columns is eliminated by ONE workgroup, then the other columns get the
+// accumulated rank-w update in one grid-wide launch:
 //     A[:, J] <- (P A)[:, J] with the pivot rows zeroed  +  W * (P A)[K, J]
 // where W (m x w) is what the in-place elimination leaves in the panel columns and K are the panel's pivot rows.
-// 2 launches per w pivots instead of 2 per pivot; the arithmetic is the same elimination in the same order.
-template <typename T>
-__global__ __launch_bounds__(1024) void gj_panel_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k0, int32_t w,
-                                                        int32_t* __restrict__ ipiv, T* __restrict__ Y, int32_t* __restrict__ flag, double tiny2) {
-    extern __shared__ __attribute__((aligned(16))) char dyn[];
-    T* Pt = (T*)dyn;                      // Pt[j * m + i] = a[i, k0 + j]
-    T* prow = Pt + (size_t)w * m;         // w entries
+// 3 launches per w pivots instead of 2 per pivot; the arithmetic is the same elimination in the same order.
+//
+// The panel lives in REGISTERS: thread t owns rows t, t + 1024, ... (RPT of them), w complex values each.  Per pivot the
+// workgroup does a shuffle/LDS arg-max, the two owner threads publish rows k and p through LDS (2w values), and every
+// thread updates its own rows from the broadcast pivot row: three barriers and a few hundred bytes of LDS traffic per
+// pivot (an LDS-resident panel moved 24 KB per wavefront per pivot and took 5 us per pivot).
+constexpr int kPanelW = 8;
+template <typename T, int NT, int RPT, int W>
+__global__ __launch_bounds__(NT) void gj_panel_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k0, int32_t w,
+                                                        int32_t* __restrict__ ipiv, int32_t* __restrict__ perm, int32_t* __restrict__ flag,
+                                                        double tiny2) {
+    __shared__ T rowk[kPanelW], rowp[kPanelW];
     __shared__ double smag[16];
     __shared__ int32_t sidx[16];
-    __shared__ int32_t spiv[64];
+    __shared__ int32_t spiv[kPanelW];
+    __shared__ int32_t aff[2 * kPanelW], src[2 * kPanelW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int32_t idx = tid; idx < m * w; idx += 1024) {
-        const int32_t i = idx / w, j = idx - i * w;
-        Pt[(size_t)j * m + i] = a[(size_t)i * ld + k0 + j];
+    T r[RPT][W];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int32_t i = tid + NT * q;
+#pragma unroll
+        for (int j = 0; j < W; ++j) r[q][j] = (i < m && j < w) ? a[(size_t)i * ld + k0 + j] : scalar_traits<T>::zero();
     }
-    __syncthreads();
     for (int32_t jj = 0; jj < w; ++jj) {
         const int32_t k = k0 + jj;
-        T* col = Pt + (size_t)jj * m;
         double best = -1.0;
         int32_t bi = k;
-        for (int32_t i = k + tid; i < m; i += 1024) {
-            const double mag = s_abs2(col[i]);
-            if (mag > best) {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int32_t i = tid + NT * q;
+            T cv = scalar_traits<T>::zero();
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+                if (j == jj) cv = r[q][j];
+            const double mag = s_abs2(cv);
+            if (i >= k && i < m && mag > best) {
                 best = mag;
                 bi = i;
             }
@@ -243,92 +258,170 @@ __global__ __launch_bounds__(1024) void gj_panel_kernel(T* __restrict__ a, int32
             sidx[wave] = bi;
         }
         __syncthreads();
-        if (tid == 0) {
-            double b = smag[0];
-            int32_t i0 = sidx[0];
-            for (int q = 1; q < 16; ++q)
-                if (smag[q] > b || (smag[q] == b && sidx[q] < i0)) {
-                    b = smag[q];
-                    i0 = sidx[q];
+        if (wave == 0) {
+            double b = (lane < NT / 64) ? smag[lane] : -2.0;
+            int32_t i0 = (lane < NT / 64) ? sidx[lane] : 0;
+#pragma unroll
+            for (int s = 8; s > 0; s >>= 1) {
+                const double ob = __shfl_xor(b, s, 64);
+                const int32_t oi = __shfl_xor(i0, s, 64);
+                if (ob > b || (ob == b && oi < i0)) {
+                    b = ob;
+                    i0 = oi;
                 }
-            spiv[jj] = i0;
-            ipiv[k] = i0;
-            if (!(b > tiny2)) atomicCAS(&flag[1], 0, k + 1);
+            }
+            if (lane == 0) {
+                spiv[jj] = i0;
+                ipiv[k] = i0;
+                if (!(b > tiny2)) atomicCAS(&flag[1], 0, k + 1);
+            }
         }
         __syncthreads();
         const int32_t p = spiv[jj];
-        if (p != k && tid < w) {
-            const T tmp = Pt[(size_t)tid * m + k];
-            Pt[(size_t)tid * m + k] = Pt[(size_t)tid * m + p];
-            Pt[(size_t)tid * m + p] = tmp;
+        // the owners of rows k and p publish them
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int32_t i = tid + NT * q;
+            if (i == k) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) rowk[j] = r[q][j];
+            }
+            if (i == p) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) rowp[j] = r[q][j];
+            }
         }
         __syncthreads();
-        T piv = col[k];
+        // scaled pivot row (row p moves to position k); every thread forms it from the broadcast copy
+        T piv = scalar_traits<T>::zero();
+#pragma unroll
+        for (int j = 0; j < W; ++j)
+            if (j == jj) piv = rowp[j];
         if (s_abs2(piv) == 0.0) s_from(piv, 1.0, 0.0);
         const T pinv = s_inv(piv);
-        __syncthreads();
-        if (tid < w) {
-            const T v = (tid == jj) ? pinv : s_mul(pinv, Pt[(size_t)tid * m + k]);
-            prow[tid] = v;
-            Pt[(size_t)tid * m + k] = v;
-        }
-        __syncthreads();
-        for (int32_t i = tid; i < m; i += 1024) {
-            if (i == k) continue;
-            const T fm = col[i];
+        T prow[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) prow[j] = (j == jj) ? pinv : s_mul(pinv, rowp[j]);
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int32_t i = tid + NT * q;
+            if (i >= m) continue;
+            if (i == k) {
+#pragma unroll
+                for (int j = 0; j < W; ++j) r[q][j] = prow[j];
+                continue;
+            }
+            if (i == p) {  // p != k here: this row receives the old row k
+#pragma unroll
+                for (int j = 0; j < W; ++j) r[q][j] = rowk[j];
+            }
+            T fm = scalar_traits<T>::zero();
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+                if (j == jj) fm = r[q][j];
             if (s_abs2(fm) == 0.0) continue;
-            for (int32_t j = 0; j < w; ++j) {
-                T* e = Pt + (size_t)j * m + i;
-                const T base = (j == jj) ? scalar_traits<T>::zero() : *e;
-                *e = s_sub(base, s_mul(fm, prow[j]));
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                const T base = (j == jj) ? scalar_traits<T>::zero() : r[q][j];
+                r[q][j] = s_sub(base, s_mul(fm, prow[j]));
             }
         }
-        __syncthreads();
     }
-    // row interchanges on the columns outside the panel, in pivot order
-    for (int32_t jj = 0; jj < w; ++jj) {
-        const int32_t k = k0 + jj, p = spiv[jj];
-        if (p != k) {
-            for (int32_t c = tid; c < m; c += 1024) {
-                if (c >= k0 && c < k0 + w) continue;
-                const T tmp = a[(size_t)k * ld + c];
-                a[(size_t)k * ld + c] = a[(size_t)p * ld + c];
-                a[(size_t)p * ld + c] = tmp;
-            }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int32_t i = tid + NT * q;
+        if (i < m) {
+#pragma unroll
+            for (int j = 0; j < W; ++j)
+                if (j < w) a[(size_t)i * ld + k0 + j] = r[q][j];
         }
-        __syncthreads();
     }
-    // the pivot rows of the other columns, as they are before this panel's elimination touches them
-    for (int32_t idx = tid; idx < m * w; idx += 1024) {
-        const int32_t jj = idx / m, c = idx - jj * m;
-        Y[(size_t)jj * m + c] = a[(size_t)(k0 + jj) * ld + c];
-    }
-    // panel back to global memory
-    for (int32_t idx = tid; idx < m * w; idx += 1024) {
-        const int32_t i = idx / w, j = idx - i * w;
-        a[(size_t)i * ld + k0 + j] = Pt[(size_t)j * m + i];
+    // Row interchanges on the columns outside the panel are left to the whole grid (one CU moves ~50 GB/s, and the w
+    // swaps touch up to 2w rows of m entries): thread 0 replays them on an index list and publishes, for every touched
+    // row, the row its final content comes from.  perm[0] = count, perm[1 + q] = row, perm[33 + q] = slot of its source.
+    if (tid == 0) {
+        int cnt = 0;
+        auto slot = [&](int32_t rr) {
+            for (int q = 0; q < cnt; ++q)
+                if (aff[q] == rr) return q;
+            aff[cnt] = rr;
+            src[cnt] = rr;
+            return cnt++;
+        };
+        for (int32_t jj = 0; jj < w; ++jj) {
+            const int qa = slot(k0 + jj), qb = slot(spiv[jj]);
+            const int32_t t = src[qa];
+            src[qa] = src[qb];
+            src[qb] = t;
+        }
+        perm[0] = cnt;
+        for (int q = 0; q < cnt; ++q) {
+            perm[1 + q] = aff[q];
+            int qs = 0;
+            for (int t = 0; t < cnt; ++t)
+                if (aff[t] == src[q]) qs = t;
+            perm[33 + q] = qs;
+        }
     }
 }
 
-// a[i, c] = (i in panel rows ? 0 : a[i, c]) + sum_j W[i, j] Y[j, c] for the columns c outside the panel; wavefront per row
+// Z[q, :] = a[perm row q, :]: the rows touched by the panel's interchanges, staged before anything overwrites them
+template <typename T>
+__global__ __launch_bounds__(256) void gj_stage_kernel(const T* __restrict__ a, int32_t ld, int32_t m, const int32_t* __restrict__ perm,
+                                                       T* __restrict__ Z) {
+    const int32_t q = blockIdx.y;
+    if (q >= perm[0]) return;
+    const int32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c < m) Z[(size_t)q * m + c] = a[(size_t)perm[1 + q] * ld + c];
+}
+
+// For the columns c outside the panel:  a[i, c] = base(i, c) + sum_j W[i, j] Y[j, c],  where Y[j, :] is pivot row k0 + j
+// after the interchanges (read from the staged rows Z), and base is 0 for the pivot rows, the interchanged content
+// (from Z) for the other touched rows, and a[i, c] itself elsewhere.  A 256-thread workgroup owns kUpdRows rows; a
+// thread walks columns (coalesced), loads the w pivot-row values ONCE and applies them to all kUpdRows rows.
+constexpr int kUpdRows = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void gj_panel_update_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k0, int32_t w,
-                                                              const T* __restrict__ Y) {
-    const int lane = threadIdx.x & 63;
-    const int32_t i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= m) return;
-    T* ri = a + (size_t)i * ld;
-    T wv[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) wv[j] = (j < w) ? ri[k0 + j] : scalar_traits<T>::zero();
-    const bool pivot_row = i >= k0 && i < k0 + w;
-    for (int32_t c = lane; c < m; c += 64) {
+                                                              const int32_t* __restrict__ perm, const T* __restrict__ Z) {
+    __shared__ T Ws[kUpdRows][kPanelW];
+    __shared__ int32_t yslot[kPanelW];     // staged row holding pivot row k0 + j
+    __shared__ int32_t rslot[kUpdRows];    // staged row holding the new content of my row r, or -1
+    const int32_t i0 = blockIdx.x * kUpdRows;
+    if (threadIdx.x < kUpdRows * kPanelW) {
+        const int r = threadIdx.x / kPanelW, j = threadIdx.x % kPanelW;
+        Ws[r][j] = (i0 + r < m && j < w) ? a[(size_t)(i0 + r) * ld + k0 + j] : scalar_traits<T>::zero();
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + kPanelW + kUpdRows) {
+        const int32_t t = (int32_t)threadIdx.x - 64;
+        const int32_t na = perm[0];
+        const int32_t row = (t < kPanelW) ? k0 + t : i0 + (t - kPanelW);
+        int32_t sl = -1;
+        for (int32_t q = 0; q < na; ++q)
+            if (perm[1 + q] == row) sl = perm[33 + q];
+        if (t < kPanelW) yslot[t] = (t < w) ? sl : 0;
+        else rslot[t - kPanelW] = sl;
+    }
+    __syncthreads();
+    // (columns are not unrolled: the W tile and the y values already fill the register budget of two waves per SIMD)
+#pragma unroll 1
+    for (int32_t c = threadIdx.x; c < m; c += 256) {
         if (c >= k0 && c < k0 + w) continue;
-        T acc = pivot_row ? scalar_traits<T>::zero() : ri[c];
+        T y[kPanelW];
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (j < w) fma_acc(acc, wv[j], Y[(size_t)j * m + c]);
-        ri[c] = acc;
+        for (int j = 0; j < kPanelW; ++j) y[j] = Z[(size_t)yslot[j] * m + c];  // W is zero beyond w, slot 0 is always valid
+#pragma unroll
+        for (int r = 0; r < kUpdRows; ++r) {
+            const int32_t i = i0 + r;
+            if (i >= m) break;
+            T* e = a + (size_t)i * ld + c;
+            T acc;
+            if (i >= k0 && i < k0 + w) acc = scalar_traits<T>::zero();
+            else if (rslot[r] >= 0) acc = Z[(size_t)rslot[r] * m + c];
+            else acc = *e;
+#pragma unroll
+            for (int j = 0; j < kPanelW; ++j) fma_acc(acc, Ws[r][j], y[j]);
+            *e = acc;
+        }
     }
 }
 
@@ -402,12 +495,12 @@ __global__ __launch_bounds__(256) void blu_sparse_both_kernel(int32_t bs, int32_
 
 // out[r] = sum_s Sinv[r, s] in[s] over the whole diagonal block; one wavefront per row, 8 loads in flight per lane
 template <typename MT, typename VT>
-__global__ __launch_bounds__(256) void blu_dense_kernel(int32_t bs, int32_t be, int32_t B, const MT* __restrict__ sinv,
+__global__ __launch_bounds__(256) void blu_dense_kernel(int32_t bs, int32_t be, int32_t ld, const MT* __restrict__ sinv,
                                                         const VT* __restrict__ in, VT* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int32_t r = bs + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= be) return;
-    const MT* row = sinv + (size_t)r * B - bs;
+    const MT* row = sinv + (size_t)r * ld - bs;
     VT acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = scalar_traits<VT>::zero();
@@ -439,9 +532,9 @@ __global__ __launch_bounds__(256) void blu_dense_kernel(int32_t bs, int32_t be, 
 
 template <typename T>
 int factorize(lsa_ctx* ctx, lsa_blu* f) {
-    const int32_t B = f->B, n = f->n;
+    const int32_t B = f->B, n = f->n, ld = f->ld;
     const lsa_mat* C = f->C;
-    const size_t inv_bytes = (size_t)n * B * sizeof(T);
+    const size_t inv_bytes = (size_t)n * ld * sizeof(T);
     LSA_HIP_CHECK(ctx, hipMemsetAsync(f->sinv, 0, inv_bytes, ctx->stream));
     LSA_HIP_CHECK(ctx, hipMemsetAsync(f->flag, 0, 4 * sizeof(int32_t), ctx->stream));
     // pivots below 1e-12 of the largest entry of C mean a singular Schur block (a singular leading block of C): block
@@ -464,62 +557,98 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
         LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    // panel width of the blocked Gauss-Jordan: the m x w panel must fit LDS (w = 8 for complex B = 1024); w < 2 or
-    // LSA_GJ_PANEL=1 selects the unblocked form (two launches per pivot)
-    int32_t panel_w = (int32_t)std::min<size_t>(16, (144 * 1024) / ((size_t)B * sizeof(T)));
-    if (const char* e = getenv("LSA_GJ_PANEL")) panel_w = std::min(panel_w, atoi(e));
-    if (panel_w >= 2) {
-        const size_t plds = ((size_t)panel_w * B + panel_w) * sizeof(T);
-        LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)gj_panel_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-    }
-    // one block: scatter C_bb, subtract the Schur corrections of the already inverted neighbours, invert in place
+    // panel width of the blocked Gauss-Jordan (LSA_GJ_PANEL=1 selects the unblocked form: two launches per pivot): 8
+    // columns while a thread of the panel kernel holds at most 4 rows, 4 columns up to 8 rows (blocks of 4096 rows)
+    int32_t panel_w = B <= 2048 ? 8 : B <= 4096 ? 4 : 1;
+    if (const char* e = getenv("LSA_GJ_PANEL")) panel_w = std::max(1, std::min(panel_w, atoi(e)));
+    // LSA_BLU_TIMING=2: HIP events around every launch of block 1 (development aid; per-kernel sums go to stderr)
+    const bool probe = getenv("LSA_BLU_TIMING") && atoi(getenv("LSA_BLU_TIMING")) >= 2;
+    std::vector<std::pair<int, hipEvent_t>> marks;
     auto factor_block = [&](hipStream_t st, int chain, int32_t b, bool corr_left, bool corr_right) {
         const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
-        T* S = (T*)f->sinv + (size_t)bs * B;
-        hipLaunchKernelGGL((blu_scatter_kernel<T>), dim3((m * 16 + 255) / 256), dim3(256), 0, st, bs, be, B, C->rp, C->ci, f->lsplit, f->usplit,
+        auto mark = [&](int kind) {
+            if (!probe || b != 1) return;
+            hipEvent_t ev;
+            (void)hipEventCreate(&ev);
+            (void)hipEventRecord(ev, st);
+            marks.push_back({kind, ev});
+        };
+        mark(-1);
+        T* S = (T*)f->sinv + (size_t)bs * ld;
+        hipLaunchKernelGGL((blu_scatter_kernel<T>), dim3((m * 16 + 255) / 256), dim3(256), 0, st, bs, be, ld, C->rp, C->ci, f->lsplit, f->usplit,
                            (const T*)C->val, S);
         if (corr_left) {
             const int32_t ns = bs - B;
-            hipLaunchKernelGGL((blu_corner_kernel<T, false>), dim3(m), dim3(256), lds, st, ns, bs, bs, be, B, C->rp, C->ci, f->lsplit, f->usplit,
-                               (const T*)C->val, f->cptr, f->crow, f->cpos, (const T*)f->sinv + (size_t)ns * B, S);
+            hipLaunchKernelGGL((blu_corner_kernel<T, false>), dim3(m), dim3(256), lds, st, ns, bs, bs, be, ld, C->rp, C->ci, f->lsplit, f->usplit,
+                               (const T*)C->val, f->cptr, f->crow, f->cpos, (const T*)f->sinv + (size_t)ns * ld, S);
         }
         if (corr_right) {
             const int32_t ns = be, ne = std::min(n, be + B);
-            hipLaunchKernelGGL((blu_corner_kernel<T, true>), dim3(m), dim3(256), lds, st, ns, ne, bs, be, B, C->rp, C->ci, f->lsplit, f->usplit,
-                               (const T*)C->val, f->cptr, f->crow, f->cpos, (const T*)f->sinv + (size_t)ns * B, S);
+            hipLaunchKernelGGL((blu_corner_kernel<T, true>), dim3(m), dim3(256), lds, st, ns, ne, bs, be, ld, C->rp, C->ci, f->lsplit, f->usplit,
+                               (const T*)C->val, f->cptr, f->crow, f->cpos, (const T*)f->sinv + (size_t)ns * ld, S);
         }
+        mark(0);
         int32_t* ipiv = f->ipiv[chain];
+        int32_t* perm = ipiv + B;  // interchange lists of the current panel (80 ints behind the pivot indices)
         T* ws = (T*)f->colbuf[chain];
         if (panel_w >= 2) {
             for (int32_t k0 = 0; k0 < m; k0 += panel_w) {
                 const int32_t w = std::min(panel_w, m - k0);
-                const size_t plds = ((size_t)w * m + w) * sizeof(T);
-                hipLaunchKernelGGL((gj_panel_kernel<T>), dim3(1), dim3(1024), plds, st, S, B, m, k0, w, ipiv, ws, f->flag, tiny2);
-                hipLaunchKernelGGL((gj_panel_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, st, S, B, m, k0, w, (const T*)ws);
+                if (B <= 1024) hipLaunchKernelGGL((gj_panel_kernel<T, 1024, 1, 8>), dim3(1), dim3(1024), 0, st, S, ld, m, k0, w, ipiv, perm, f->flag, tiny2);
+                else if (B <= 2048) hipLaunchKernelGGL((gj_panel_kernel<T, 512, 4, 8>), dim3(1), dim3(512), 0, st, S, ld, m, k0, w, ipiv, perm, f->flag, tiny2);
+                else hipLaunchKernelGGL((gj_panel_kernel<T, 512, 8, 4>), dim3(1), dim3(512), 0, st, S, ld, m, k0, w, ipiv, perm, f->flag, tiny2);
+                mark(1);
+                hipLaunchKernelGGL((gj_stage_kernel<T>), dim3((m + 255) / 256, 2 * w), dim3(256), 0, st, (const T*)S, ld, m, (const int32_t*)perm, ws);
+                mark(2);
+                hipLaunchKernelGGL((gj_panel_update_kernel<T>), dim3((m + kUpdRows - 1) / kUpdRows), dim3(256), 0, st, S, ld, m, k0, w,
+                                   (const int32_t*)perm, (const T*)ws);
+                mark(3);
             }
         } else {
             for (int32_t k = 0; k < m; ++k) {
-                hipLaunchKernelGGL((gj_pivot_kernel<T>), dim3(1), dim3(1024), 0, st, S, B, m, k, ipiv, ws, f->flag, tiny2);
-                hipLaunchKernelGGL((gj_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, st, S, B, m, k, (const T*)ws);
+                hipLaunchKernelGGL((gj_pivot_kernel<T>), dim3(1), dim3(1024), 0, st, S, ld, m, k, ipiv, ws, f->flag, tiny2);
+                hipLaunchKernelGGL((gj_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, st, S, ld, m, k, (const T*)ws);
             }
         }
-        hipLaunchKernelGGL((gj_unpivot_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, st, S, B, m, ipiv);
+        hipLaunchKernelGGL((gj_unpivot_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, st, S, ld, m, ipiv);
     };
     // twisted order: chain 0 eliminates downwards from block 0, chain 1 upwards from the last block, on two streams;
     // they meet at the middle block, which receives both corrections
     const int32_t nb = f->nb, mid = f->mid;
     LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_fork, ctx->stream));
     LSA_HIP_CHECK(ctx, hipStreamWaitEvent(f->stream2, f->ev_fork, 0));
-    for (int32_t b = 0; b < mid; ++b) factor_block(ctx->stream, 0, b, b > 0, false);
-    for (int32_t b = nb - 1; b > mid; --b) factor_block(f->stream2, 1, b, false, b < nb - 1);
+    // (the launches of the two chains are enqueued alternately so that neither queue waits for the host)
+    const double t_enq = now_s();
+    for (int32_t lo = 0, hi = nb - 1; lo < mid || hi > mid; ++lo, --hi) {
+        if (lo < mid) factor_block(ctx->stream, 0, lo, lo > 0, false);
+        if (hi > mid) factor_block(f->stream2, 1, hi, false, hi < nb - 1);
+    }
     LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_join, f->stream2));
     LSA_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, f->ev_join, 0));
     if (nb > 0) factor_block(ctx->stream, 0, mid, mid > 0, mid < nb - 1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "block LU launch failed: %s", hipGetErrorString(e));
+    const double t_sub = now_s();
     int32_t hflag[4];
     LSA_HIP_CHECK(ctx, hipMemcpyAsync(hflag, f->flag, sizeof hflag, hipMemcpyDeviceToHost, ctx->stream));
     LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!marks.empty()) {
+        double sum[4] = {0, 0, 0, 0};
+        int cnt[4] = {0, 0, 0, 0};
+        for (size_t i = 1; i < marks.size(); ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second);
+            sum[marks[i].first] += ms;
+            ++cnt[marks[i].first];
+        }
+        const char* names[4] = {"scatter+corner", "panel", "stage", "update"};
+        for (int q = 0; q < 4; ++q)
+            fprintf(stderr, "[lsa_blu] block 1 %-14s %4d intervals, %8.1f us each, %7.2f ms total\n", names[q], cnt[q], cnt[q] ? sum[q] * 1e3 / cnt[q] : 0.0, sum[q]);
+        for (auto& mk : marks) (void)hipEventDestroy(mk.second);
+    }
+    if (getenv("LSA_BLU_TIMING"))
+        fprintf(stderr, "[lsa_blu] numeric factorisation: host enqueue %.1f ms, device drained after %.1f ms\n", (t_sub - t_enq) * 1e3,
+                (now_s() - t_enq) * 1e3);
     if (hflag[1] != 0) return lsa_set_error(ctx, LSA_ERR_ZERO_PIVOT, "block LU: a Schur block is singular (pivot column %d)", hflag[1] - 1);
     return LSA_OK;
 }
@@ -544,7 +673,7 @@ int launch_apply(lsa_ctx* ctx, lsa_blu* f, const VT* v, VT* x, VT* y, VT* z, VT*
     };
     auto dense = [&](hipStream_t st, int32_t b, const VT* in, VT* out) {
         const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
-        hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3((m + 3) / 4), dim3(256), 0, st, bs, be, B, (const MT*)f->sinv, in, out);
+        hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3((m + 3) / 4), dim3(256), 0, st, bs, be, f->ld, (const MT*)f->sinv, in, out);
     };
     // elimination towards the middle, two chains in parallel:  y_b = v_b - C_{b,b-+1} z_{b-+1},  z_b = Sinv_b y_b
     LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_fork, s0));
@@ -668,7 +797,8 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     int32_t B = std::max(block_size > 0 ? block_size : 1024, bw + 1);
     B = ((B + 255) / 256) * 256;
     const size_t esz = C->dtype == LSA_C128 ? 16 : 8;
-    const size_t inv_bytes = (size_t)std::max(n, 1) * B * esz;
+    const int32_t ld = B + 16;
+    const size_t inv_bytes = (size_t)std::max(n, 1) * ld * esz;
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     if (inv_bytes > free_b / 2)
@@ -679,6 +809,7 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     f->C = C;
     f->n = n;
     f->B = B;
+    f->ld = ld;
     f->nb = n > 0 ? (n + B - 1) / B : 0;
     f->mid = f->nb / 2;
     if (const char* e = getenv("LSA_BLU_TWIST"))  // 0: one chain from the first block (the middle block is the last one)
@@ -708,8 +839,8 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     bool ok = hipMalloc((void**)&f->lsplit, 4 * n1) == hipSuccess && hipMalloc((void**)&f->usplit, 4 * n1) == hipSuccess &&
               hipMalloc((void**)&f->cptr, 4 * (n1 + 1)) == hipSuccess && hipMalloc((void**)&f->crow, 4 * z1) == hipSuccess &&
               hipMalloc((void**)&f->cpos, 4 * z1) == hipSuccess && hipMalloc(&f->sinv, inv_bytes) == hipSuccess &&
-              hipMalloc((void**)&f->ipiv[0], 4 * (size_t)B) == hipSuccess && hipMalloc((void**)&f->ipiv[1], 4 * (size_t)B) == hipSuccess &&
-              hipMalloc(&f->colbuf[0], esz * (size_t)B * 16) == hipSuccess && hipMalloc(&f->colbuf[1], esz * (size_t)B * 16) == hipSuccess &&
+              hipMalloc((void**)&f->ipiv[0], 4 * ((size_t)B + 128)) == hipSuccess && hipMalloc((void**)&f->ipiv[1], 4 * ((size_t)B + 128)) == hipSuccess &&
+              hipMalloc(&f->colbuf[0], esz * (size_t)B * 48) == hipSuccess && hipMalloc(&f->colbuf[1], esz * (size_t)B * 48) == hipSuccess &&
               hipMalloc((void**)&f->flag, 16) == hipSuccess && hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming) == hipSuccess;
@@ -723,6 +854,7 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
         lsa_blu_destroy(f);
         return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_blu_create: out of device memory");
     }
+    if (getenv("LSA_BLU_TIMING")) fprintf(stderr, "[lsa_blu] symbolic setup + allocation + upload %.1f ms\n", (now_s() - t0) * 1e3);
     int rc = f->dtype == LSA_C128 ? factorize<cplx>(ctx, f) : factorize<double>(ctx, f);
     if (rc != LSA_OK) {
         lsa_blu_destroy(f);

@@ -199,109 +199,226 @@ __global__ __launch_bounds__(256) void gj_update_kernel(T* __restrict__ a, int32
     }
 }
 
-// ---- blocked form: a panel of w <= kPanelW pivot columns is eliminated by ONE workgroup, then the other columns get the
-// accumulated rank-w update in one grid-wide launch:
-//     A[:, J] <- (P A)[:, J] with the pivot rows zeroed  +  W * (P A)[K, J]
-// where W (m x w) is what the in-place elimination leaves in the panel columns and K are the panel's pivot rows.
-// 3 launches per w pivots instead of 2 per pivot; the arithmetic is the same elimination in the same order.
+// max of a 64-bit key over the wavefront, returned to every lane: DPP steps inside each row of 16 lanes (a ds_bpermute
+// butterfly costs ~100 cycles per step on the pivot search's critical path), then the four row maxima through SGPRs
+__device__ __forceinline__ unsigned long long dpp_max_step(unsigned long long v, unsigned long long o) { return o > v ? o : v; }
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_mov_u64(unsigned long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v & 0xFFFFFFFFull), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+    v = dpp_max_step(v, dpp_mov_u64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = dpp_max_step(v, dpp_mov_u64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = dpp_max_step(v, dpp_mov_u64<0x141>(v));  // row_half_mirror
+    v = dpp_max_step(v, dpp_mov_u64<0x140>(v));  // row_mirror: every lane of a row now holds the row's max
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xFFFFFFFFull), 16 * row);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * row);
+        const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+        best = o > best ? o : best;
+    }
+    return best;
+}
+
+// ---- blocked form with look-ahead: ONE launch per panel of w <= W pivot columns -------------------------------------------
+// Eliminating a panel leaves W (m x w) in its columns; the other columns then need the accumulated rank-w update
+//     A[:, J] <- (P A)[:, J] with the pivot rows zeroed  +  W * (P A)[K, J]          (K = the panel's pivot rows),
+// the same elimination in the same order as the unblocked form.  Launch p of a block does both halves at once:
+//   * workgroup 0 applies the update of panel p to the columns of panel p + 1 ONLY and then eliminates panel p + 1
+//     (the critical path: the next launch needs its W and its row interchanges),
+//   * workgroup 1 + t applies the update of panel p to column tile t (W columns, all m rows); the tiles of panels p and
+//     p + 1 are skipped.
+// A column tile is owned by one workgroup, so the few rows touched by the interchanges are staged in LDS by their only
+// reader and nothing has to be ordered between workgroups: m / w + 1 launches per block instead of 2 m (a dependent
+// launch costs ~9 us on this part; measured per panel: 3 launches 54 us -> 1 launch).
 //
-// The panel lives in REGISTERS: thread t owns rows t, t + 1024, ... (RPT of them), w complex values each.  Per pivot the
-// workgroup does a shuffle/LDS arg-max, the two owner threads publish rows k and p through LDS (2w values), and every
-// thread updates its own rows from the broadcast pivot row: three barriers and a few hundred bytes of LDS traffic per
-// pivot (an LDS-resident panel moved 24 KB per wavefront per pivot and took 5 us per pivot).
+// Registers hold the tile: thread t owns rows t, t + NT, ... (RPT of them) x W columns; (NT, RPT, W) is picked per block
+// size so that nothing spills (a kernel with scratch also pays a per-dispatch scratch set-up).  Per pivot the panel
+// workgroup does a shuffle/LDS arg-max, the two owner threads publish rows k and p through LDS, and every thread updates
+// its own rows from the broadcast pivot row: three barriers per pivot.
+//
+// Interchange lists (perm): [0] = count of touched rows, [1 + q] = row, [33 + q] = slot of the row its new content comes
+// from, [50 + j] = that slot for pivot row k0 + j; written by workgroup 0 for panel p + 1 into pnext while everybody reads pprev (two buffers, alternating).
 constexpr int kPanelW = 8;
 template <typename T, int NT, int RPT, int W>
-__global__ __launch_bounds__(NT) void gj_panel_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k0, int32_t w,
-                                                        int32_t* __restrict__ ipiv, int32_t* __restrict__ perm, int32_t* __restrict__ flag,
-                                                        double tiny2) {
-    __shared__ T rowk[kPanelW], rowp[kPanelW];
-    __shared__ double smag[16];
-    __shared__ int32_t sidx[16];
+__global__ __launch_bounds__(NT) void gj_fused_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t kprev, int32_t wprev, int32_t knext,
+                                                      int32_t wnext, int32_t* __restrict__ ipiv, const int32_t* __restrict__ pprev,
+                                                      int32_t* __restrict__ pnext, int32_t* __restrict__ flag, double tiny2) {
+    __shared__ T Zs[2 * kPanelW][W];  // staged rows of this tile (update phase)
+    __shared__ int32_t zrow[2 * kPanelW], zsrc[2 * kPanelW], yslot[kPanelW];
+    __shared__ T rowk[2][kPanelW], rowp[2][kPanelW];  // double-buffered: pivot jj + 1 publishes while stragglers read jj
+    __shared__ unsigned long long skey[kPanelW];
     __shared__ int32_t spiv[kPanelW];
-    __shared__ int32_t aff[2 * kPanelW], src[2 * kPanelW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    T r[RPT][W];
-#pragma unroll
-    for (int q = 0; q < RPT; ++q) {
-        const int32_t i = tid + NT * q;
-#pragma unroll
-        for (int j = 0; j < W; ++j) r[q][j] = (i < m && j < w) ? a[(size_t)i * ld + k0 + j] : scalar_traits<T>::zero();
+    const bool panel_wg = blockIdx.x == 0;
+    if (tid < kPanelW) skey[tid] = 0ull;
+    int32_t c0;
+    if (panel_wg) {
+        if (knext < 0) return;
+        c0 = knext;
+    } else {
+        c0 = ((int32_t)blockIdx.x - 1) * W;
+        if (kprev < 0 || c0 == kprev || c0 == knext) return;
     }
-    for (int32_t jj = 0; jj < w; ++jj) {
-        const int32_t k = k0 + jj;
-        double best = -1.0;
-        int32_t bi = k;
+    const int32_t cw = min(W, m - c0);
+    T r[RPT][W];
+    if (kprev >= 0) {
+        // ---- rank-wprev update of this tile ----
+        // (the list loads are independent of each other: one memory latency, then one more for the staged rows; the
+        // look-ahead workgroup also issues the loads of its own rows before waiting for either)
+        const int32_t cnt = pprev[0];
+        if (tid < 2 * kPanelW) {
+            zrow[tid] = pprev[1 + tid];
+            zsrc[tid] = pprev[33 + tid];
+        }
+        if (tid >= 64 && tid < 64 + kPanelW) yslot[tid - 64] = pprev[50 + (tid - 64)];
+        if (tid >= 128 && tid < 128 + 2 * kPanelW * W) {
+            const int q = (tid - 128) / W, c = (tid - 128) % W;
+            const int32_t zr = min(max(pprev[1 + q], 0), m - 1);  // entries beyond cnt are stale: keep the address in range
+            if (q < cnt && c < cw) Zs[q][c] = a[(size_t)zr * ld + c0 + c];
+        }
+        // (its W values too while RPT * W is small enough to keep them in registers next to the tile)
+        constexpr bool kPrefetchW = RPT * W <= 8;
+        T wv[kPrefetchW ? RPT : 1][W];
+        if (panel_wg) {
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int32_t i = min(tid + NT * q, m - 1);
+                const T* ai = a + (size_t)i * ld;
+#pragma unroll
+                for (int c = 0; c < W; ++c) r[q][c] = ai[c0 + c];  // ld - B = 16 columns of padding keep c0 + c in range
+                if constexpr (kPrefetchW) {
+#pragma unroll
+                    for (int j = 0; j < W; ++j) wv[q][j] = ai[kprev + j];
+                }
+            }
+        }
+        __syncthreads();
+        if (!panel_wg) {
+            // update-only tile: W consecutive lanes walk one row segment (coalesced), NT / W rows per step.  Every row is
+            // first treated as untouched; the <= 2 wprev rows the interchanges touch are redone after a barrier.
+            constexpr int RS = NT / W;
+            const int c = tid % W;
+            const bool live = c < cw;
+            T y[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) y[j] = (j < wprev) ? Zs[yslot[j]][c] : scalar_traits<T>::zero();
+#pragma unroll 4
+            for (int32_t i = tid / W; i < m; i += RS) {
+                T* ai = a + (size_t)i * ld;
+                if (live) {
+                    T acc = ai[c0 + c];
+#pragma unroll
+                    for (int j = 0; j < W; ++j)
+                        if (j < wprev) fma_acc(acc, ai[kprev + j], y[j]);
+                    ai[c0 + c] = acc;
+                }
+            }
+            __syncthreads();
+            if (tid < cnt * W && live) {
+                const int q = tid / W;
+                const int32_t i = zrow[q];
+                T* ai = a + (size_t)i * ld;
+                T acc = (i >= kprev && i < kprev + wprev) ? scalar_traits<T>::zero() : Zs[zsrc[q]][c];
+#pragma unroll
+                for (int j = 0; j < W; ++j)
+                    if (j < wprev) fma_acc(acc, ai[kprev + j], y[j]);
+                ai[c0 + c] = acc;
+            }
+            return;
+        }
+        // look-ahead tile (the next panel's columns): thread per row, the rows stay in registers for the elimination
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int32_t i = tid + NT * q;
-            T cv = scalar_traits<T>::zero();
+            int32_t sl = -1;
 #pragma unroll
-            for (int j = 0; j < W; ++j)
-                if (j == jj) cv = r[q][j];
-            const double mag = s_abs2(cv);
-            if (i >= k && i < m && mag > best) {
-                best = mag;
-                bi = i;
+            for (int t = 0; t < 2 * kPanelW; ++t)
+                if (t < cnt && zrow[t] == i) sl = zsrc[t];
+            const bool pivot_row = i >= kprev && i < kprev + wprev;
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                if (pivot_row || c >= cw || i >= m) r[q][c] = scalar_traits<T>::zero();
+                else if (sl >= 0) r[q][c] = Zs[sl][c];
             }
-        }
+            if (i < m) {
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) {
-            const double ob = __shfl_xor(best, s, 64);
-            const int32_t oi = __shfl_xor(bi, s, 64);
-            if (ob > best || (ob == best && oi < bi)) {
-                best = ob;
-                bi = oi;
-            }
-        }
-        if (lane == 0) {
-            smag[wave] = best;
-            sidx[wave] = bi;
-        }
-        __syncthreads();
-        if (wave == 0) {
-            double b = (lane < NT / 64) ? smag[lane] : -2.0;
-            int32_t i0 = (lane < NT / 64) ? sidx[lane] : 0;
+                for (int j = 0; j < W; ++j) {
+                    if (j < wprev) {
+                        const int ys = yslot[j];
+                        T wij;
+                        if constexpr (kPrefetchW) wij = wv[q][j];
+                        else wij = a[(size_t)i * ld + kprev + j];
 #pragma unroll
-            for (int s = 8; s > 0; s >>= 1) {
-                const double ob = __shfl_xor(b, s, 64);
-                const int32_t oi = __shfl_xor(i0, s, 64);
-                if (ob > b || (ob == b && oi < i0)) {
-                    b = ob;
-                    i0 = oi;
+                        for (int c = 0; c < W; ++c) fma_acc(r[q][c], wij, Zs[ys][c]);
+                    }
                 }
             }
-            if (lane == 0) {
-                spiv[jj] = i0;
-                ipiv[k] = i0;
-                if (!(b > tiny2)) atomicCAS(&flag[1], 0, k + 1);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int32_t i = tid + NT * q;
+#pragma unroll
+            for (int c = 0; c < W; ++c) r[q][c] = (i < m && c < cw) ? a[(size_t)i * ld + c0 + c] : scalar_traits<T>::zero();
+        }
+        __syncthreads();  // skey is initialised
+    }
+    // ---- workgroup 0: eliminate the panel [knext, knext + wnext) held in r ----
+    // Pivot search: one 64-bit key per candidate row, |a|^2 with its low 13 mantissa bits replaced by (4096 - row), so that
+    // a single unsigned max picks the largest magnitude and, among magnitudes equal to 2^-39 relative, the lowest row;
+    // wave shuffle-reduce, then one LDS atomic max per wave: two barriers per pivot.  The pivot loop is fully unrolled so
+    // that "column jj of my row" is a register, not a select chain.
+    const int32_t k0 = knext, w = wnext;
+#pragma unroll
+    for (int jj = 0; jj < W; ++jj) {
+        if (jj >= w) break;
+        const int32_t k = k0 + jj;
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int32_t i = tid + NT * q;
+            if (i >= k && i < m) {
+                const double mag = s_abs2(r[q][jj]);
+                const unsigned long long kq = ((unsigned long long)__double_as_longlong(mag) & ~0x1FFFull) | (unsigned long long)(4096 - i);
+                key = kq > key ? kq : key;
             }
         }
+        key = wave_max_u64(key);
+        if (lane == 0) atomicMax(&skey[jj], key);
         __syncthreads();
-        const int32_t p = spiv[jj];
-        // the owners of rows k and p publish them
+        key = skey[jj];
+        const int32_t p = 4096 - (int32_t)(key & 0x1FFFull);
+        if (tid == 0) {
+            ipiv[k] = p;
+            if (!(__longlong_as_double((long long)(key & ~0x1FFFull)) > tiny2)) atomicCAS(&flag[1], 0, k + 1);
+        }
+        if (lane == 0 && wave == 0) spiv[jj] = p;
+        // the owner of row k publishes it; the owner of row p publishes the SCALED pivot row (one complex division per
+        // pivot instead of one per thread)
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int32_t i = tid + NT * q;
             if (i == k) {
 #pragma unroll
-                for (int j = 0; j < W; ++j) rowk[j] = r[q][j];
+                for (int j = 0; j < W; ++j) rowk[jj & 1][j] = r[q][j];
             }
             if (i == p) {
+                T piv = r[q][jj];
+                if (s_abs2(piv) == 0.0) s_from(piv, 1.0, 0.0);
+                const T pinv = s_inv(piv);
 #pragma unroll
-                for (int j = 0; j < W; ++j) rowp[j] = r[q][j];
+                for (int j = 0; j < W; ++j) rowp[jj & 1][j] = (j == jj) ? pinv : s_mul(pinv, r[q][j]);
             }
         }
         __syncthreads();
-        // scaled pivot row (row p moves to position k); every thread forms it from the broadcast copy
-        T piv = scalar_traits<T>::zero();
-#pragma unroll
-        for (int j = 0; j < W; ++j)
-            if (j == jj) piv = rowp[j];
-        if (s_abs2(piv) == 0.0) s_from(piv, 1.0, 0.0);
-        const T pinv = s_inv(piv);
         T prow[W];
 #pragma unroll
-        for (int j = 0; j < W; ++j) prow[j] = (j == jj) ? pinv : s_mul(pinv, rowp[j]);
+        for (int j = 0; j < W; ++j) prow[j] = rowp[jj & 1][j];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int32_t i = tid + NT * q;
@@ -313,18 +430,14 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(T* __restrict__ a, int32_t
             }
             if (i == p) {  // p != k here: this row receives the old row k
 #pragma unroll
-                for (int j = 0; j < W; ++j) r[q][j] = rowk[j];
+                for (int j = 0; j < W; ++j) r[q][j] = rowk[jj & 1][j];
             }
-            T fm = scalar_traits<T>::zero();
-#pragma unroll
-            for (int j = 0; j < W; ++j)
-                if (j == jj) fm = r[q][j];
+            const T fm = r[q][jj];
             if (s_abs2(fm) == 0.0) continue;
+            const T nfm = s_sub(scalar_traits<T>::zero(), fm);
+            r[q][jj] = scalar_traits<T>::zero();
 #pragma unroll
-            for (int j = 0; j < W; ++j) {
-                const T base = (j == jj) ? scalar_traits<T>::zero() : r[q][j];
-                r[q][j] = s_sub(base, s_mul(fm, prow[j]));
-            }
+            for (int j = 0; j < W; ++j) fma_acc(r[q][j], nfm, prow[j]);
         }
     }
 #pragma unroll
@@ -336,92 +449,43 @@ __global__ __launch_bounds__(NT) void gj_panel_kernel(T* __restrict__ a, int32_t
                 if (j < w) a[(size_t)i * ld + k0 + j] = r[q][j];
         }
     }
-    // Row interchanges on the columns outside the panel are left to the whole grid (one CU moves ~50 GB/s, and the w
-    // swaps touch up to 2w rows of m entries): thread 0 replays them on an index list and publishes, for every touched
-    // row, the row its final content comes from.  perm[0] = count, perm[1 + q] = row, perm[33 + q] = slot of its source.
-    if (tid == 0) {
-        int cnt = 0;
-        auto slot = [&](int32_t rr) {
-            for (int q = 0; q < cnt; ++q)
-                if (aff[q] == rr) return q;
-            aff[cnt] = rr;
-            src[cnt] = rr;
-            return cnt++;
-        };
-        for (int32_t jj = 0; jj < w; ++jj) {
-            const int qa = slot(k0 + jj), qb = slot(spiv[jj]);
-            const int32_t t = src[qa];
-            src[qa] = src[qb];
-            src[qb] = t;
-        }
-        perm[0] = cnt;
-        for (int q = 0; q < cnt; ++q) {
-            perm[1 + q] = aff[q];
-            int qs = 0;
-            for (int t = 0; t < cnt; ++t)
-                if (aff[t] == src[q]) qs = t;
-            perm[33 + q] = qs;
-        }
-    }
-}
-
-// Z[q, :] = a[perm row q, :]: the rows touched by the panel's interchanges, staged before anything overwrites them
-template <typename T>
-__global__ __launch_bounds__(256) void gj_stage_kernel(const T* __restrict__ a, int32_t ld, int32_t m, const int32_t* __restrict__ perm,
-                                                       T* __restrict__ Z) {
-    const int32_t q = blockIdx.y;
-    if (q >= perm[0]) return;
-    const int32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c < m) Z[(size_t)q * m + c] = a[(size_t)perm[1 + q] * ld + c];
-}
-
-// For the columns c outside the panel:  a[i, c] = base(i, c) + sum_j W[i, j] Y[j, c],  where Y[j, :] is pivot row k0 + j
-// after the interchanges (read from the staged rows Z), and base is 0 for the pivot rows, the interchanged content
-// (from Z) for the other touched rows, and a[i, c] itself elsewhere.  A 256-thread workgroup owns kUpdRows rows; a
-// thread walks columns (coalesced), loads the w pivot-row values ONCE and applies them to all kUpdRows rows.
-constexpr int kUpdRows = 4;
-template <typename T>
-__global__ __launch_bounds__(256) void gj_panel_update_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k0, int32_t w,
-                                                              const int32_t* __restrict__ perm, const T* __restrict__ Z) {
-    __shared__ T Ws[kUpdRows][kPanelW];
-    __shared__ int32_t yslot[kPanelW];     // staged row holding pivot row k0 + j
-    __shared__ int32_t rslot[kUpdRows];    // staged row holding the new content of my row r, or -1
-    const int32_t i0 = blockIdx.x * kUpdRows;
-    if (threadIdx.x < kUpdRows * kPanelW) {
-        const int r = threadIdx.x / kPanelW, j = threadIdx.x % kPanelW;
-        Ws[r][j] = (i0 + r < m && j < w) ? a[(size_t)(i0 + r) * ld + k0 + j] : scalar_traits<T>::zero();
-    }
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + kPanelW + kUpdRows) {
-        const int32_t t = (int32_t)threadIdx.x - 64;
-        const int32_t na = perm[0];
-        const int32_t row = (t < kPanelW) ? k0 + t : i0 + (t - kPanelW);
-        int32_t sl = -1;
-        for (int32_t q = 0; q < na; ++q)
-            if (perm[1 + q] == row) sl = perm[33 + q];
-        if (t < kPanelW) yslot[t] = (t < w) ? sl : 0;
-        else rslot[t - kPanelW] = sl;
-    }
-    __syncthreads();
-    // (columns are not unrolled: the W tile and the y values already fill the register budget of two waves per SIMD)
-#pragma unroll 1
-    for (int32_t c = threadIdx.x; c < m; c += 256) {
-        if (c >= k0 && c < k0 + w) continue;
-        T y[kPanelW];
+    // the panel's interchanges as lists for the next launch, built by wave 0 in registers (a single thread walking LDS
+    // lists cost ~25 us of serial LDS latency per panel): lane l < 8 stands for row k0 + l, lane 8 + l for pivot row
+    // spiv[l]; every lane tracks which original row's content its row holds while the w swaps are replayed.
+    if (wave == 0) {
+        int32_t row = -1;
+        if (lane < kPanelW && lane < w) row = k0 + lane;
+        else if (lane >= kPanelW && lane < kPanelW + w) row = spiv[lane - kPanelW];
+        int32_t content = row;
 #pragma unroll
-        for (int j = 0; j < kPanelW; ++j) y[j] = Z[(size_t)yslot[j] * m + c];  // W is zero beyond w, slot 0 is always valid
-#pragma unroll
-        for (int r = 0; r < kUpdRows; ++r) {
-            const int32_t i = i0 + r;
-            if (i >= m) break;
-            T* e = a + (size_t)i * ld + c;
-            T acc;
-            if (i >= k0 && i < k0 + w) acc = scalar_traits<T>::zero();
-            else if (rslot[r] >= 0) acc = Z[(size_t)rslot[r] * m + c];
-            else acc = *e;
-#pragma unroll
-            for (int j = 0; j < kPanelW; ++j) fma_acc(acc, Ws[r][j], y[j]);
-            *e = acc;
+        for (int jj = 0; jj < W; ++jj) {
+            if (jj < w) {
+                const int32_t ra = k0 + jj, rb = __builtin_amdgcn_readlane(row, kPanelW + jj);
+                const int32_t ca = __builtin_amdgcn_readlane(content, jj), cb = __builtin_amdgcn_readlane(content, kPanelW + jj);
+                if (row == ra) content = cb;
+                else if (row == rb) content = ca;
+            }
         }
+        bool primary = row >= 0;
+#pragma unroll
+        for (int t = 0; t < 2 * kPanelW; ++t) {
+            const int32_t rt = __builtin_amdgcn_readlane(row, t);
+            if (t < lane && rt == row) primary = false;
+        }
+        const unsigned long long pm = __ballot(primary);
+        const int32_t myslot = __popcll(pm & ((1ull << lane) - 1ull));
+        int32_t qs = 0;
+#pragma unroll
+        for (int t = 0; t < 2 * kPanelW; ++t) {
+            const int32_t rt = __builtin_amdgcn_readlane(row, t), stt = __builtin_amdgcn_readlane(myslot, t);
+            if (((pm >> t) & 1ull) && rt == content) qs = stt;
+        }
+        if (lane == 0) pnext[0] = __popcll(pm);
+        if (primary) {
+            pnext[1 + myslot] = row;
+            pnext[33 + myslot] = qs;
+        }
+        if (lane < w) pnext[50 + lane] = qs;  // where pivot row k0 + lane's new content is staged (rows k0 + l are primary)
     }
 }
 
@@ -557,23 +621,14 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
         LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    // panel width of the blocked Gauss-Jordan (LSA_GJ_PANEL=1 selects the unblocked form: two launches per pivot): 8
-    // columns while a thread of the panel kernel holds at most 4 rows, 4 columns up to 8 rows (blocks of 4096 rows)
+    // panel width of the blocked Gauss-Jordan = the W of the gj_fused_kernel instance used below: 8 columns while a
+    // thread holds at most 4 rows, 4 columns up to 8 rows (blocks of 4096 rows); LSA_GJ_PANEL=1 selects the unblocked
+    // form (two launches per pivot), which is also what larger blocks get
     int32_t panel_w = B <= 2048 ? 8 : B <= 4096 ? 4 : 1;
-    if (const char* e = getenv("LSA_GJ_PANEL")) panel_w = std::max(1, std::min(panel_w, atoi(e)));
-    // LSA_BLU_TIMING=2: HIP events around every launch of block 1 (development aid; per-kernel sums go to stderr)
-    const bool probe = getenv("LSA_BLU_TIMING") && atoi(getenv("LSA_BLU_TIMING")) >= 2;
-    std::vector<std::pair<int, hipEvent_t>> marks;
+    if (const char* e = getenv("LSA_GJ_PANEL"))
+        if (atoi(e) == 1) panel_w = 1;
     auto factor_block = [&](hipStream_t st, int chain, int32_t b, bool corr_left, bool corr_right) {
         const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
-        auto mark = [&](int kind) {
-            if (!probe || b != 1) return;
-            hipEvent_t ev;
-            (void)hipEventCreate(&ev);
-            (void)hipEventRecord(ev, st);
-            marks.push_back({kind, ev});
-        };
-        mark(-1);
         T* S = (T*)f->sinv + (size_t)bs * ld;
         hipLaunchKernelGGL((blu_scatter_kernel<T>), dim3((m * 16 + 255) / 256), dim3(256), 0, st, bs, be, ld, C->rp, C->ci, f->lsplit, f->usplit,
                            (const T*)C->val, S);
@@ -587,22 +642,27 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
             hipLaunchKernelGGL((blu_corner_kernel<T, true>), dim3(m), dim3(256), lds, st, ns, ne, bs, be, ld, C->rp, C->ci, f->lsplit, f->usplit,
                                (const T*)C->val, f->cptr, f->crow, f->cpos, (const T*)f->sinv + (size_t)ns * ld, S);
         }
-        mark(0);
         int32_t* ipiv = f->ipiv[chain];
         int32_t* perm = ipiv + B;  // interchange lists of the current panel (80 ints behind the pivot indices)
         T* ws = (T*)f->colbuf[chain];
         if (panel_w >= 2) {
-            for (int32_t k0 = 0; k0 < m; k0 += panel_w) {
-                const int32_t w = std::min(panel_w, m - k0);
-                if (B <= 1024) hipLaunchKernelGGL((gj_panel_kernel<T, 1024, 1, 8>), dim3(1), dim3(1024), 0, st, S, ld, m, k0, w, ipiv, perm, f->flag, tiny2);
-                else if (B <= 2048) hipLaunchKernelGGL((gj_panel_kernel<T, 512, 4, 8>), dim3(1), dim3(512), 0, st, S, ld, m, k0, w, ipiv, perm, f->flag, tiny2);
-                else hipLaunchKernelGGL((gj_panel_kernel<T, 512, 8, 4>), dim3(1), dim3(512), 0, st, S, ld, m, k0, w, ipiv, perm, f->flag, tiny2);
-                mark(1);
-                hipLaunchKernelGGL((gj_stage_kernel<T>), dim3((m + 255) / 256, 2 * w), dim3(256), 0, st, (const T*)S, ld, m, (const int32_t*)perm, ws);
-                mark(2);
-                hipLaunchKernelGGL((gj_panel_update_kernel<T>), dim3((m + kUpdRows - 1) / kUpdRows), dim3(256), 0, st, S, ld, m, k0, w,
-                                   (const int32_t*)perm, (const T*)ws);
-                mark(3);
+            // launch 0 eliminates panel 0; launch 1 + p updates with panel p and eliminates panel p + 1
+            const int32_t np = (m + panel_w - 1) / panel_w;
+            for (int32_t pn = -1; pn < np; ++pn) {
+                const int32_t kprev = pn >= 0 ? pn * panel_w : -1, wprev = pn >= 0 ? std::min(panel_w, m - kprev) : 0;
+                const int32_t knext = pn + 1 < np ? (pn + 1) * panel_w : -1, wnext = knext >= 0 ? std::min(panel_w, m - knext) : 0;
+                const int32_t* pprev = perm + 64 * (pn & 1);
+                int32_t* pnext = perm + 64 * ((pn + 1) & 1);
+                const dim3 grid(pn >= 0 ? 1 + np : 1);
+                if (B <= 1024)
+                    hipLaunchKernelGGL((gj_fused_kernel<T, 1024, 1, 8>), grid, dim3(1024), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev, pnext,
+                                       f->flag, tiny2);
+                else if (B <= 2048)
+                    hipLaunchKernelGGL((gj_fused_kernel<T, 512, 4, 8>), grid, dim3(512), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev, pnext,
+                                       f->flag, tiny2);
+                else
+                    hipLaunchKernelGGL((gj_fused_kernel<T, 512, 8, 4>), grid, dim3(512), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev, pnext,
+                                       f->flag, tiny2);
             }
         } else {
             for (int32_t k = 0; k < m; ++k) {
@@ -632,20 +692,6 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
     int32_t hflag[4];
     LSA_HIP_CHECK(ctx, hipMemcpyAsync(hflag, f->flag, sizeof hflag, hipMemcpyDeviceToHost, ctx->stream));
     LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (!marks.empty()) {
-        double sum[4] = {0, 0, 0, 0};
-        int cnt[4] = {0, 0, 0, 0};
-        for (size_t i = 1; i < marks.size(); ++i) {
-            float ms = 0.f;
-            (void)hipEventElapsedTime(&ms, marks[i - 1].second, marks[i].second);
-            sum[marks[i].first] += ms;
-            ++cnt[marks[i].first];
-        }
-        const char* names[4] = {"scatter+corner", "panel", "stage", "update"};
-        for (int q = 0; q < 4; ++q)
-            fprintf(stderr, "[lsa_blu] block 1 %-14s %4d intervals, %8.1f us each, %7.2f ms total\n", names[q], cnt[q], cnt[q] ? sum[q] * 1e3 / cnt[q] : 0.0, sum[q]);
-        for (auto& mk : marks) (void)hipEventDestroy(mk.second);
-    }
     if (getenv("LSA_BLU_TIMING"))
         fprintf(stderr, "[lsa_blu] numeric factorisation: host enqueue %.1f ms, device drained after %.1f ms\n", (t_sub - t_enq) * 1e3,
                 (now_s() - t_enq) * 1e3);

@@ -506,45 +506,32 @@ __global__ void gj_unpivot_kernel(T* __restrict__ a, int32_t ld, int32_t m, cons
 }
 
 // ---- solve kernels ------------------------------------------------------------------------------------------------------
-// out[r] = rhs[r] - sum over the entries of row r left of (LEFT) / right of its diagonal block of val * x[col]
-template <typename MT, typename VT, bool LEFT>
-__global__ __launch_bounds__(256) void blu_sparse_kernel(int32_t bs, int32_t be, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+// The twisted sweeps advance two independent chains (one from each end of the block tridiagonal matrix).  Every launch
+// serves one block of EACH chain -- "A" in the first workgroups, "B" in the rest -- so a sweep costs half the dependent
+// launches and each launch moves twice the bytes; a chain that has run out passes an empty range.
+struct BluRange {
+    int32_t bs, be;  // rows [bs, be) of one diagonal block
+    int32_t mode;    // sparse kernel: 1 = entries left of the block, 2 = right of it, 3 = both
+};
+
+// out[r] = rhs[r] - sum over the selected off-block entries of row r of val * x[col]; 16 lanes per row
+template <typename MT, typename VT>
+__global__ __launch_bounds__(256) void blu_sparse_kernel(BluRange ra, BluRange rb, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                          const int32_t* __restrict__ lsplit, const int32_t* __restrict__ usplit,
                                                          const MT* __restrict__ val, const VT* __restrict__ rhs, const VT* __restrict__ x,
                                                          VT* __restrict__ out) {
-    const int32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t ga = ((ra.be - ra.bs) * 16 + 255) / 256;
+    const bool second = (int32_t)blockIdx.x >= ga;
+    const BluRange rg = second ? rb : ra;
+    const int32_t gid = ((int32_t)blockIdx.x - (second ? ga : 0)) * 256 + threadIdx.x;
     const int lane = gid & 15;
-    const int32_t r = bs + (gid >> 4);
-    if (r >= be) return;
-    const int32_t p0 = LEFT ? rp[r] : usplit[r];
-    const int32_t p1 = LEFT ? lsplit[r] : rp[r + 1];
+    const int32_t r = rg.bs + (gid >> 4);
+    if (r >= rg.be) return;
     VT acc = scalar_traits<VT>::zero();
-    for (int32_t p = p0 + lane; p < p1; p += 16) fma_acc(acc, val[p], x[ci[p]]);
-#pragma unroll
-    for (int s = 8; s > 0; s >>= 1) {
-        if constexpr (sizeof(VT) == 16) {
-            acc.re += __shfl_xor(acc.re, s, 64);
-            acc.im += __shfl_xor(acc.im, s, 64);
-        } else {
-            acc += __shfl_xor(acc, s, 64);
-        }
-    }
-    if (lane == 0) out[r] = s_sub(rhs[r], acc);
-}
-
-// middle block of the twisted sweep: out[r] = rhs[r] - (entries left AND right of the diagonal block) * x
-template <typename MT, typename VT>
-__global__ __launch_bounds__(256) void blu_sparse_both_kernel(int32_t bs, int32_t be, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
-                                                              const int32_t* __restrict__ lsplit, const int32_t* __restrict__ usplit,
-                                                              const MT* __restrict__ val, const VT* __restrict__ rhs, const VT* __restrict__ x,
-                                                              VT* __restrict__ out) {
-    const int32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = gid & 15;
-    const int32_t r = bs + (gid >> 4);
-    if (r >= be) return;
-    VT acc = scalar_traits<VT>::zero();
-    for (int32_t p = rp[r] + lane; p < lsplit[r]; p += 16) fma_acc(acc, val[p], x[ci[p]]);
-    for (int32_t p = usplit[r] + lane; p < rp[r + 1]; p += 16) fma_acc(acc, val[p], x[ci[p]]);
+    if (rg.mode & 1)
+        for (int32_t p = rp[r] + lane; p < lsplit[r]; p += 16) fma_acc(acc, val[p], x[ci[p]]);
+    if (rg.mode & 2)
+        for (int32_t p = usplit[r] + lane; p < rp[r + 1]; p += 16) fma_acc(acc, val[p], x[ci[p]]);
 #pragma unroll
     for (int s = 8; s > 0; s >>= 1) {
         if constexpr (sizeof(VT) == 16) {
@@ -559,10 +546,13 @@ __global__ __launch_bounds__(256) void blu_sparse_both_kernel(int32_t bs, int32_
 
 // out[r] = sum_s Sinv[r, s] in[s] over the whole diagonal block; one wavefront per row, 8 loads in flight per lane
 template <typename MT, typename VT>
-__global__ __launch_bounds__(256) void blu_dense_kernel(int32_t bs, int32_t be, int32_t ld, const MT* __restrict__ sinv,
+__global__ __launch_bounds__(256) void blu_dense_kernel(BluRange ra, BluRange rb, int32_t ld, const MT* __restrict__ sinv,
                                                         const VT* __restrict__ in, VT* __restrict__ out) {
+    const int32_t ga = (ra.be - ra.bs + 3) / 4;
+    const bool second = (int32_t)blockIdx.x >= ga;
+    const int32_t bs = second ? rb.bs : ra.bs, be = second ? rb.be : ra.be;
     const int lane = threadIdx.x & 63;
-    const int32_t r = bs + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int32_t r = bs + ((int32_t)blockIdx.x - (second ? ga : 0)) * 4 + (threadIdx.x >> 6);
     if (r >= be) return;
     const MT* row = sinv + (size_t)r * ld - bs;
     VT acc[4];
@@ -703,64 +693,28 @@ template <typename MT, typename VT>
 int launch_apply(lsa_ctx* ctx, lsa_blu* f, const VT* v, VT* x, VT* y, VT* z, VT* t) {
     const int32_t B = f->B, nb = f->nb, n = f->n, mid = f->mid;
     const lsa_mat* C = f->C;
-    // The sweeps' kernels are a few microseconds each: measured at S30k, running the two chains on two queues costs
-    // 796 us per apply against 538 us for the same twisted order on one queue (graph replay), so the solve stays on
-    // one stream; the factorisation, whose panel kernels occupy one CU for ~50 us, does gain from two (0.35 -> 0.21 s).
-    static const bool two_streams = getenv("LSA_BLU_SOLVE_STREAMS") && atoi(getenv("LSA_BLU_SOLVE_STREAMS")) == 2;
-    hipStream_t s0 = ctx->stream, s1 = two_streams ? f->stream2 : ctx->stream;
-    auto sparse = [&](hipStream_t st, bool left, int32_t b, const VT* rhs, const VT* xin, VT* out) {
-        const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
-        if (left)
-            hipLaunchKernelGGL((blu_sparse_kernel<MT, VT, true>), dim3((m * 16 + 255) / 256), dim3(256), 0, st, bs, be, C->rp, C->ci, f->lsplit,
-                               f->usplit, (const MT*)C->val, rhs, xin, out);
-        else
-            hipLaunchKernelGGL((blu_sparse_kernel<MT, VT, false>), dim3((m * 16 + 255) / 256), dim3(256), 0, st, bs, be, C->rp, C->ci, f->lsplit,
-                               f->usplit, (const MT*)C->val, rhs, xin, out);
+    hipStream_t st = ctx->stream;
+    auto range = [&](int32_t b, int32_t mode) {
+        if (b < 0 || b >= nb) return BluRange{0, 0, 0};
+        return BluRange{b * B, std::min(n, b * B + B), mode};
     };
-    auto dense = [&](hipStream_t st, int32_t b, const VT* in, VT* out) {
-        const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
-        hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3((m + 3) / 4), dim3(256), 0, st, bs, be, f->ld, (const MT*)f->sinv, in, out);
+    auto step = [&](BluRange ra, BluRange rb, const VT* rhs, const VT* xin, VT* tmp, VT* out) {
+        const int32_t gs = ((ra.be - ra.bs) * 16 + 255) / 256 + ((rb.be - rb.bs) * 16 + 255) / 256;
+        const int32_t gd = (ra.be - ra.bs + 3) / 4 + (rb.be - rb.bs + 3) / 4;
+        if (gs == 0) return;
+        hipLaunchKernelGGL((blu_sparse_kernel<MT, VT>), dim3(gs), dim3(256), 0, st, ra, rb, C->rp, C->ci, f->lsplit, f->usplit, (const MT*)C->val, rhs,
+                           xin, tmp);
+        hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3(gd), dim3(256), 0, st, ra, rb, f->ld, (const MT*)f->sinv, (const VT*)tmp, out);
     };
-    // elimination towards the middle, two chains in parallel:  y_b = v_b - C_{b,b-+1} z_{b-+1},  z_b = Sinv_b y_b
-    LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_fork, s0));
-    LSA_HIP_CHECK(ctx, hipStreamWaitEvent(s1, f->ev_fork, 0));
-    // (the two chains are enqueued alternately so that neither queue waits for the host)
+    // elimination towards the middle, both chains per launch:  y_b = v_b - C_{b,b-+1} z_{b-+1},  z_b = Sinv_b y_b
     for (int32_t k = 0; k < std::max(mid, nb - 1 - mid); ++k) {
         const int32_t bt = k, bb = nb - 1 - k;
-        if (bt < mid) {
-            sparse(s0, true, bt, v, (const VT*)z, y);
-            dense(s0, bt, (const VT*)y, z);
-        }
-        if (bb > mid) {
-            sparse(s1, false, bb, v, (const VT*)z, y);
-            dense(s1, bb, (const VT*)y, z);
-        }
+        step(range(bt < mid ? bt : -1, 1), range(bb > mid ? bb : -1, 2), v, (const VT*)z, y, z);
     }
-    LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_join, s1));
-    LSA_HIP_CHECK(ctx, hipStreamWaitEvent(s0, f->ev_join, 0));
     // middle block: x_m = Sinv_m (v_m - C_{m,m-1} z_{m-1} - C_{m,m+1} z_{m+1})
-    {
-        const int32_t bs = mid * B, be = std::min(n, bs + B), m = be - bs;
-        hipLaunchKernelGGL((blu_sparse_both_kernel<MT, VT>), dim3((m * 16 + 255) / 256), dim3(256), 0, s0, bs, be, C->rp, C->ci, f->lsplit,
-                           f->usplit, (const MT*)C->val, v, (const VT*)z, t);
-        dense(s0, mid, (const VT*)t, x);
-    }
-    // substitution outwards, two chains in parallel:  x_b = Sinv_b (y_b - C_{b,b+-1} x_{b+-1})
-    LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_fork, s0));
-    LSA_HIP_CHECK(ctx, hipStreamWaitEvent(s1, f->ev_fork, 0));
-    for (int32_t k = 1; k <= std::max(mid, nb - 1 - mid); ++k) {
-        const int32_t bt = mid - k, bb = mid + k;
-        if (bt >= 0) {
-            sparse(s0, false, bt, (const VT*)y, (const VT*)x, t);
-            dense(s0, bt, (const VT*)t, x);
-        }
-        if (bb < nb) {
-            sparse(s1, true, bb, (const VT*)y, (const VT*)x, t);
-            dense(s1, bb, (const VT*)t, x);
-        }
-    }
-    LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_join, s1));
-    LSA_HIP_CHECK(ctx, hipStreamWaitEvent(s0, f->ev_join, 0));
+    step(range(mid, 3), range(-1, 0), v, (const VT*)z, t, x);
+    // substitution outwards, both chains per launch:  x_b = Sinv_b (y_b - C_{b,b+-1} x_{b+-1})
+    for (int32_t k = 1; k <= std::max(mid, nb - 1 - mid); ++k) step(range(mid - k, 2), range(mid + k, 1), (const VT*)y, (const VT*)x, t, x);
     return LSA_OK;
 }
 

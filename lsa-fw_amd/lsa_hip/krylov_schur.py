@@ -22,6 +22,7 @@ from typing import Callable
 
 import numpy as np
 import scipy.linalg as sla
+from scipy.linalg import lapack as _lapack
 
 
 @dataclass
@@ -35,19 +36,23 @@ class KrylovSchurResult:
     history: list = field(default_factory=list)
 
 
-def _schur_wanted_first(H: np.ndarray, rank_key, k: int, eigenvalues: np.ndarray):
-    """Complex Schur form H = Q T Q^H with (at least) the k best-ranked eigenvalues in the leading block.
+def _schur_wanted_first(T: np.ndarray, Q: np.ndarray, rank_key, k: int):
+    """Reorder the complex Schur form H = Q T Q^H so that (at least) the k best-ranked eigenvalues lead.
 
-    ``eigenvalues`` are H's eigenvalues (any order; used only to place the selection threshold between the k-th and
-    the (k+1)-th key).  Returns (T, Q, sdim) where sdim is the size of the leading block LAPACK actually selected."""
-    m = H.shape[0]
+    One LAPACK ``ztrsen`` on the factors the convergence test already computed (a second ``zgees`` with a Python sort
+    callback costs as much as the first).  Ties at the selection threshold are all selected, like a sort callback would;
+    returns (T, Q, sdim) with sdim the size of the leading block actually selected."""
+    m = T.shape[0]
     if k <= 0 or k >= m:
-        T, Q = sla.schur(H, output="complex")
-        return T, Q, m if k >= m else 0
-    keys = np.sort(rank_key(eigenvalues))
+        return T, Q, (m if k >= m else 0)
+    key_diag = rank_key(np.diag(T))
+    keys = np.sort(key_diag)
     thr = 0.5 * (keys[k - 1] + keys[k]) if keys[k] > keys[k - 1] else keys[k - 1]
-    T, Q, sdim = sla.schur(H, output="complex", sort=lambda z: bool(rank_key(np.array([z]))[0] <= thr))
-    return T, Q, int(sdim)
+    select = (key_diag <= thr).astype(np.int32)
+    Ts, Qs, _w, sdim, _s, _sep, info = _lapack.ztrsen(select, T, Q, job="N", wantq=1)
+    if info != 0:  # reordering failed (ill-conditioned swap): fall back to a sorted factorisation of Q T Q^H
+        Ts, Qs, sdim = sla.schur(Q @ T @ Q.conj().T, output="complex", sort=lambda z: bool(rank_key(np.array([z]))[0] <= thr))
+    return Ts, Qs, int(sdim)
 
 
 def krylov_schur(
@@ -126,7 +131,7 @@ def krylov_schur(
         # ---- truncate to the wanted part of the Schur form and restart -----------------------------------------------
         knew = nconv + int((m_eff - nconv) * keep_fraction)
         knew = max(min(knew, m_eff - 1), 1)
-        T, Q, sdim = _schur_wanted_first(Hm, rank_key, knew, w)
+        T, Q, sdim = _schur_wanted_first(T, Q, rank_key, knew)
         knew = max(min(sdim, m_eff - 1), 1)
         bt = b @ Q
         backend.restart(m_eff, Q[:, :knew])

@@ -1,0 +1,38 @@
+"""cProfile of one warm EigenSolver.solve() on the bench workload (development aid)."""
+import argparse
+import cProfile
+import pstats
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "lsa-fw_amd")]
+import numpy as np  # noqa: E402
+
+from oracle import fem  # noqa: E402
+from Solver.eigen import EigenSolver, EigensolverConfig  # noqa: E402
+from Solver.utils import PreconditionerType, iSTType  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--case", default="S30k")
+ap.add_argument("--pc", default="lu")
+args = ap.parse_args()
+es = fem.cylinder_case(args.case)
+cfg = EigensolverConfig(num_eig=20, atol=1e-10, ncv=80, max_it=500)
+pc = PreconditionerType.LU if args.pc == "lu" else PreconditionerType.ILU
+solver = EigenSolver(es.A, es.M, cfg, check_hermitian=False)
+inner = solver.solver
+inner.set_st_type(iSTType.SINVERT)
+inner.set_target(fem.SIGMA_RE50)
+inner.set_st_pc_type(pc)
+inner.prepare()
+inner.solve()
+t0 = time.time()
+inner.solve()
+print(f"warm solve {time.time() - t0:.3f} s  stats={inner.stats}")
+pr = cProfile.Profile()
+pr.enable()
+inner.solve()
+pr.disable()
+pstats.Stats(pr).sort_stats("cumulative").print_stats(28)

@@ -21,7 +21,11 @@ def _ordered(case, sigma):
     return es, Cp
 
 
-@pytest.mark.parametrize("case,sigma,block", [("S2k", 0.018 + 0.7379601143282424j, 256), ("S5k", 0.018 + 0.7379601143282424j, 0), ("S5k", 0.05, 512)])
+# block sizes 1536 and 2560 exercise the panel-kernel instances for blocks of <= 2048 and <= 4096 rows (4 and 8 rows per
+# thread, panels of 8 and 4 columns); the default and 256 / 512 use the thread-per-row instance
+@pytest.mark.parametrize("case,sigma,block", [("S2k", 0.018 + 0.7379601143282424j, 256), ("S5k", 0.018 + 0.7379601143282424j, 0),
+                                              ("S5k", 0.05, 512), ("S5k", 0.018 + 0.7379601143282424j, 1536),
+                                              ("S5k", 0.018 + 0.7379601143282424j, 2560)])
 def test_block_lu_is_a_direct_solver(hip_ctx, case, sigma, block):
     import lsa_hip
 
@@ -41,6 +45,42 @@ def test_block_lu_is_a_direct_solver(hip_ctx, case, sigma, block):
     assert np.linalg.norm(x - xref) <= 1e-11 * np.linalg.norm(xref)
     f.solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)  # graph replay gives the same answer
     assert np.array_equal(dx.numpy(), x)
+
+
+@pytest.mark.parametrize("block", [256, 1536, 2560])
+def test_block_lu_real_matrix(hip_ctx, block):
+    """float64 instantiation: a real, non-symmetric, banded matrix that needs row interchanges (weak diagonal)."""
+    import lsa_hip
+
+    n, bw = 3000, 40
+    rng = np.random.default_rng(11)
+    offs = [-bw, -7, -1, 0, 1, 5, bw]
+    A = sp.diags([rng.standard_normal(n - abs(o)) for o in offs], offs, format="csr")
+    A = A + sp.diags(0.05 * np.ones(n), 0)
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    f = lsa_hip.BlockLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), block)
+    b = rng.standard_normal(n)
+    dx = lsa_hip.DeviceVector(hip_ctx, n, np.float64)
+    f.solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
+    xref = spla.splu(sp.csc_matrix(A)).solve(b)
+    assert np.linalg.norm(dx.numpy() - xref) <= 1e-9 * np.linalg.norm(xref)
+
+
+def test_block_lu_unblocked_elimination_agrees(hip_ctx, monkeypatch):
+    """LSA_GJ_PANEL=1 selects the two-launches-per-pivot Gauss-Jordan (what blocks of more than 4096 rows get)."""
+    import lsa_hip
+
+    es, Cp = _ordered("S2k", 0.018 + 0.7379601143282424j)
+    dC = lsa_hip.CsrMatrix.from_scipy(hip_ctx, Cp)
+    b = np.random.default_rng(5).standard_normal(es.n) + 0j
+    xs = []
+    for panel in ("8", "1"):
+        monkeypatch.setenv("LSA_GJ_PANEL", panel)
+        dx = lsa_hip.DeviceVector(hip_ctx, es.n, np.complex128)
+        lsa_hip.BlockLu(hip_ctx, dC, 512).solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
+        xs.append(dx.numpy())
+    assert np.linalg.norm(xs[0] - xs[1]) <= 1e-11 * np.linalg.norm(xs[1])
 
 
 def test_block_lu_reports_singular_block(hip_ctx):

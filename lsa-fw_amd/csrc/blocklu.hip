@@ -489,9 +489,43 @@ __global__ __launch_bounds__(NT) void gj_fused_kernel(T* __restrict__ a, int32_t
     }
 }
 
-// undo the row interchanges on the columns of the inverse: thread per row, swaps in reverse order
+// Undo the row interchanges on the columns of the inverse: every row r needs  for k = m-1 .. 0: swap(r[k], r[ipiv[k]]).
+// The swaps are the same for all rows, so the column each entry ends up in is computed once (thread j follows the entry
+// that starts in column j through the m swaps, ipiv broadcast from LDS), then every row is permuted in one pass.
+__global__ __launch_bounds__(256) void gj_colperm_kernel(int32_t m, const int32_t* __restrict__ ipiv, int32_t* __restrict__ pos) {
+    extern __shared__ int32_t spv[];
+    for (int32_t k = threadIdx.x; k < m; k += 256) spv[k] = ipiv[k];
+    __syncthreads();
+    const int32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    int32_t at = j;
+    for (int32_t k = m - 1; k >= 0; --k) {
+        const int32_t p = spv[k];
+        at = (at == k) ? p : (at == p ? k : at);
+    }
+    pos[j] = at;
+}
+
 template <typename T>
-__global__ void gj_unpivot_kernel(T* __restrict__ a, int32_t ld, int32_t m, const int32_t* __restrict__ ipiv) {
+__global__ __launch_bounds__(256) void gj_unpivot_kernel(T* __restrict__ a, int32_t ld, int32_t m, const int32_t* __restrict__ pos) {
+    T* row = a + (size_t)blockIdx.x * ld;
+    T v[16];  // m <= 4096
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int32_t j = threadIdx.x + 256 * q;
+        if (j < m) v[q] = row[j];
+    }
+    __syncthreads();  // the whole row is in registers before any of it is overwritten
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int32_t j = threadIdx.x + 256 * q;
+        if (j < m) row[pos[j]] = v[q];
+    }
+}
+
+// (blocks of more than 4096 rows: thread per row, swaps replayed in place)
+template <typename T>
+__global__ void gj_unpivot_serial_kernel(T* __restrict__ a, int32_t ld, int32_t m, const int32_t* __restrict__ ipiv) {
     const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     T* ri = a + (size_t)i * ld;
@@ -660,7 +694,13 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
                 hipLaunchKernelGGL((gj_update_kernel<T>), dim3((m + 3) / 4), dim3(256), 0, st, S, ld, m, k, (const T*)ws);
             }
         }
-        hipLaunchKernelGGL((gj_unpivot_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, st, S, ld, m, ipiv);
+        if (m <= 4096) {
+            int32_t* pos = perm + 128;  // behind the two interchange-list buffers
+            hipLaunchKernelGGL(gj_colperm_kernel, dim3((m + 255) / 256), dim3(256), (size_t)m * sizeof(int32_t), st, m, (const int32_t*)ipiv, pos);
+            hipLaunchKernelGGL((gj_unpivot_kernel<T>), dim3(m), dim3(256), 0, st, S, ld, m, (const int32_t*)pos);
+        } else {
+            hipLaunchKernelGGL((gj_unpivot_serial_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, st, S, ld, m, (const int32_t*)ipiv);
+        }
     };
     // twisted order: chain 0 eliminates downwards from block 0, chain 1 upwards from the last block, on two streams;
     // they meet at the middle block, which receives both corrections
@@ -839,7 +879,7 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     bool ok = hipMalloc((void**)&f->lsplit, 4 * n1) == hipSuccess && hipMalloc((void**)&f->usplit, 4 * n1) == hipSuccess &&
               hipMalloc((void**)&f->cptr, 4 * (n1 + 1)) == hipSuccess && hipMalloc((void**)&f->crow, 4 * z1) == hipSuccess &&
               hipMalloc((void**)&f->cpos, 4 * z1) == hipSuccess && hipMalloc(&f->sinv, inv_bytes) == hipSuccess &&
-              hipMalloc((void**)&f->ipiv[0], 4 * ((size_t)B + 128)) == hipSuccess && hipMalloc((void**)&f->ipiv[1], 4 * ((size_t)B + 128)) == hipSuccess &&
+              hipMalloc((void**)&f->ipiv[0], 4 * (2 * (size_t)B + 128)) == hipSuccess && hipMalloc((void**)&f->ipiv[1], 4 * (2 * (size_t)B + 128)) == hipSuccess &&
               hipMalloc(&f->colbuf[0], esz * (size_t)B * 48) == hipSuccess && hipMalloc(&f->colbuf[1], esz * (size_t)B * 48) == hipSuccess &&
               hipMalloc((void**)&f->flag, 16) == hipSuccess && hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) == hipSuccess &&

@@ -39,6 +39,8 @@ struct lsa_blu {
     void *in[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr};
     void* graph[2] = {nullptr, nullptr};
     double seconds = 0.0;
+    uint64_t pattern_hash = 0;  // of C's host row pointers and column indices (key of the per-context cache)
+    int64_t nnz = 0;
 };
 
 namespace {
@@ -808,7 +810,7 @@ int blu_solve_dev(lsa_ctx* ctx, lsa_blu* f, int vdtype, const void* b, void* x) 
 
 extern "C" {
 
-void lsa_blu_destroy(lsa_blu* f) {
+static void blu_free(lsa_blu* f) {
     if (!f) return;
     if (f->ctx && f->ctx->stream) (void)hipStreamSynchronize(f->ctx->stream);
     for (int vd = 0; vd < 2; ++vd) {
@@ -826,37 +828,37 @@ void lsa_blu_destroy(lsa_blu* f) {
     delete f;
 }
 
-int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu** out) {
-    if (!ctx || !C || !out) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_blu_create: null argument");
-    if (C->n != C->ncols) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_blu_create: the matrix must be square");
-    const double t0 = now_s();
-    const int32_t n = C->n;
-    int32_t bw = 0;
-    for (int32_t i = 0; i < n; ++i)
-        for (int32_t p = C->h_rp[i]; p < C->h_rp[i + 1]; ++p) bw = std::max(bw, std::abs(C->h_ci[p] - i));
-    int32_t B = std::max(block_size > 0 ? block_size : 1024, bw + 1);
-    B = ((B + 255) / 256) * 256;
+void lsa_blu_drop_cache(lsa_ctx* ctx) {
+    if (!ctx || !ctx->blu_cache) return;
+    blu_free(ctx->blu_cache);
+    ctx->blu_cache = nullptr;
+}
+
+// A destroyed factorisation parks its symbolic data and buffers in the context (one slot): allocating, clearing and
+// freeing n x B scalars and rebuilding the CSC view cost ~15 ms per shift at S30k, a fifth of the numeric work.
+void lsa_blu_destroy(lsa_blu* f) {
+    if (!f) return;
+    lsa_ctx* ctx = f->ctx;
+    if (!ctx || !f->sinv || !f->cptr || f->pattern_hash == 0 || getenv("LSA_BLU_NO_CACHE")) {
+        blu_free(f);
+        return;
+    }
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int vd = 0; vd < 2; ++vd) {  // the captured sweeps point into the values of a matrix that is going away
+        if (f->graph[vd]) (void)hipGraphExecDestroy((hipGraphExec_t)f->graph[vd]);
+        f->graph[vd] = nullptr;
+    }
+    f->C = nullptr;
+    lsa_blu_drop_cache(ctx);
+    ctx->blu_cache = f;
+}
+
+// symbolic part of a factorisation: splits on C's pattern, a CSC view (positions into C's value array) for the corner
+// update, and every device buffer
+static bool blu_setup(lsa_ctx* ctx, lsa_blu* f, const lsa_mat* C) {
+    const int32_t n = f->n, B = f->B;
     const size_t esz = C->dtype == LSA_C128 ? 16 : 8;
-    const int32_t ld = B + 16;
-    const size_t inv_bytes = (size_t)std::max(n, 1) * ld * esz;
-    size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
-    if (inv_bytes > free_b / 2)
-        return lsa_set_error(ctx, LSA_ERR_HIP, "block LU: bandwidth %d needs %.1f GB of inverted Schur blocks (%.1f GB free); use ILU(k)", bw,
-                             inv_bytes / 1e9, free_b / 1e9);
-    lsa_blu* f = new lsa_blu();
-    f->ctx = ctx;
-    f->C = C;
-    f->n = n;
-    f->B = B;
-    f->ld = ld;
-    f->nb = n > 0 ? (n + B - 1) / B : 0;
-    f->mid = f->nb / 2;
-    if (const char* e = getenv("LSA_BLU_TWIST"))  // 0: one chain from the first block (the middle block is the last one)
-        if (atoi(e) == 0) f->mid = f->nb > 0 ? f->nb - 1 : 0;
-    f->bandwidth = bw;
-    f->dtype = C->dtype;
-    // splits on C's pattern and a CSC view (positions into C's value array) for the corner update
+    const size_t inv_bytes = (size_t)std::max(n, 1) * f->ld * esz;
     std::vector<int32_t> ls((size_t)n), us((size_t)n), cptr((size_t)n + 1, 0), crow((size_t)C->nnz), cpos((size_t)C->nnz);
     const int32_t* c = C->h_ci.data();
     for (int32_t r = 0; r < n; ++r) {
@@ -890,20 +892,76 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
          hipMemcpyAsync(f->cptr, cptr.data(), 4 * ((size_t)n + 1), hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(f->crow, crow.data(), 4 * (size_t)C->nnz, hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(f->cpos, cpos.data(), 4 * (size_t)C->nnz, hipMemcpyHostToDevice, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess;
-    if (!ok) {
-        lsa_blu_destroy(f);
-        return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_blu_create: out of device memory");
+    return ok;
+}
+
+int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu** out) {
+    if (!ctx || !C || !out) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_blu_create: null argument");
+    if (C->n != C->ncols) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_blu_create: the matrix must be square");
+    const double t0 = now_s();
+    const int32_t n = C->n;
+    int32_t bw = 0;
+    for (int32_t i = 0; i < n; ++i)
+        for (int32_t p = C->h_rp[i]; p < C->h_rp[i + 1]; ++p) bw = std::max(bw, std::abs(C->h_ci[p] - i));
+    int32_t B = std::max(block_size > 0 ? block_size : 1024, bw + 1);
+    B = ((B + 255) / 256) * 256;
+    const size_t esz = C->dtype == LSA_C128 ? 16 : 8;
+    const int32_t ld = B + 16;
+    const size_t inv_bytes = (size_t)std::max(n, 1) * ld * esz;
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    if (inv_bytes > free_b / 2)
+        return lsa_set_error(ctx, LSA_ERR_HIP, "block LU: bandwidth %d needs %.1f GB of inverted Schur blocks (%.1f GB free); use ILU(k)", bw,
+                             inv_bytes / 1e9, free_b / 1e9);
+    // FNV-1a over the host pattern: the key of the per-context cache
+    uint64_t hash = 1469598103934665603ull;
+    auto mix = [&](const int32_t* v, size_t cnt) {
+        for (size_t i = 0; i < cnt; ++i) {
+            hash ^= (uint32_t)v[i];
+            hash *= 1099511628211ull;
+        }
+    };
+    mix(C->h_rp.data(), C->h_rp.size());
+    mix(C->h_ci.data(), C->h_ci.size());
+    if (hash == 0) hash = 1;
+    int32_t mid = (n > 0 ? (n + B - 1) / B : 0) / 2;
+    if (const char* e = getenv("LSA_BLU_TWIST"))  // 0: one chain from the first block (the middle block is the last one)
+        if (atoi(e) == 0) mid = n > 0 ? (n + B - 1) / B - 1 : 0;
+    lsa_blu* f = nullptr;
+    if (lsa_blu* c = ctx->blu_cache) {
+        if (c->pattern_hash == hash && c->n == n && c->nnz == C->nnz && c->B == B && c->dtype == C->dtype && c->mid == mid &&
+            !getenv("LSA_BLU_NO_CACHE")) {
+            f = c;
+            ctx->blu_cache = nullptr;
+            f->C = C;
+        } else {
+            lsa_blu_drop_cache(ctx);  // do not hold n x B scalars for a pattern that is gone
+        }
     }
-    if (getenv("LSA_BLU_TIMING")) fprintf(stderr, "[lsa_blu] symbolic setup + allocation + upload %.1f ms\n", (now_s() - t0) * 1e3);
+    const bool reused = f != nullptr;
+    if (!reused) {
+        f = new lsa_blu();
+        f->ctx = ctx;
+        f->C = C;
+        f->n = n;
+        f->B = B;
+        f->ld = ld;
+        f->nb = n > 0 ? (n + B - 1) / B : 0;
+        f->mid = mid;
+        f->bandwidth = bw;
+        f->dtype = C->dtype;
+        f->pattern_hash = hash;
+        f->nnz = C->nnz;
+        if (!blu_setup(ctx, f, C)) {
+            blu_free(f);
+            return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_blu_create: out of device memory");
+        }
+    }
+    if (getenv("LSA_BLU_TIMING")) fprintf(stderr, "[lsa_blu] symbolic setup + allocation + upload %.1f ms%s\n", (now_s() - t0) * 1e3, reused ? " (cached)" : "");
     int rc = f->dtype == LSA_C128 ? factorize<cplx>(ctx, f) : factorize<double>(ctx, f);
     if (rc != LSA_OK) {
-        lsa_blu_destroy(f);
+        blu_free(f);
         return rc;
-    }
-    // the CSC view is only needed by the factorisation
-    for (int32_t** p : {&f->cptr, &f->crow, &f->cpos}) {
-        (void)hipFree(*p);
-        *p = nullptr;
     }
     f->seconds = now_s() - t0;
     *out = f;

@@ -96,7 +96,11 @@ struct lsa_ctx {
     // RCCL (multi-GPU); null when single-process
     void* comm = nullptr;
     int nranks = 1, rank = 0;
+    // the last destroyed block LU (symbolic data + buffers), reused when the next one has the same pattern and shape:
+    // a shift sweep refactorises the same pattern once per sigma (.examples/eigenvalues.py:97-108)
+    struct lsa_blu* blu_cache = nullptr;
 };
+extern "C" void lsa_blu_drop_cache(lsa_ctx* ctx);  // blocklu.hip (internal; not part of include/lsa_hip.h)
 
 struct lsa_vec {
     lsa_ctx* ctx;

@@ -67,6 +67,23 @@ def test_block_lu_real_matrix(hip_ctx, block):
     assert np.linalg.norm(dx.numpy() - xref) <= 1e-9 * np.linalg.norm(xref)
 
 
+@pytest.mark.parametrize("n", [1, 2, 7, 8, 9, 17, 255, 256, 257, 300, 519])
+def test_block_lu_ragged_sizes(hip_ctx, n):
+    """Blocks whose size is not a multiple of the panel width, a last block of a few rows, a single row."""
+    import lsa_hip
+
+    rng = np.random.default_rng(100 + n)
+    offs = [o for o in (-3, -1, 0, 1, 2) if abs(o) < n]
+    A = sp.csr_matrix(sp.diags([rng.standard_normal(n - abs(o)) + 1j * rng.standard_normal(n - abs(o)) for o in offs], offs, format="csr"))
+    A.sort_indices()
+    f = lsa_hip.BlockLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), 256)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    dx = lsa_hip.DeviceVector(hip_ctx, n, np.complex128)
+    f.solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
+    xref = np.linalg.solve(A.toarray(), b)
+    assert np.linalg.norm(dx.numpy() - xref) <= 1e-9 * np.linalg.norm(xref)
+
+
 def test_block_lu_unblocked_elimination_agrees(hip_ctx, monkeypatch):
     """LSA_GJ_PANEL=1 selects the two-launches-per-pivot Gauss-Jordan (what blocks of more than 4096 rows get)."""
     import lsa_hip

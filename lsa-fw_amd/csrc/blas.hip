@@ -157,6 +157,44 @@ __global__ __launch_bounds__(64) void nrm2_finish_kernel(int nblocks, const doub
     if (threadIdx.x == 0) out[0] = acc;
 }
 
+// w = b - z together with the partial sums of |w|^2 and |b|^2 (slots 2 blk, 2 blk + 1): the residual check of a direct
+// inner solve in one pass instead of copy + axpy + two norms
+template <typename T>
+__global__ __launch_bounds__(kThreads) void residual_norms_partial_kernel(int64_t n, const T* __restrict__ b, const T* __restrict__ z,
+                                                                          T* __restrict__ w, double* __restrict__ partial) {
+    __shared__ double smem[4];
+    double rw = 0.0, rb = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const T bi = b[i];
+        const T wi = s_sub(bi, z[i]);
+        w[i] = wi;
+        rw += s_abs2(wi);
+        rb += s_abs2(bi);
+    }
+    const double sw = block_sum<double>(rw, smem);
+    __syncthreads();
+    const double sb = block_sum<double>(rb, smem);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = sw;
+        partial[2 * blockIdx.x + 1] = sb;
+    }
+}
+
+__global__ __launch_bounds__(64) void nrm2_finish2_kernel(int nblocks, const double* __restrict__ partial, double* __restrict__ out) {
+    double a0 = 0.0, a1 = 0.0;
+    for (int k = threadIdx.x; k < nblocks; k += 64) {
+        a0 += partial[2 * k];
+        a1 += partial[2 * k + 1];
+    }
+    a0 = wave_sum<double>(a0);
+    a1 = wave_sum<double>(a1);
+    if (threadIdx.x == 0) {
+        out[0] = a0;
+        out[1] = a1;
+    }
+}
+
 template <typename T>
 __global__ void scale_inv_norm_kernel(int64_t n, const T* __restrict__ x, const double* __restrict__ nrm2,
                                       T* __restrict__ y) {
@@ -291,6 +329,19 @@ int k_nrm2(lsa_ctx* ctx, int dtype, int64_t n, const void* x, double* nrm2_dev) 
     });
     hipLaunchKernelGGL(nrm2_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, blocks, partial, nrm2_dev);
     return check_launch(ctx, "nrm2");
+}
+
+// w = b - z;  nrm2_dev[0] = ||w||^2,  nrm2_dev[1] = ||b||^2  (fixed-order two-stage sums)
+int k_residual_norms(lsa_ctx* ctx, int dtype, int64_t n, const void* b, const void* z, void* w, double* nrm2_dev) {
+    const int blocks = stream_blocks(ctx, n);
+    LSA_CHECK(lsa_ensure_scratch(ctx, sizeof(double) * 2 * (size_t)blocks, 0));
+    double* partial = (double*)ctx->dscratch;
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((residual_norms_partial_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, (const T*)b, (const T*)z, (T*)w,
+                           partial);
+    });
+    hipLaunchKernelGGL(nrm2_finish2_kernel, dim3(1), dim3(64), 0, ctx->stream, blocks, partial, nrm2_dev);
+    return check_launch(ctx, "residual_norms");
 }
 
 int k_scale_by_inv_norm(lsa_ctx* ctx, int dtype, int64_t n, const void* x, const double* nrm2_dev, void* y) {

@@ -161,23 +161,34 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, PcRef pc, int dtype, const void* b
     const size_t vb = (size_t)n * esize(dtype);
     auto col = [&](int j) { return (void*)((char*)W.V + (size_t)j * vb); };
     double bnorm = 0.0;
-    LSA_CHECK(device_norm(ctx, dtype, n, b, W.ow.nrm2, &bnorm));
-    if (!std::isfinite(bnorm)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "GMRES: right-hand side is not finite");
-    if (!use_x0) LSA_CHECK(k_set_zero(ctx, dtype, n, x));
+    double beta0 = -1.0;  // ||b - C x|| of the first cycle when it was computed together with ||b||
     int total = 0;
     double relres = 0.0;
+    if (pc.blu && !use_x0) {
+        // exact (block LU) preconditioner: x = P^-1 b is already the solution on one GPU; the loop below then only
+        // checks b - C x and iterates on the residual when the factors are block-Jacobi over ranks.  The check and
+        // ||b|| come from one fused pass and one stream synchronisation.
+        LSA_CHECK(pc_global(ctx, pc, C->row0, n, dtype, b, x));
+        if (st) st->sptrsv_calls += 2;
+        LSA_CHECK(spmv_global(ctx, C, dtype, x, W.z));
+        if (st) ++st->spmv_calls;
+        LSA_CHECK(k_residual_norms(ctx, dtype, n, b, W.z, W.w, W.ow.nrm2));
+        LSA_CHECK(lsa_ensure_scratch(ctx, 0, 2 * sizeof(double)));
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pinned, W.ow.nrm2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        beta0 = std::sqrt(((const double*)ctx->pinned)[0]);
+        bnorm = std::sqrt(((const double*)ctx->pinned)[1]);
+        use_x0 = true;
+    } else {
+        LSA_CHECK(device_norm(ctx, dtype, n, b, W.ow.nrm2, &bnorm));
+    }
+    if (!std::isfinite(bnorm)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "GMRES: right-hand side is not finite");
+    if (!use_x0) LSA_CHECK(k_set_zero(ctx, dtype, n, x));
     if (bnorm == 0.0) {
         LSA_CHECK(k_set_zero(ctx, dtype, n, x));
         if (iters_out) *iters_out = 0;
         if (relres_out) *relres_out = 0.0;
         return LSA_OK;
-    }
-    if (pc.blu && !use_x0) {
-        // exact (block LU) preconditioner: x = P^-1 b is already the solution on one GPU; the loop below then only
-        // checks b - C x and iterates on the residual when the factors are block-Jacobi over ranks
-        LSA_CHECK(pc_global(ctx, pc, C->row0, n, dtype, b, x));
-        if (st) st->sptrsv_calls += 2;
-        use_x0 = true;
     }
     bool converged = false;
     bool first_cycle = true;
@@ -186,7 +197,9 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, PcRef pc, int dtype, const void* b
     double last_verified = 1e300;
     while (!converged && (total < maxit || pending)) {
         // r = b - C x  -> w
-        if (first_cycle && !use_x0) {
+        if (beta0 >= 0.0) {
+            // already in W.w
+        } else if (first_cycle && !use_x0) {
             LSA_CHECK(k_copy(ctx, dtype, n, b, W.w));
         } else {
             LSA_CHECK(spmv_global(ctx, C, dtype, x, W.z));
@@ -196,8 +209,9 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, PcRef pc, int dtype, const void* b
             LSA_CHECK(k_axpy(ctx, dtype, n, minus1, W.z, W.w));
         }
         first_cycle = false;
-        double beta = 0.0;
-        LSA_CHECK(device_norm(ctx, dtype, n, W.w, W.ow.nrm2, &beta));
+        double beta = beta0;
+        if (beta0 < 0.0) LSA_CHECK(device_norm(ctx, dtype, n, W.w, W.ow.nrm2, &beta));
+        beta0 = -1.0;
         if (!std::isfinite(beta)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "GMRES: residual is not finite");
         relres = beta / bnorm;
         pending = false;

@@ -150,6 +150,11 @@ int lsa_op_create(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, const double
 void lsa_op_destroy(lsa_op *op);
 int lsa_op_apply(lsa_ctx *ctx, lsa_op *op, const lsa_vec *x, lsa_vec *y);
 int lsa_op_stats(const lsa_op *op, lsa_stats *out);
+/* Projected operator  y = P Kfac^-1 Kmul x  with P = diag(keep): keep[i] in {0, 1}, host array of n doubles (NULL
+ * removes the projection).  Stands in for the velocity-subspace projection of ArpackEigenSolver's matvec
+ * (Solver/eigen2.py:164-201: pressure dofs zeroed before and after the inner solve); the input side of the
+ * projection is the caller's: Krylov vectors are outputs of this operator, the start vector is masked on the host. */
+int lsa_op_set_projection(lsa_ctx *ctx, lsa_op *op, const double *keep);
 
 /* ---- Krylov basis: BV + Arnoldi recurrences of EPS Krylov-Schur (SLEPc.EPS.solve, Solver/utils.py:270) -- */
 /* Basis of up to ncv+1 complex vectors of length n, resident in HBM, column-major. */

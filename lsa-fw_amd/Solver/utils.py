@@ -288,7 +288,8 @@ class iEpsSolver:
 
     def __init__(self, A=None, M=None, comm=None, *, device: int = 0, ksp_type: KSPType = KSPType.GMRES,
                  ksp_rtol: float | None = None, restart: int = 1000, ksp_max_it: int = 4000, ilu_levels: int | None = None,
-                 ilu_shift: float = 0.0, ordering: str = "rcm", seed: int = 0, layout: str = "single") -> None:
+                 ilu_shift: float = 0.0, ordering: str = "rcm", seed: int = 0, layout: str = "single",
+                 project_out: np.ndarray | None = None) -> None:
         if M is not None and A is None:
             raise ValueError("Cannot set right-hand operator M without left-hand operator A.")
         self._A = self._M = None
@@ -308,6 +309,9 @@ class iEpsSolver:
         if layout not in ("single", "sharded"):
             raise ValueError("layout must be 'single' or 'sharded'")
         self._layout = layout  # 'sharded': rows of (A, M) and the ILU split over the ranks of torch.distributed
+        # dof indices zeroed on both sides of every operator apply (the velocity-subspace projection of
+        # ``ArpackEigenSolver``, reference ``Solver/eigen2.py:164-201``)
+        self._project_out = None if project_out is None else np.unique(np.asarray(project_out, dtype=np.int64))
         self._eigenvalues = np.zeros(0, dtype=np.complex128)
         self._eigenvectors = np.zeros((0, 0), dtype=np.complex128)
         self._residual_estimates = np.zeros(0)
@@ -476,7 +480,16 @@ class iEpsSolver:
                 A_diag=prep["dAd"], M_diag=prep["dMd"],
             )
             part = prep["part"]
-            mask = None if part is None else part.pad_vector(np.ones(n))
+            keep = None
+            if self._project_out is not None:
+                if self._project_out.size and (self._project_out[0] < 0 or self._project_out[-1] >= n):
+                    raise ValueError("project_out holds dof indices outside [0, n)")
+                keep = np.ones(n)
+                keep[self._project_out] = 0.0
+                keep = keep[perm]  # the iteration runs in permuted numbering
+            mask = keep if part is None else part.pad_vector(np.ones(n) if keep is None else keep)
+            if keep is not None:
+                op.set_projection(mask)
             basis = lsa_hip.KrylovBasis(ctx, op, ncv, mask)
             if sinvert:
                 theta_key = lambda th: lam_key(sigma + 1.0 / np.where(th == 0, np.finfo(float).tiny, th))  # noqa: E731

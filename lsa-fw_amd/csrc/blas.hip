@@ -331,6 +331,19 @@ int k_nrm2(lsa_ctx* ctx, int dtype, int64_t n, const void* x, double* nrm2_dev) 
     return check_launch(ctx, "nrm2");
 }
 
+template <typename T>
+__global__ void mask_mul_kernel(int64_t n, const double* __restrict__ keep, T* __restrict__ y) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        if (keep[i] == 0.0) y[i] = scalar_traits<T>::zero();
+}
+
+// y[i] = 0 where keep[i] == 0
+int k_mask(lsa_ctx* ctx, int dtype, int64_t n, const double* keep_dev, void* y) {
+    DISPATCH_T(dtype, { hipLaunchKernelGGL((mask_mul_kernel<T>), dim3(stream_blocks(ctx, n)), dim3(kThreads), 0, ctx->stream, n, keep_dev, (T*)y); });
+    return check_launch(ctx, "mask");
+}
+
 // w = b - z;  nrm2_dev[0] = ||w||^2,  nrm2_dev[1] = ||b||^2  (fixed-order two-stage sums)
 int k_residual_norms(lsa_ctx* ctx, int dtype, int64_t n, const void* b, const void* z, void* w, double* nrm2_dev) {
     const int blocks = stream_blocks(ctx, n);

@@ -159,6 +159,7 @@ int k_multi_axpy(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64
                  double* nrm2_dev);
 // nrm2_dev[0] = ||x||^2
 int k_nrm2(lsa_ctx* ctx, int dtype, int64_t n, const void* x, double* nrm2_dev);
+int k_mask(lsa_ctx* ctx, int dtype, int64_t n, const double* keep_dev, void* y);
 int k_residual_norms(lsa_ctx* ctx, int dtype, int64_t n, const void* b, const void* z, void* w, double* nrm2_dev);
 // y = x / sqrt(nrm2_dev[0])   (no host round trip)
 int k_scale_by_inv_norm(lsa_ctx* ctx, int dtype, int64_t n, const void* x, const double* nrm2_dev, void* y);

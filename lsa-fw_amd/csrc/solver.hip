@@ -347,6 +347,7 @@ struct lsa_op {
     GmresWork gw;
     bool gw_ready;
     void* t;  // device temp vector (complex)
+    double* keep = nullptr;  // device 0/1 mask of the projected operator (lsa_op_set_projection), or null
     lsa_stats st;
 };
 
@@ -511,6 +512,7 @@ void lsa_op_destroy(lsa_op* op) {
     if (op->owned_diag) lsa_mat_destroy(op->owned_diag);
     if (op->gw_ready) op->gw.release();
     if (op->t) (void)hipFree(op->t);
+    if (op->keep) (void)hipFree(op->keep);
     delete op;
 }
 
@@ -527,6 +529,7 @@ static int op_apply_dev(lsa_ctx* ctx, lsa_op* op, const void* x, void* y) {
     }
     if (!op->Kfac) {
         if (!op->Kmul) LSA_CHECK(k_copy(ctx, dtype, op->n, x, y));
+        if (op->keep) LSA_CHECK(k_mask(ctx, dtype, op->n, op->keep, y));
         return LSA_OK;
     }
     if (!op->gw_ready) {
@@ -539,8 +542,25 @@ static int op_apply_dev(lsa_ctx* ctx, lsa_op* op, const void* x, void* y) {
     PcRef pcr;
     pcr.ilu = op->pc;
     pcr.blu = op->blu;
-    return gmres_run(ctx, op->Kfac, pcr, dtype, rhs, y, false, op->opts.ksp_rtol, op->opts.ksp_maxit, op->gw, nullptr, nullptr,
-                     &op->st);
+    LSA_CHECK(gmres_run(ctx, op->Kfac, pcr, dtype, rhs, y, false, op->opts.ksp_rtol, op->opts.ksp_maxit, op->gw, nullptr, nullptr, &op->st));
+    if (op->keep) LSA_CHECK(k_mask(ctx, dtype, op->n, op->keep, y));
+    return LSA_OK;
+}
+
+int lsa_op_set_projection(lsa_ctx* ctx, lsa_op* op, const double* keep) {
+    if (!ctx || !op) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_set_projection: null argument");
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (!keep) {
+        if (op->keep) (void)hipFree(op->keep);
+        op->keep = nullptr;
+        return LSA_OK;
+    }
+    for (int64_t i = 0; i < op->n; ++i)
+        if (keep[i] != 0.0 && keep[i] != 1.0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_set_projection: keep[%lld] is neither 0 nor 1", (long long)i);
+    const size_t bytes = sizeof(double) * (size_t)std::max<int64_t>(op->n, 1);
+    if (!op->keep) LSA_HIP_CHECK(ctx, hipMalloc((void**)&op->keep, bytes));
+    LSA_HIP_CHECK(ctx, hipMemcpy(op->keep, keep, sizeof(double) * (size_t)op->n, hipMemcpyHostToDevice));
+    return LSA_OK;
 }
 
 int lsa_op_apply(lsa_ctx* ctx, lsa_op* op, const lsa_vec* x, lsa_vec* y) {

@@ -101,6 +101,7 @@ SIGNATURES = {
     "lsa_op_destroy": (None, [_P]),
     "lsa_op_apply": (ctypes.c_int, [_P, _P, _P, _P]),
     "lsa_op_stats": (ctypes.c_int, [_P, ctypes.POINTER(lsa_stats)]),
+    "lsa_op_set_projection": (ctypes.c_int, [_P, _P, _P]),
     "lsa_krylov_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
     "lsa_krylov_destroy": (None, [_P]),
     "lsa_krylov_set_start": (ctypes.c_int, [_P, _P, _P]),
@@ -433,6 +434,16 @@ class ShiftInvertOperator:
 
     def apply(self, x: DeviceVector, y: DeviceVector) -> None:
         self.ctx.check(self.ctx._lib.lsa_op_apply(self.ctx.handle, self.handle, x.handle, y.handle))
+
+    def set_projection(self, keep: np.ndarray | None) -> None:
+        """Projected operator ``y = P Kfac^-1 Kmul x``, ``P = diag(keep)`` with 0/1 entries (``None`` removes it)."""
+        if keep is None:
+            self.ctx.check(self.ctx._lib.lsa_op_set_projection(self.ctx.handle, self.handle, None))
+            return
+        keep = np.ascontiguousarray(keep, dtype=np.float64)
+        if keep.shape != (self.n,):
+            raise ValueError(f"projection mask must have shape ({self.n},)")
+        self.ctx.check(self.ctx._lib.lsa_op_set_projection(self.ctx.handle, self.handle, _ptr(keep)))
 
     def stats(self) -> dict:
         st = lsa_stats()

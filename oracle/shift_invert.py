@@ -42,8 +42,11 @@ def compute_residuals(A, M, lam: np.ndarray, V: np.ndarray) -> np.ndarray:
 
 
 def solve(A, M, sigma: complex, k: int = 20, *, tol: float = 1e-12, ncv: int | None = None, maxiter: int = 500,
-          v0: np.ndarray | None = None, return_info: bool = False):
-    """k eigenpairs of A x = lam M x nearest sigma.  Returns (lam, V, residuals), nearest first, unit 2-norm vectors."""
+          v0: np.ndarray | None = None, return_info: bool = False, project_out: np.ndarray | None = None):
+    """k eigenpairs of A x = lam M x nearest sigma.  Returns (lam, V, residuals), nearest first, unit 2-norm vectors.
+
+    ``project_out``: dof indices zeroed before and after every operator apply -- the velocity-subspace operator of
+    ``Solver/eigen2.py:164-201`` (``x[dofs_p] = 0``; ``M x``; solve; ``y[dofs_p] = 0``)."""
     n = A.shape[0]
     A = sp.csr_matrix(A).astype(np.complex128)
     Mc = None if M is None else sp.csr_matrix(M).astype(np.complex128)
@@ -55,7 +58,13 @@ def solve(A, M, sigma: complex, k: int = 20, *, tol: float = 1e-12, ncv: int | N
 
     def op(x):
         applies[0] += 1
-        return lu.solve(Mc @ x if Mc is not None else x)
+        if project_out is not None:
+            x = x.copy()
+            x[project_out] = 0.0
+        y = lu.solve(Mc @ x if Mc is not None else x)
+        if project_out is not None:
+            y[project_out] = 0.0
+        return y
 
     lop = spla.LinearOperator((n, n), matvec=op, dtype=np.complex128)
     ncv = ncv if ncv is not None else max(4 * k, 40)

@@ -185,3 +185,21 @@ def test_ilu_with_full_fill_is_lu(small_pair):
     assert p0.nnz == Cp.nnz and p1.nnz > p0.nnz
     with pytest.raises(ZeroDivisionError):
         kernels.ILU0(sp.csr_matrix((np.array([0.0, 1.0, 1.0, 0.0]), np.array([0, 1, 0, 1]), np.array([0, 2, 4])), shape=(2, 2)), 0.0)
+
+
+def test_projected_operator_of_eigen2_keeps_the_spectrum():
+    """``Solver/eigen2.py:164-201`` zeroes the pressure dofs around every apply; M has no pressure columns, so the
+    non-zero spectrum is that of the full problem and the vectors are the velocity parts."""
+    from oracle import fem, shift_invert
+
+    es = fem.cylinder_case("S2k")
+    sigma = fem.SIGMA_RE50
+    full, Vf, _ = shift_invert.solve(es.A, es.M, sigma, k=4, tol=1e-13, ncv=40)
+    proj, Vp, _ = shift_invert.solve(es.A, es.M, sigma, k=4, tol=1e-13, ncv=40, project_out=es.dofs_p)
+    for r in full:
+        assert np.min(np.abs(proj - r)) <= 1e-9 * abs(r)
+    assert np.abs(Vp[es.dofs_p, :]).max() <= 1e-14
+    j = int(np.argmin(np.abs(proj - full[0])))
+    vu = Vf[:, 0].copy()
+    vu[es.dofs_p] = 0.0
+    assert abs(abs(np.vdot(vu, Vp[:, j])) / np.linalg.norm(vu) - 1.0) <= 1e-8

@@ -139,12 +139,14 @@ typedef struct {
     int32_t ksp_restart;  /* GMRES restart length                                            */
     int32_t ksp_maxit;    /* GMRES iteration cap                                             */
     int32_t pc_type;      /* 0 = none, 1 = ILU(k), 2 = exact block LU (falls back to ILU(k) if the band does not fit) */
+    double antishift[2];  /* mode 2 only: nu of the Cayley transform (re, im); SLEPc's default is nu = sigma */
 } lsa_op_options;
 
 /* Builds C = A - sigma*M (complex if sigma has an imaginary part or A/M are complex), factors it, and
  * allocates the inner-solver workspace.  M may be NULL (standard problem, M = I).
  * mode: 0 = shift-invert  y = (A - sigma M)^-1 M x     (iSTType.SINVERT)
- *       1 = shift         y = M^-1 (A - sigma M) x     (iSTType.SHIFT; needs M = NULL here, then y = (A - sigma I) x) */
+ *       1 = shift         y = M^-1 (A - sigma M) x     (iSTType.SHIFT; needs M = NULL here, then y = (A - sigma I) x)
+ *       2 = Cayley        y = (A - sigma M)^-1 (A + nu M) x   (iSTType.CAYLEY, nu = opts->antishift) */
 int lsa_op_create(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, const double sigma[2], int mode,
                   const lsa_op_options *opts, lsa_op **out);
 void lsa_op_destroy(lsa_op *op);

@@ -300,6 +300,7 @@ class iEpsSolver:
         self._target: complex = 0.0
         self._interval = None
         self._st_type = iSTType.SHIFT
+        self._antishift: complex | None = None
         self._pc_type = PreconditionerType.LU  # SLEPc's default for the ST's KSP is preonly + LU
         self._ksp_type = ksp_type
         self._ksp_rtol, self._restart_len, self._ksp_max_it = ksp_rtol, restart, ksp_max_it
@@ -355,6 +356,11 @@ class iEpsSolver:
     def set_st_type(self, st_type: iSTType) -> None:
         self._st_type = st_type
 
+    def set_st_antishift(self, nu: float | complex | None) -> None:
+        """Antishift of the Cayley transform ``(A - sigma M)^-1 (A + nu M)`` (``STCayleySetAntishift``; build-only:
+        the reference never sets it, SLEPc then uses ``nu = sigma``)."""
+        self._antishift = nu
+
     def set_st_pc_type(self, pc_type: PreconditionerType) -> None:
         self._pc_type = PreconditionerType(pc_type)
 
@@ -375,7 +381,7 @@ class iEpsSolver:
 
     def _signature(self):
         return (id(self._A), id(self._M), self._st_type, self._target, self._pc_type, self._ilu_levels, self._ordering, self._device,
-                self._layout)
+                self._layout)  # (the antishift only changes the multiplied matrix, built per solve)
 
     def prepare(self) -> None:
         """Host-side analysis + upload: shared pattern, fill-reducing / pivot-safe ordering, CSR -> HBM.
@@ -386,15 +392,16 @@ class iEpsSolver:
 
         if self._A is None:
             raise ValueError("Operators are not set.")
-        if self._st_type not in (iSTType.SHIFT, iSTType.SINVERT):
-            raise NotImplementedError(f"Spectral transformation {self._st_type.name} is not available on the HIP path.")
         if getattr(self, "_prepared", None) is not None and self._prepared["sig"] == self._signature():
             return
         self.release()
         A = self._A.as_scipy_array()
         M = None if self._M is None else self._M.as_scipy_array()
         n = A.shape[0]
-        sinvert = self._st_type is iSTType.SINVERT
+        if self._st_type not in (iSTType.SHIFT, iSTType.SINVERT, iSTType.CAYLEY):
+            raise NotImplementedError(f"spectral transformation {self._st_type.name} is not available on the HIP path "
+                                      "(SHIFT, SINVERT and CAYLEY are)")
+        sinvert = self._st_type in (iSTType.SINVERT, iSTType.CAYLEY)  # both factorise A - sigma M
         sigma = self._target if sinvert else 0.0
         # one shared sparsity pattern for A and M (explicit zeros where only the other matrix has an entry)
         if M is not None and (A.nnz != M.nnz or not (np.array_equal(A.indptr, M.indptr) and np.array_equal(A.indices, M.indices))):
@@ -438,7 +445,8 @@ class iEpsSolver:
             dA = lsa_hip.CsrMatrix.from_scipy(ctx, Ap)
             dM = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, Mp)
         self._prepared = {"sig": self._signature(), "ctx": ctx, "dA": dA, "dM": dM, "dAd": dAd, "dMd": dMd, "part": part, "perm": perm,
-                          "n": n, "sinvert": sinvert, "sigma": sigma, "pc_code": pc_code, "levels": levels}
+                          "n": n, "sinvert": sinvert, "cayley": self._st_type is iSTType.CAYLEY, "sigma": sigma, "pc_code": pc_code,
+                          "levels": levels}
 
     def release(self) -> None:
         """Free the device copies made by :meth:`prepare`."""
@@ -469,13 +477,16 @@ class iEpsSolver:
         ctx, n, sinvert, sigma, perm = prep["ctx"], prep["n"], prep["sinvert"], prep["sigma"], prep["perm"]
         ncv = min(self._ncv if self._ncv is not None else max(2 * self._nev, self._nev + 15), n)
         nev = min(self._nev, ncv)
+        cayley = prep["cayley"]
+        nu = complex(sigma if self._antishift is None else self._antishift)  # STCayleySetAntishift defaults to the shift
         which = self._which or (iEpsWhich.TARGET_MAGNITUDE if sinvert else iEpsWhich.LARGEST_MAGNITUDE)
         lam_key = _lambda_rank_key(which, self._target)
         ksp_rtol = self._ksp_rtol if self._ksp_rtol is not None else float(np.clip(self._tol * 1e-2, 1e-13, 1e-8))
         op = basis = None
         try:
             op = lsa_hip.ShiftInvertOperator(
-                ctx, prep["dA"], prep["dM"], sigma, mode=0 if sinvert else 1, ilu_levels=prep["levels"], ilu_shift=self._ilu_shift,
+                ctx, prep["dA"], prep["dM"], sigma, mode=2 if cayley else 0 if sinvert else 1, antishift=nu, ilu_levels=prep["levels"],
+                ilu_shift=self._ilu_shift,
                 ksp_rtol=ksp_rtol, ksp_restart=_restart_length(self._restart_len, n), ksp_maxit=self._ksp_max_it, pc_type=prep["pc_code"],
                 A_diag=prep["dAd"], M_diag=prep["dMd"],
             )
@@ -491,13 +502,17 @@ class iEpsSolver:
             if keep is not None:
                 op.set_projection(mask)
             basis = lsa_hip.KrylovBasis(ctx, op, ncv, mask)
-            if sinvert:
-                theta_key = lambda th: lam_key(sigma + 1.0 / np.where(th == 0, np.finfo(float).tiny, th))  # noqa: E731
+            tiny = np.finfo(float).tiny
+            if cayley:  # theta = (lambda + nu) / (lambda - sigma)
+                back = lambda th: (sigma * th + nu) / np.where(th == 1.0, 1.0 + 1e-300, th - 1.0)  # noqa: E731
+            elif sinvert:  # theta = 1 / (lambda - sigma)
+                back = lambda th: sigma + 1.0 / np.where(th == 0, tiny, th)  # noqa: E731
             else:
-                theta_key = lambda th: lam_key(th + sigma)  # noqa: E731
+                back = lambda th: th + sigma  # noqa: E731
+            theta_key = lambda th: lam_key(back(np.asarray(th, dtype=np.complex128)))  # noqa: E731
             res = krylov_schur(basis, nev, self._tol, self._max_it, theta_key, rng_seed=self._seed)
             theta = res.theta
-            lam = sigma + 1.0 / theta if sinvert else theta + sigma
+            lam = back(np.asarray(theta, dtype=np.complex128))
             vecs = res.vectors if part is None else part.unpad_vector(res.vectors)
             X = np.empty_like(vecs)
             X[perm, :] = vecs

@@ -334,12 +334,15 @@ __global__ void shift_diag_kernel(int32_t n, int32_t row0, const int32_t* __rest
 }  // namespace
 
 // ---- objects ------------------------------------------------------------------------------------------------------
+static_assert(sizeof(lsa_op_options) == 56, "lsa_op_options layout is part of the C-ABI (tests/test_abi.py)");
+
 struct lsa_op {
     lsa_ctx* ctx;
     int64_t n;
     const lsa_mat* Kmul;  // y = Kfac^-1 (Kmul x); either may be null (identity)
     const lsa_mat* Kfac;
     lsa_mat* owned;       // the matrix built here (C = A - sigma M), destroyed with the operator
+    lsa_mat* owned_mul = nullptr;  // Cayley: A + nu M
     lsa_mat* owned_diag;  // sharded layout: this rank's diagonal block of C (input of the block-Jacobi ILU)
     lsa_ilu* pc;
     lsa_blu* blu;         // exact block LU (opts.pc_type == 2)
@@ -417,7 +420,7 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
     const bool sharded = Ad != nullptr;
     if (!sharded && A->n != A->ncols) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: A must be square (got %d x %d)", A->n, A->ncols);
     if (M && (M->n != A->n || M->ncols != A->ncols || M->row0 != A->row0)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: M does not match A's shape");
-    if (mode != 0 && mode != 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: mode must be 0 (sinvert) or 1 (shift)");
+    if (mode < 0 || mode > 2) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: mode must be 0 (sinvert), 1 (shift) or 2 (Cayley)");
     if (sharded) {
         if (Ad->n != Ad->ncols || Ad->n != A->n || (Md && (Md->n != Ad->n || Md->ncols != Ad->ncols)) || (M != nullptr) != (Md != nullptr))
             return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create_sharded: diagonal blocks must be square with the shard's row count");
@@ -450,9 +453,19 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
         op->owned = C;
     }
     const lsa_mat* fac_src = nullptr;  // the square matrix the preconditioner is built from
-    if (mode == 0) {
+    if (mode == 0 || mode == 2) {
         op->Kfac = C;
         op->Kmul = M;
+        if (mode == 2) {  // Cayley: multiply by A + nu M = A - (-nu) M
+            const double mnu[2] = {-opts->antishift[0], -opts->antishift[1]};
+            const bool cmul = cdt || opts->antishift[1] != 0.0;
+            rc = build_shifted(ctx, A, M, mnu, cmul, &op->owned_mul);
+            if (rc != LSA_OK) {
+                lsa_op_destroy(op);
+                return rc;
+            }
+            op->Kmul = op->owned_mul;
+        }
         if (sharded) {
             rc = build_shifted(ctx, Ad, Md, sigma, cdt, &op->owned_diag);
             if (rc != LSA_OK) {
@@ -509,6 +522,7 @@ void lsa_op_destroy(lsa_op* op) {
     if (op->pc) lsa_ilu_destroy(op->pc);
     if (op->blu) lsa_blu_destroy(op->blu);
     if (op->owned) lsa_mat_destroy(op->owned);
+    if (op->owned_mul) lsa_mat_destroy(op->owned_mul);
     if (op->owned_diag) lsa_mat_destroy(op->owned_diag);
     if (op->gw_ready) op->gw.release();
     if (op->t) (void)hipFree(op->t);

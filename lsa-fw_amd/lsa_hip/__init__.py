@@ -58,6 +58,7 @@ class lsa_op_options(ctypes.Structure):
         ("ksp_restart", ctypes.c_int32),
         ("ksp_maxit", ctypes.c_int32),
         ("pc_type", ctypes.c_int32),
+        ("antishift", ctypes.c_double * 2),
     ]
 
 
@@ -408,16 +409,20 @@ def gmres(ctx: Context, C: CsrMatrix, pc: Ilu | None, b: DeviceVector, x: Device
 
 
 class ShiftInvertOperator:
-    """``y = (A - sigma M)^-1 M x`` (mode 0, iSTType.SINVERT) or ``y = M^-1 (A - sigma M) x`` (mode 1, iSTType.SHIFT)."""
+    """``y = (A - sigma M)^-1 M x`` (mode 0, iSTType.SINVERT), ``y = M^-1 (A - sigma M) x`` (mode 1, iSTType.SHIFT) or
+    ``y = (A - sigma M)^-1 (A + nu M) x`` (mode 2, iSTType.CAYLEY with antishift ``nu``)."""
 
-    def __init__(self, ctx: Context, A: CsrMatrix, M: CsrMatrix | None, sigma: complex, *, mode: int = 0, ilu_levels: int = 0,
+    def __init__(self, ctx: Context, A: CsrMatrix, M: CsrMatrix | None, sigma: complex, *, mode: int = 0, antishift: complex = 0.0,
+                 ilu_levels: int = 0,
                  ilu_shift: float = 0.0, ksp_rtol: float = 1e-11, ksp_restart: int = 200, ksp_maxit: int = 2000, pc_type: int = 1,
                  A_diag: CsrMatrix | None = None, M_diag: CsrMatrix | None = None):
         """With ``A_diag`` (and ``M_diag``) given, ``A`` / ``M`` are this rank's row shards in the padded block layout
         (:mod:`lsa_hip.sharding`) and the preconditioner is block-Jacobi ILU(k) over ranks."""
         self.ctx, self._A, self._M, self._Ad, self._Md = ctx, A, M, A_diag, M_diag
         sigma = complex(sigma)
-        opts = lsa_op_options(int(ilu_levels), float(ilu_shift), float(ksp_rtol), int(ksp_restart), int(ksp_maxit), int(pc_type))
+        antishift = complex(antishift)
+        opts = lsa_op_options(int(ilu_levels), float(ilu_shift), float(ksp_rtol), int(ksp_restart), int(ksp_maxit), int(pc_type),
+                              (_DBL * 2)(antishift.real, antishift.imag))
         h = ctypes.c_void_p()
         sig = (_DBL * 2)(sigma.real, sigma.imag)
         if A_diag is None:

@@ -269,3 +269,36 @@ def test_reynolds_sweep_harness(tmp_path, monkeypatch):
         es = fem.cylinder_case("S2k", re=float(re))
         ref, _, _ = shift_invert.solve(es.A, es.M, target, k=1, tol=1e-12)
         assert abs(got - ref[0]) <= 1e-3 * abs(ref[0]) * 10  # the harness runs at the reference's atol = 1e-3
+
+
+def test_cayley_transform_matches_shift_invert():
+    """iSTType.CAYLEY: OP = (A - sigma M)^-1 (A + nu M), theta = (lambda + nu) / (lambda - sigma); the eigenvalues nearest
+    the target are those of shift-invert, for SLEPc's default antishift (nu = sigma) and for an explicit one."""
+    from oracle import fem, shift_invert
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    es = fem.cylinder_case("S2k")
+    sigma = fem.SIGMA_RE50
+    ref, _, _ = shift_invert.solve(es.A, es.M, sigma, k=6, tol=1e-13, ncv=40)
+    for nu in (None, 0.3 - 0.2j):
+        solver = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=6, atol=1e-10, ncv=40), check_hermitian=False)
+        solver.solver.set_st_type(iSTType.CAYLEY)
+        solver.solver.set_st_antishift(nu)
+        solver.solver.set_target(sigma)
+        solver.solver.set_st_pc_type(PreconditionerType.LU)
+        lam = np.array([p[0] for p in solver.solve()])
+        assert len(lam) == 6
+        for r in ref:
+            assert np.min(np.abs(lam - r)) <= 1e-8 * abs(r)
+        assert solver.solver.residuals().max() <= 1e-8
+
+
+def test_unsupported_spectral_transformations_fail_loudly():
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import iSTType
+
+    solver = EigenSolver(np.diag([1.0, 2.0, 3.0, 4.0]), None, EigensolverConfig(num_eig=1))
+    solver.solver.set_st_type(iSTType.FILTER)
+    with pytest.raises(NotImplementedError, match="FILTER"):
+        solver.solve()

@@ -35,6 +35,14 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path[:0] = [str(ROOT), str(ROOT / "lsa-fw_amd")]
 
+# Host BLAS on one thread (unless the caller chose otherwise).  Measured on the GPU box (tools/micro/after_solve.py,
+# DESIGN.md section 6): numpy's 64 OpenBLAS workers keep spinning for ~0.1 s after any threaded call (a 30k-entry norm
+# is enough); on the 16-core share of a one-GPU box that starves the HIP runtime's helper thread and the next
+# factorisation's 3 900 dependent launches take 88-144 ms instead of 66.  It also is the honest setting for the CPU
+# baseline: single-threaded SuperLU/ARPACK ran 5x FASTER with one BLAS thread than with 64 (6 s vs 30 s per solve).
+for _var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_var, "1")
+
 import numpy as np  # noqa: E402
 import scipy.sparse as sp  # noqa: E402
 
@@ -138,7 +146,8 @@ def cpu_baseline(es, sigma, args):
         "value": nconv / dt, "unit": "eigenpairs/s", "cores": 1, "kind": "port",
         "sample": f"one full solve of the same {args.case} problem (k={args.k}, ncv={args.ncv}, tol={args.atol:g}): {dt:.1f} s "
                   f"(SuperLU factor {info['seconds_factor']:.1f} s, {info['op_applies']} applies), scipy ARPACK+SuperLU, "
-                  f"single-threaded; host has {os.cpu_count()} cores; SLEPc itself is not installed",
+                  f"one thread (BLAS threads = {os.environ.get('OPENBLAS_NUM_THREADS')}); host has {os.cpu_count()} cores; "
+                  f"SLEPc itself is not installed",
     }, lam
 
 
@@ -203,10 +212,14 @@ def main() -> None:
         solver.solve()
     barrier()
     t0 = time.perf_counter()
+    step_marks = [t0]
     for _ in range(args.steps):
         solver.solve()
+        step_marks.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
+    log("seconds per step: " + " ".join(f"{b - a:.3f}" for a, b in zip(step_marks[:-1], step_marks[1:]))
+        + f"; last solve: factor {solver.solver.stats.get('seconds_factor', 0.0):.3f} s, Arnoldi {solver.solver.stats.get('seconds_solve', 0.0):.3f} s")
     # count pairs that pass the true residual test (device evaluation, after the timed region)
     res = solver.solver.residuals()
     nconv = int(np.sum(res[: args.k] <= RESIDUAL_TOL))

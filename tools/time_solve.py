@@ -17,7 +17,14 @@ from Solver.utils import PreconditionerType, iSTType  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--case", default="S30k")
 ap.add_argument("--pc", default="lu")
+ap.add_argument("--torch", action="store_true", help="initialise PyTorch's HIP context first, as bench.py does")
 args = ap.parse_args()
+if args.torch:
+    import torch
+
+    torch.cuda.set_device(0)
+    torch.cuda.synchronize()
+    print("torch initialised; threads", torch.get_num_threads())
 es = fem.cylinder_case(args.case)
 cfg = EigensolverConfig(num_eig=20, atol=1e-10, ncv=80, max_it=500)
 pc = PreconditionerType.LU if args.pc == "lu" else PreconditionerType.ILU
@@ -28,11 +35,15 @@ inner.set_target(fem.SIGMA_RE50)
 inner.set_st_pc_type(pc)
 inner.prepare()
 inner.solve()
+for _ in range(3):
+    t0 = time.time()
+    inner.solve()
+    print(f"warm solve {time.time() - t0:.3f} s  factor {inner.stats['seconds_factor']:.3f} solve {inner.stats['seconds_solve']:.3f}")
 t0 = time.time()
-inner.solve()
-print(f"warm solve {time.time() - t0:.3f} s  stats={inner.stats}")
+solver.solve()
+print(f"warm EigenSolver.solve() {time.time() - t0:.3f} s")
 pr = cProfile.Profile()
 pr.enable()
-inner.solve()
+solver.solve()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(28)

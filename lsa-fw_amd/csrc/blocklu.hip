@@ -39,6 +39,7 @@ struct lsa_blu {
     void *in[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr};
     void* graph[2] = {nullptr, nullptr};
     double seconds = 0.0;
+    std::vector<int32_t> uwin_lo, lwin_hi;  // per block: first row with entries right of the block / end of the rows with entries left of it
     uint64_t pattern_hash = 0;  // of C's host row pointers and column indices (key of the per-context cache)
     int64_t nnz = 0;
 };
@@ -547,22 +548,29 @@ __global__ void gj_unpivot_serial_kernel(T* __restrict__ a, int32_t ld, int32_t 
 // launches and each launch moves twice the bytes; a chain that has run out passes an empty range.
 struct BluRange {
     int32_t bs, be;  // rows [bs, be) of one diagonal block
-    int32_t mode;    // sparse kernel: 1 = entries left of the block, 2 = right of it, 3 = both
+    int32_t mode;    // sparse kernel: 1 = entries left of the block, 2 = right of it, 3 = both; +4 = window form
+    int32_t cs, ce;  // window form (substitution sweep): only rows [cs, ce) of the block couple to the neighbour, so the
+                     // sparse kernel forms u = C_{b,b+-1} x there and the dense kernel needs only those COLUMNS of Sinv_b
 };
 
-// out[r] = rhs[r] - sum over the selected off-block entries of row r of val * x[col]; 16 lanes per row
+// rows the sparse kernel visits for one range
+__host__ __device__ inline int32_t blu_rows(const BluRange& r) { return (r.mode & 4) ? r.ce - r.cs : r.be - r.bs; }
+
+// out[r] = rhs[r] - sum over the selected off-block entries of row r of val * x[col]  (window form: out[r] = + the sum,
+// rows [cs, ce) only); 16 lanes per row
 template <typename MT, typename VT>
 __global__ __launch_bounds__(256) void blu_sparse_kernel(BluRange ra, BluRange rb, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                          const int32_t* __restrict__ lsplit, const int32_t* __restrict__ usplit,
                                                          const MT* __restrict__ val, const VT* __restrict__ rhs, const VT* __restrict__ x,
                                                          VT* __restrict__ out) {
-    const int32_t ga = ((ra.be - ra.bs) * 16 + 255) / 256;
+    const int32_t ga = ((blu_rows(ra)) * 16 + 255) / 256;
     const bool second = (int32_t)blockIdx.x >= ga;
     const BluRange rg = second ? rb : ra;
+    const bool window = (rg.mode & 4) != 0;
     const int32_t gid = ((int32_t)blockIdx.x - (second ? ga : 0)) * 256 + threadIdx.x;
     const int lane = gid & 15;
-    const int32_t r = rg.bs + (gid >> 4);
-    if (r >= rg.be) return;
+    const int32_t r = (window ? rg.cs : rg.bs) + (gid >> 4);
+    if (r >= (window ? rg.ce : rg.be)) return;
     VT acc = scalar_traits<VT>::zero();
     if (rg.mode & 1)
         for (int32_t p = rp[r] + lane; p < lsplit[r]; p += 16) fma_acc(acc, val[p], x[ci[p]]);
@@ -577,16 +585,19 @@ __global__ __launch_bounds__(256) void blu_sparse_kernel(BluRange ra, BluRange r
             acc += __shfl_xor(acc, s, 64);
         }
     }
-    if (lane == 0) out[r] = s_sub(rhs[r], acc);
+    if (lane == 0) out[r] = window ? acc : s_sub(rhs[r], acc);
 }
 
 // out[r] = sum_s Sinv[r, s] in[s] over the whole diagonal block; one wavefront per row, 8 loads in flight per lane
 template <typename MT, typename VT>
 __global__ __launch_bounds__(256) void blu_dense_kernel(BluRange ra, BluRange rb, int32_t ld, const MT* __restrict__ sinv,
-                                                        const VT* __restrict__ in, VT* __restrict__ out) {
+                                                        const VT* __restrict__ in, const VT* __restrict__ add, VT* __restrict__ out) {
     const int32_t ga = (ra.be - ra.bs + 3) / 4;
     const bool second = (int32_t)blockIdx.x >= ga;
-    const int32_t bs = second ? rb.bs : ra.bs, be = second ? rb.be : ra.be;
+    const BluRange rg = second ? rb : ra;
+    const int32_t bs = rg.bs, be = rg.be;
+    const bool window = (rg.mode & 4) != 0;
+    const int32_t lo = window ? rg.cs : bs, hi = window ? rg.ce : be;  // columns of Sinv_b that meet a non-zero of `in`
     const int lane = threadIdx.x & 63;
     const int32_t r = bs + ((int32_t)blockIdx.x - (second ? ga : 0)) * 4 + (threadIdx.x >> 6);
     if (r >= be) return;
@@ -594,8 +605,8 @@ __global__ __launch_bounds__(256) void blu_dense_kernel(BluRange ra, BluRange rb
     VT acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = scalar_traits<VT>::zero();
-    int32_t s = bs + lane;
-    for (; s + 7 * 64 < be; s += 8 * 64) {
+    int32_t s = lo + lane;
+    for (; s + 7 * 64 < hi; s += 8 * 64) {
         MT a[8];
         VT tv[8];
 #pragma unroll
@@ -606,7 +617,7 @@ __global__ __launch_bounds__(256) void blu_dense_kernel(BluRange ra, BluRange rb
 #pragma unroll
         for (int k = 0; k < 8; ++k) fma_acc(acc[k & 3], a[k], tv[k]);
     }
-    for (; s < be; s += 64) fma_acc(acc[0], row[s], in[s]);
+    for (; s < hi; s += 64) fma_acc(acc[0], row[s], in[s]);
     VT v = s_add(s_add(acc[0], acc[1]), s_add(acc[2], acc[3]));
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) {
@@ -617,7 +628,7 @@ __global__ __launch_bounds__(256) void blu_dense_kernel(BluRange ra, BluRange rb
             v += __shfl_xor(v, m, 64);
         }
     }
-    if (lane == 0) out[r] = v;
+    if (lane == 0) out[r] = window ? s_sub(add[r], v) : v;
 }
 
 template <typename T>
@@ -737,26 +748,35 @@ int launch_apply(lsa_ctx* ctx, lsa_blu* f, const VT* v, VT* x, VT* y, VT* z, VT*
     const lsa_mat* C = f->C;
     hipStream_t st = ctx->stream;
     auto range = [&](int32_t b, int32_t mode) {
-        if (b < 0 || b >= nb) return BluRange{0, 0, 0};
-        return BluRange{b * B, std::min(n, b * B + B), mode};
+        if (b < 0 || b >= nb) return BluRange{0, 0, 0, 0, 0};
+        return BluRange{b * B, std::min(n, b * B + B), mode, 0, 0};
     };
-    auto step = [&](BluRange ra, BluRange rb, const VT* rhs, const VT* xin, VT* tmp, VT* out) {
-        const int32_t gs = ((ra.be - ra.bs) * 16 + 255) / 256 + ((rb.be - rb.bs) * 16 + 255) / 256;
+    // substitution sweep: rows of block b that couple to the block it is solved after
+    auto window = [&](int32_t b, int32_t mode) {
+        if (b < 0 || b >= nb) return BluRange{0, 0, 0, 0, 0};
+        const int32_t bs = b * B, be = std::min(n, bs + B);
+        if (mode == 2) return BluRange{bs, be, 2 | 4, f->uwin_lo[b], be};  // entries right of the block: the last rows
+        return BluRange{bs, be, 1 | 4, bs, f->lwin_hi[b]};                 // entries left of the block: the first rows
+    };
+    auto step = [&](BluRange ra, BluRange rb, const VT* rhs, const VT* xin, VT* tmp, const VT* add, VT* out) {
+        const int32_t gs = (blu_rows(ra) * 16 + 255) / 256 + (blu_rows(rb) * 16 + 255) / 256;
         const int32_t gd = (ra.be - ra.bs + 3) / 4 + (rb.be - rb.bs + 3) / 4;
-        if (gs == 0) return;
-        hipLaunchKernelGGL((blu_sparse_kernel<MT, VT>), dim3(gs), dim3(256), 0, st, ra, rb, C->rp, C->ci, f->lsplit, f->usplit, (const MT*)C->val, rhs,
-                           xin, tmp);
-        hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3(gd), dim3(256), 0, st, ra, rb, f->ld, (const MT*)f->sinv, (const VT*)tmp, out);
+        if (gd == 0) return;
+        if (gs > 0)
+            hipLaunchKernelGGL((blu_sparse_kernel<MT, VT>), dim3(gs), dim3(256), 0, st, ra, rb, C->rp, C->ci, f->lsplit, f->usplit, (const MT*)C->val,
+                               rhs, xin, tmp);
+        hipLaunchKernelGGL((blu_dense_kernel<MT, VT>), dim3(gd), dim3(256), 0, st, ra, rb, f->ld, (const MT*)f->sinv, (const VT*)tmp, add, out);
     };
     // elimination towards the middle, both chains per launch:  y_b = v_b - C_{b,b-+1} z_{b-+1},  z_b = Sinv_b y_b
     for (int32_t k = 0; k < std::max(mid, nb - 1 - mid); ++k) {
         const int32_t bt = k, bb = nb - 1 - k;
-        step(range(bt < mid ? bt : -1, 1), range(bb > mid ? bb : -1, 2), v, (const VT*)z, y, z);
+        step(range(bt < mid ? bt : -1, 1), range(bb > mid ? bb : -1, 2), v, (const VT*)z, y, nullptr, z);
     }
     // middle block: x_m = Sinv_m (v_m - C_{m,m-1} z_{m-1} - C_{m,m+1} z_{m+1})
-    step(range(mid, 3), range(-1, 0), v, (const VT*)z, t, x);
-    // substitution outwards, both chains per launch:  x_b = Sinv_b (y_b - C_{b,b+-1} x_{b+-1})
-    for (int32_t k = 1; k <= std::max(mid, nb - 1 - mid); ++k) step(range(mid - k, 2), range(mid + k, 1), (const VT*)y, (const VT*)x, t, x);
+    step(range(mid, 3), range(-1, 0), v, (const VT*)z, t, nullptr, x);
+    // substitution outwards, both chains per launch:  x_b = z_b - Sinv_b (C_{b,b+-1} x_{b+-1});  the product is non-zero
+    // only on the rows within the bandwidth of the neighbour, so only those columns of Sinv_b are read (~70 % at S30k)
+    for (int32_t k = 1; k <= std::max(mid, nb - 1 - mid); ++k) step(window(mid - k, 2), window(mid + k, 1), nullptr, (const VT*)x, t, (const VT*)z, x);
     return LSA_OK;
 }
 
@@ -868,6 +888,18 @@ static bool blu_setup(lsa_ctx* ctx, lsa_blu* f, const lsa_mat* C) {
         for (int32_t p = C->h_rp[r]; p < C->h_rp[r + 1]; ++p) ++cptr[(size_t)c[p] + 1];
     }
     for (int32_t j = 0; j < n; ++j) cptr[(size_t)j + 1] += cptr[j];
+    f->uwin_lo.assign((size_t)f->nb, 0);
+    f->lwin_hi.assign((size_t)f->nb, 0);
+    for (int32_t b = 0; b < f->nb; ++b) {
+        const int32_t bs = b * B, be = std::min(n, bs + B);
+        int32_t ulo = be, lhi = bs;
+        for (int32_t r = bs; r < be; ++r) {
+            if (us[r] < C->h_rp[r + 1]) ulo = std::min(ulo, r);
+            if (C->h_rp[r] < ls[r]) lhi = std::max(lhi, r + 1);
+        }
+        f->uwin_lo[b] = ulo;
+        f->lwin_hi[b] = lhi;
+    }
     {
         std::vector<int32_t> cur(cptr.begin(), cptr.end() - 1);
         for (int32_t r = 0; r < n; ++r)

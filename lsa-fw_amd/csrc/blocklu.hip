@@ -310,7 +310,10 @@ __global__ __launch_bounds__(NT) void gj_fused_kernel(T* __restrict__ a, int32_t
             T y[W];
 #pragma unroll
             for (int j = 0; j < W; ++j) y[j] = (j < wprev) ? Zs[yslot[j]][c] : scalar_traits<T>::zero();
-#pragma unroll 4
+            // rows in flight per thread: the panel path fixes the register allocation of the whole kernel, so the fewer
+            // waves fit a SIMD the more loads each must keep in flight (256 threads: 1 wave per SIMD, 512: 2, 1024: 4)
+            constexpr int kRowsInFlight = NT <= 256 ? 12 : NT <= 512 ? 8 : 4;
+#pragma unroll kRowsInFlight
             for (int32_t i = tid / W; i < m; i += RS) {
                 T* ai = a + (size_t)i * ld;
                 if (live) {
@@ -348,16 +351,38 @@ __global__ __launch_bounds__(NT) void gj_fused_kernel(T* __restrict__ a, int32_t
                 if (pivot_row || c >= cw || i >= m) r[q][c] = scalar_traits<T>::zero();
                 else if (sl >= 0) r[q][c] = Zs[sl][c];
             }
-            if (i < m) {
+            if constexpr (kPrefetchW) {
+                if (i < m) {
 #pragma unroll
-                for (int j = 0; j < W; ++j) {
-                    if (j < wprev) {
-                        const int ys = yslot[j];
-                        T wij;
-                        if constexpr (kPrefetchW) wij = wv[q][j];
-                        else wij = a[(size_t)i * ld + kprev + j];
+                    for (int j = 0; j < W; ++j) {
+                        if (j < wprev) {
+                            const int ys = yslot[j];
 #pragma unroll
-                        for (int c = 0; c < W; ++c) fma_acc(r[q][c], wij, Zs[ys][c]);
+                            for (int c = 0; c < W; ++c) fma_acc(r[q][c], wv[q][j], Zs[ys][c]);
+                        }
+                    }
+                }
+            }
+        }
+        if constexpr (!kPrefetchW) {
+            // many rows per thread: one column of W at a time for all of them (RPT independent loads in flight instead of
+            // a load-use chain per row), the staged pivot row read from LDS once per column instead of once per row
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                if (j < wprev) {
+                    T wj[RPT];
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) wj[q] = a[(size_t)min(tid + NT * q, m - 1) * ld + kprev + j];
+                    const int ys = yslot[j];
+                    T yj[W];
+#pragma unroll
+                    for (int c = 0; c < W; ++c) yj[c] = Zs[ys][c];
+#pragma unroll
+                    for (int q = 0; q < RPT; ++q) {
+                        if (tid + NT * q < m) {
+#pragma unroll
+                            for (int c = 0; c < W; ++c) fma_acc(r[q][c], wj[q], yj[c]);
+                        }
                     }
                 }
             }
@@ -489,6 +514,75 @@ __global__ __launch_bounds__(NT) void gj_fused_kernel(T* __restrict__ a, int32_t
             pnext[33 + myslot] = qs;
         }
         if (lane < w) pnext[50 + lane] = qs;  // where pivot row k0 + lane's new content is staged (rows k0 + l are primary)
+    }
+}
+
+// ---- blocks of more than 2048 rows: the update of the other columns as its own, row-tiled launch ------------------------
+// gj_fused_kernel's column-tile workgroups inherit the register allocation of its panel path (466 VGPRs when a thread
+// holds 12 rows: one wave per SIMD) and read 128 B per row: measured 0.75 TB/s on 151 MB blocks (S500k).  Here the
+// panel workgroup runs alone (grid = 1) and the rank-w update of all other columns streams whole rows: the <= 16 rows
+// the interchanges touch are staged first (other workgroups overwrite them), then a workgroup owns kUpdRows rows and
+// walks the columns.
+template <typename T>
+__global__ __launch_bounds__(256) void gj_stage_kernel(const T* __restrict__ a, int32_t ld, int32_t m, const int32_t* __restrict__ perm,
+                                                       T* __restrict__ Z) {
+    const int32_t q = blockIdx.y;
+    if (q >= perm[0]) return;
+    const int32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c < m) Z[(size_t)q * m + c] = a[(size_t)perm[1 + q] * ld + c];
+}
+
+// a[i, c] = base(i, c) + sum_j W[i, j] Y[j, c] for every column c outside [k0, k0 + w) and [kskip, kskip + wskip) (the
+// look-ahead tile, which the panel workgroup updates itself): Y[j, :] is the staged row perm[50 + j], base is 0 for the
+// pivot rows, the staged interchanged content for the other touched rows, a[i, c] itself elsewhere.
+constexpr int kUpdRows = 16;
+constexpr int kUpdCols = 512;  // columns per workgroup (grid.y): enough workgroups to fill 256 CUs at m = 3072
+template <typename T>
+__global__ __launch_bounds__(256) void gj_panel_update_kernel(T* __restrict__ a, int32_t ld, int32_t m, int32_t k0, int32_t w, int32_t kskip,
+                                                              int32_t wskip, const int32_t* __restrict__ perm, const T* __restrict__ Z) {
+    __shared__ T Ws[kUpdRows][kPanelW];
+    __shared__ int32_t yslot[kPanelW];   // staged row holding pivot row k0 + j
+    __shared__ int32_t rslot[kUpdRows];  // staged row holding the new content of my row r, or -1
+    const int32_t i0 = blockIdx.x * kUpdRows;
+    if (threadIdx.x < kUpdRows * kPanelW) {
+        const int r = threadIdx.x / kPanelW, j = threadIdx.x % kPanelW;
+        Ws[r][j] = (i0 + r < m && j < w) ? a[(size_t)(i0 + r) * ld + k0 + j] : scalar_traits<T>::zero();
+    }
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + kPanelW) {
+        const int j = threadIdx.x - 64;
+        yslot[j] = (j < w) ? perm[50 + j] : 0;  // W is zero beyond w; slot 0 is always valid
+    }
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + kUpdRows) {
+        const int32_t na = perm[0], row = i0 + ((int32_t)threadIdx.x - 128);
+        int32_t sl = -1;
+        for (int32_t q = 0; q < na; ++q)
+            if (perm[1 + q] == row) sl = perm[33 + q];
+        rslot[threadIdx.x - 128] = sl;
+    }
+    __syncthreads();
+    // y (the w pivot-row values of my column) stays in registers for all kUpdRows rows, so the staged rows are re-read
+    // once per kUpdRows rows of the block; W comes from LDS two rows at a time (unrolling further would hoist the whole
+    // W tile into registers: 312 VGPRs at 8 rows)
+    const int32_t cend = min(m, ((int32_t)blockIdx.y + 1) * kUpdCols);
+#pragma unroll 1
+    for (int32_t c = blockIdx.y * kUpdCols + threadIdx.x; c < cend; c += 256) {
+        if ((c >= k0 && c < k0 + w) || (c >= kskip && c < kskip + wskip)) continue;
+        T y[kPanelW];
+#pragma unroll
+        for (int j = 0; j < kPanelW; ++j) y[j] = Z[(size_t)yslot[j] * m + c];
+#pragma unroll 4
+        for (int r = 0; r < kUpdRows; ++r) {
+            const int32_t i = i0 + r;
+            if (i >= m) break;
+            T* e = a + (size_t)i * ld + c;
+            T acc;
+            if (i >= k0 && i < k0 + w) acc = scalar_traits<T>::zero();
+            else if (rslot[r] >= 0) acc = Z[(size_t)rslot[r] * m + c];
+            else acc = *e;
+#pragma unroll
+            for (int j = 0; j < kPanelW; ++j) fma_acc(acc, Ws[r][j], y[j]);
+            *e = acc;
+        }
     }
 }
 
@@ -661,7 +755,7 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
     // panel width of the blocked Gauss-Jordan = the W of the gj_fused_kernel instance used below: 8 columns while a
     // thread holds at most 4 rows, 4 columns up to 8 rows (blocks of 4096 rows); LSA_GJ_PANEL=1 selects the unblocked
     // form (two launches per pivot), which is also what larger blocks get
-    int32_t panel_w = B <= 2048 ? 8 : B <= 4096 ? 4 : 1;
+    int32_t panel_w = B <= 3072 ? 8 : B <= 4096 ? 4 : 1;
     if (const char* e = getenv("LSA_GJ_PANEL"))
         if (atoi(e) == 1) panel_w = 1;
     auto factor_block = [&](hipStream_t st, int chain, int32_t b, bool corr_left, bool corr_right) {
@@ -697,9 +791,22 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
                 else if (B <= 2048)
                     hipLaunchKernelGGL((gj_fused_kernel<T, 512, 4, 8>), grid, dim3(512), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev, pnext,
                                        f->flag, tiny2);
-                else
-                    hipLaunchKernelGGL((gj_fused_kernel<T, 512, 8, 4>), grid, dim3(512), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev, pnext,
-                                       f->flag, tiny2);
+                else {
+                    // wide blocks: the other columns first (row-tiled, full rows), then the panel workgroup alone
+                    if (pn >= 0) {
+                        hipLaunchKernelGGL((gj_stage_kernel<T>), dim3((m + 255) / 256, 2 * kPanelW), dim3(256), 0, st, (const T*)S, ld, m, pprev, ws);
+                        hipLaunchKernelGGL((gj_panel_update_kernel<T>), dim3((m + kUpdRows - 1) / kUpdRows, (m + kUpdCols - 1) / kUpdCols), dim3(256), 0, st, S, ld, m, kprev, wprev,
+                                           knext, wnext, pprev, (const T*)ws);
+                    }
+                    if (knext >= 0) {
+                        if (B <= 3072)
+                            hipLaunchKernelGGL((gj_fused_kernel<T, 256, 12, 8>), dim3(1), dim3(256), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev,
+                                               pnext, f->flag, tiny2);
+                        else
+                            hipLaunchKernelGGL((gj_fused_kernel<T, 256, 16, 4>), dim3(1), dim3(256), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev,
+                                               pnext, f->flag, tiny2);
+                    }
+                }
             }
         } else {
             for (int32_t k = 0; k < m; ++k) {

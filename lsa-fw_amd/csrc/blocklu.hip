@@ -10,10 +10,17 @@
 //
 // and only a w x w corner of every Schur complement differs from C_bb.  The Schur blocks are inverted ONCE per shift
 // into dense B x B matrices that stay in HBM (n*B scalars: 0.5 GB at S30k, 25 GB at S500k -- the 288 GB at work), by an
-// in-place Gauss-Jordan elimination with partial pivoting; the off-diagonal blocks stay the sparse rows of C.  A solve is
-// then 4 dependent launches per block (dense mat-vec + sparse update, forward and backward), replayed from a hipGraph,
-// and it is a *direct* solve (residual ~1e-15): the GMRES around it converges in one iteration and only guards accuracy.
-// Not usable when the band does not fit (3D meshes): lsa_blu_create then fails and the ILU(k) path is used.
+// in-place Gauss-Jordan elimination with partial pivoting; the off-diagonal blocks stay the sparse rows of C.
+//
+// Both the factorisation and the solve are TWISTED: one chain of blocks runs down from block 0, a second one up from
+// the last block, and they meet at the middle block, which receives both Schur corrections.  The factorisation runs
+// the two chains on two streams (one launch per panel of 8 pivot columns, gj_fused_kernel); a solve advances one
+// block of each chain per launch (2 launches per pair of blocks and sweep, replayed from a hipGraph), and its
+// substitution sweep reads only the columns of the Schur inverses that meet a non-zero.  It is a *direct* solve
+// (residual ~1e-14): the GMRES around it checks b - C x and only iterates if that check fails.
+// Not usable when the band does not fit (3D meshes) or a Schur block is singular (no pivoting across blocks):
+// lsa_blu_create then fails and the ILU(k) path is used.  A destroyed factorisation parks its buffers and symbolic
+// data in the context for the next shift of the same pattern.
 #include <algorithm>
 #include <chrono>
 

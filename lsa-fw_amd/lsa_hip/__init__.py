@@ -159,11 +159,35 @@ def _np_dtype(code: int):
     return np.complex128 if code == LSA_C128 else np.float64
 
 
+_host_blas_limit = None
+
+
+def _calm_host_blas() -> None:
+    """Pin the host BLAS pools to one thread for the life of the process (once, when the first GPU context is made).
+
+    The GPU path is launch-bound (thousands of dependent launches per factorisation) and leans on the HIP runtime's
+    helper thread.  numpy's OpenBLAS workers spin for ~0.1 s after any threaded call; on a 16-core share of a GPU node
+    64 of them starve that thread and the next factorisation is 1.3-2x slower (``tools/micro/after_solve.py``).  The
+    host arithmetic of this path is tiny (80 x 80 Schur forms, n-vectors), so nothing is lost.  ``LSA_HOST_BLAS_THREADS``
+    overrides: an integer, or ``keep`` to leave the pools alone."""
+    global _host_blas_limit
+    want = os.environ.get("LSA_HOST_BLAS_THREADS", "1")
+    if _host_blas_limit is not None or want == "keep":
+        return
+    try:
+        from threadpoolctl import threadpool_limits
+
+        _host_blas_limit = threadpool_limits(limits=max(1, int(want)), user_api="blas")
+    except Exception:  # threadpoolctl missing or an unknown BLAS: the path still works, only slower under oversubscription
+        _host_blas_limit = False
+
+
 class Context:
     """One GPU + one HIP stream.  Not thread-safe (mirrors the single blocking ``eps.solve()`` of the reference)."""
 
     def __init__(self, device: int = 0):
         self._lib = load_library()
+        _calm_host_blas()
         h = ctypes.c_void_p()
         rc = self._lib.lsa_ctx_create(int(device), ctypes.byref(h))
         if rc != 0:

@@ -41,6 +41,10 @@ struct lsa_blu {
     int32_t* flag = nullptr;
     hipStream_t stream2 = nullptr;          // second chain of the twisted factorisation / solve
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // wide blocks (> 2048 rows): per chain a side stream for the panel workgroup, which runs beside the previous panel's
+    // bulk update, and the two events that order them
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t ev_panel[2] = {nullptr, nullptr}, ev_update[2] = {nullptr, nullptr};
     int32_t mid = 0;                        // middle block: chains run 0 .. mid-1 and nb-1 .. mid+1
     void *t[2] = {nullptr, nullptr}, *y[2] = {nullptr, nullptr}, *z[2] = {nullptr, nullptr};
     void *in[2] = {nullptr, nullptr}, *out[2] = {nullptr, nullptr};
@@ -765,6 +769,8 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
     int32_t panel_w = B <= 3072 ? 8 : B <= 4096 ? 4 : 1;
     if (const char* e = getenv("LSA_GJ_PANEL"))
         if (atoi(e) == 1) panel_w = 1;
+    // blocks of at least split_min rows use the split form (lone panel workgroup beside a row-tiled bulk update)
+    const int32_t split_min = getenv("LSA_GJ_SPLIT_MIN") ? atoi(getenv("LSA_GJ_SPLIT_MIN")) : 2049;
     auto factor_block = [&](hipStream_t st, int chain, int32_t b, bool corr_left, bool corr_right) {
         const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
         T* S = (T*)f->sinv + (size_t)bs * ld;
@@ -795,24 +801,37 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
                 if (B <= 1024)
                     hipLaunchKernelGGL((gj_fused_kernel<T, 1024, 1, 8>), grid, dim3(1024), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev, pnext,
                                        f->flag, tiny2);
-                else if (B <= 2048)
+                else if (B <= 2048 && B < split_min)
                     hipLaunchKernelGGL((gj_fused_kernel<T, 512, 4, 8>), grid, dim3(512), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev, pnext,
                                        f->flag, tiny2);
                 else {
-                    // wide blocks: the other columns first (row-tiled, full rows), then the panel workgroup alone
+                    // wide blocks: the bulk update of panel p (row-tiled, full rows) on the chain's stream, the panel
+                    // workgroup of p + 1 beside it on the side stream.  Panel p + 1 needs panel p (same stream) and the
+                    // bulk update of p - 1 (ev_update as recorded so far); the bulk update of p needs panel p (ev_panel as
+                    // recorded so far).  They touch disjoint columns and alternate interchange-list buffers.
+                    hipStream_t sd = f->side[chain];
                     if (pn >= 0) {
+                        (void)hipStreamWaitEvent(st, f->ev_panel[chain], 0);
                         hipLaunchKernelGGL((gj_stage_kernel<T>), dim3((m + 255) / 256, 2 * kPanelW), dim3(256), 0, st, (const T*)S, ld, m, pprev, ws);
-                        hipLaunchKernelGGL((gj_panel_update_kernel<T>), dim3((m + kUpdRows - 1) / kUpdRows, (m + kUpdCols - 1) / kUpdCols), dim3(256), 0, st, S, ld, m, kprev, wprev,
-                                           knext, wnext, pprev, (const T*)ws);
+                        hipLaunchKernelGGL((gj_panel_update_kernel<T>), dim3((m + kUpdRows - 1) / kUpdRows, (m + kUpdCols - 1) / kUpdCols), dim3(256), 0,
+                                           st, S, ld, m, kprev, wprev, knext, wnext, pprev, (const T*)ws);
+                    } else {
+                        (void)hipEventRecord(f->ev_update[chain], st);  // scatter and Schur corrections of this block are enqueued
                     }
                     if (knext >= 0) {
-                        if (B <= 3072)
-                            hipLaunchKernelGGL((gj_fused_kernel<T, 256, 12, 8>), dim3(1), dim3(256), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev,
+                        (void)hipStreamWaitEvent(sd, f->ev_update[chain], 0);
+                        if (B <= 2048)
+                            hipLaunchKernelGGL((gj_fused_kernel<T, 512, 4, 8>), dim3(1), dim3(512), 0, sd, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev,
+                                               pnext, f->flag, tiny2);
+                        else if (B <= 3072)
+                            hipLaunchKernelGGL((gj_fused_kernel<T, 256, 12, 8>), dim3(1), dim3(256), 0, sd, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev,
                                                pnext, f->flag, tiny2);
                         else
-                            hipLaunchKernelGGL((gj_fused_kernel<T, 256, 16, 4>), dim3(1), dim3(256), 0, st, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev,
+                            hipLaunchKernelGGL((gj_fused_kernel<T, 256, 16, 4>), dim3(1), dim3(256), 0, sd, S, ld, m, kprev, wprev, knext, wnext, ipiv, pprev,
                                                pnext, f->flag, tiny2);
+                        (void)hipEventRecord(f->ev_panel[chain], sd);
                     }
+                    if (pn >= 0) (void)hipEventRecord(f->ev_update[chain], st);
                 }
             }
         } else {
@@ -958,6 +977,12 @@ static void blu_free(lsa_blu* f) {
         if (p) (void)hipFree(p);
     if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
     if (f->ev_join) (void)hipEventDestroy(f->ev_join);
+    for (int c = 0; c < 2; ++c) {
+        if (f->side[c]) (void)hipStreamSynchronize(f->side[c]);
+        if (f->ev_panel[c]) (void)hipEventDestroy(f->ev_panel[c]);
+        if (f->ev_update[c]) (void)hipEventDestroy(f->ev_update[c]);
+        if (f->side[c]) (void)hipStreamDestroy(f->side[c]);
+    }
     if (f->stream2) (void)hipStreamDestroy(f->stream2);
     delete f;
 }
@@ -1030,6 +1055,12 @@ static bool blu_setup(lsa_ctx* ctx, lsa_blu* f, const lsa_mat* C) {
               hipMalloc((void**)&f->ipiv[0], 4 * (2 * (size_t)B + 128)) == hipSuccess && hipMalloc((void**)&f->ipiv[1], 4 * (2 * (size_t)B + 128)) == hipSuccess &&
               hipMalloc(&f->colbuf[0], esz * (size_t)B * 48) == hipSuccess && hipMalloc(&f->colbuf[1], esz * (size_t)B * 48) == hipSuccess &&
               hipMalloc((void**)&f->flag, 16) == hipSuccess && hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&f->side[0], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&f->side[1], hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&f->ev_panel[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&f->ev_panel[1], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&f->ev_update[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&f->ev_update[1], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming) == hipSuccess;
     hipStream_t s = ctx->stream;

@@ -14,9 +14,11 @@ reported under config.other_pc so both numbers are always on the line.
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1 (this round): every rank solves the same pair around its own shift of the reference's Re-sweep table
-(.examples/eigenvalues.py:37-49), the embarrassingly parallel "replicas" layout of SURVEY.md section 8e; no data-path
-collective.  The row-sharded single-problem layout is described in DESIGN.md.
+N > 1 (this round): the embarrassingly parallel "replicas" layout of SURVEY.md section 8e -- every rank runs the N = 1
+workload (same pair, the Re = 50 shift), so the per-GPU work is fixed as N grows ("weak") and there is no data-path
+collective.  `--sweep` gives each rank its own shift of the reference's Re-sweep table (.examples/eigenvalues.py:37-49)
+instead; the shifts need 116-259 operator applies each, so that variant measures load imbalance, not the GPUs.  The
+row-sharded single-problem layout is described in DESIGN.md.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured on the SpMV kernel (the kernel the metric names) on SROOF, a
 ~1.5e8-nnz CSR with the cylinder-flow row pattern that does not fit the 256 MB Infinity Cache; `cpu_baseline` is the
@@ -161,6 +163,7 @@ def main() -> None:
     ap.add_argument("--ncv", type=int, default=80)
     ap.add_argument("--atol", type=float, default=1e-10)
     ap.add_argument("--pc", choices=("lu", "ilu"), default="lu")
+    ap.add_argument("--sweep", action="store_true", help="N > 1: one shift of the Re-sweep table per rank instead of N replicas of the Re = 50 solve")
     ap.add_argument("--no-other-pc", action="store_true", help="skip the single timed solve of the other inner-solver variant")
     ap.add_argument("--ilu-levels", type=int, default=2)
     ap.add_argument("--restart", type=int, default=1000)
@@ -198,7 +201,7 @@ def main() -> None:
     from oracle import fem
 
     es = fem.cylinder_case(args.case)
-    sigma = SWEEP_SIGMAS[(2 + rank) % len(SWEEP_SIGMAS)]
+    sigma = SWEEP_SIGMAS[(2 + rank) % len(SWEEP_SIGMAS)] if args.sweep else SWEEP_SIGMAS[2]
     log(f"rank {rank}/{world}: {args.case} n={es.n} nnz={es.A.nnz} sigma={sigma}")
     solver = build_solver(es, sigma, args, device, args.pc)
     solver.solver.prepare()  # ordering + upload: (A, M) now resident in HBM
@@ -270,7 +273,7 @@ def main() -> None:
                                else f"inner solves: ILU({args.ilu_levels})-GMRES({args.restart}), blocked SpTRSV"),
                 "pc": args.pc,
                 "other_pc": other,
-                "layout": "replicas" if world > 1 else "single GPU",
+                "layout": ("one shift of the Re sweep per rank" if args.sweep else "replicas of the N = 1 workload") if world > 1 else "single GPU",
                 "converged_per_solve": nconv,
                 "max_residual": float(res[: args.k].max()) if len(res) else None,
                 "op_applies_per_solve": stats.get("op_applies"),

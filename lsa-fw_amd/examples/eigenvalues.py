@@ -60,41 +60,63 @@ def synthesize(save_dir: Path, case: str) -> None:
         iPETScMatrix(es.M).export(mat_dir / "M.mtx")
 
 
-def main() -> None:
+def solve_case(save_dir: Path, re: float, target: complex) -> Path | None:
+    """One Reynolds number: load (A, M), shift-invert at the tabulated target, write sigma (reference ``:66-107``)."""
+    case_dir = save_dir / f"reynolds_{re:.1f}"
+    mat_dir = case_dir / "matrices"
+    A_path, M_path = mat_dir / "A.mtx", mat_dir / "M.mtx"
+    if not A_path.exists() or not M_path.exists():
+        logger.warning("Skipping Re = %.1f: missing matrices in '%s'", re, mat_dir)
+        return None
+    logger.info("[Re=%.1f] Loading matrices from '%s'", re, mat_dir)
+    A = iPETScMatrix.from_path(A_path)
+    A.assemble()
+    M = iPETScMatrix.from_path(M_path)
+    M.assemble()
+    logger.info("[Re=%.1f] A: shape=%s, nnz=%d, norm=%.3e", re, A.shape, A.nonzero_entries, A.norm)
+    logger.info("[Re=%.1f] M: shape=%s, nnz=%d, norm=%.3e", re, M.shape, M.nonzero_entries, M.norm)
+
+    cfg = EigensolverConfig(num_eig=_NUM_EIG, atol=_ATOL)
+    es = EigenSolver(A, M, cfg=cfg, check_hermitian=False)
+    es.solver.set_st_type(iSTType.SINVERT)
+    es.solver.set_target(target)
+    es.solver.set_st_pc_type(PreconditionerType.LU)
+    es.solver.solve()
+    sigma = es.solver.get_eigenvalue(_EIG_INDEX)
+    out_path = case_dir / f"sigma_eig{_EIG_INDEX}.txt"
+    out_path.write_text(f"{sigma.real} {sigma.imag}\n", encoding="utf-8")
+    logger.info("[Re=%.1f] Wrote sigma to '%s'", re, out_path)
+    es.solver.release()
+    return out_path
+
+
+def main(argv: list[str] | None = None) -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--save-dir", type=Path, default=_SAVE_DIR)
     ap.add_argument("--synthesize", metavar="CASE", help="first write synthetic matrices (e.g. S5k)")
-    args = ap.parse_args()
+    ap.add_argument("--jobs", type=int, default=1,
+                    help="Reynolds numbers in flight on the GPU at once (threads, one HIP context and stream set each). One "
+                         "solve is a chain of dependent launches that leaves most of an MI355X idle: two in flight deliver "
+                         "1.5x the eigenpairs per second (DESIGN.md section 6), and the host-side loading and ordering of "
+                         "one case hides behind the GPU work of the other.")
+    args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     if args.synthesize:
         synthesize(args.save_dir, args.synthesize)
+    cases = list(zip(_REYNOLDS, _TARGETS))
+    if args.jobs <= 1:
+        for re, target in cases:
+            solve_case(args.save_dir, re, target)
+    else:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
 
-    for re, target in zip(_REYNOLDS, _TARGETS):
-        case_dir = args.save_dir / f"reynolds_{re:.1f}"
-        mat_dir = case_dir / "matrices"
-        A_path, M_path = mat_dir / "A.mtx", mat_dir / "M.mtx"
-        if not A_path.exists() or not M_path.exists():
-            logger.warning("Skipping Re = %.1f: missing matrices in '%s'", re, mat_dir)
-            continue
-        logger.info("[Re=%.1f] Loading matrices from '%s'", re, mat_dir)
-        A = iPETScMatrix.from_path(A_path)
-        A.assemble()
-        M = iPETScMatrix.from_path(M_path)
-        M.assemble()
-        logger.info("[Re=%.1f] A: shape=%s, nnz=%d, norm=%.3e", re, A.shape, A.nonzero_entries, A.norm)
-        logger.info("[Re=%.1f] M: shape=%s, nnz=%d, norm=%.3e", re, M.shape, M.nonzero_entries, M.norm)
-
-        cfg = EigensolverConfig(num_eig=_NUM_EIG, atol=_ATOL)
-        es = EigenSolver(A, M, cfg=cfg, check_hermitian=False)
-        es.solver.set_st_type(iSTType.SINVERT)
-        es.solver.set_target(target)
-        es.solver.set_st_pc_type(PreconditionerType.LU)
-        es.solver.solve()
-        sigma = es.solver.get_eigenvalue(_EIG_INDEX)
-        out_path = case_dir / f"sigma_eig{_EIG_INDEX}.txt"
-        out_path.write_text(f"{sigma.real} {sigma.imag}\n", encoding="utf-8")
-        logger.info("[Re=%.1f] Wrote sigma to '%s'", re, out_path)
-        es.solver.release()
+        # every solve drives up to four streams; the runtime's default of four hardware queues per process would
+        # serialise two solves on the same queues (read when the first HIP context is created)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(4 * args.jobs))
+        with ThreadPoolExecutor(max_workers=args.jobs) as pool:
+            for fut in [pool.submit(solve_case, args.save_dir, re, target) for re, target in cases]:
+                fut.result()
     logger.info("All cases processed.")
 
 

@@ -248,8 +248,10 @@ def test_direct_adjoint_pair():
     assert sw.shape == ux.shape and np.all(sw >= 0) and np.isfinite(sw).all() and sw.max() > 0
 
 
-def test_reynolds_sweep_harness(tmp_path, monkeypatch):
-    """.examples/eigenvalues.py:61-108 end to end on synthetic matrices: one sigma file per Reynolds number."""
+@pytest.mark.parametrize("jobs", [1, 2])
+def test_reynolds_sweep_harness(tmp_path, monkeypatch, jobs):
+    """.examples/eigenvalues.py:61-108 end to end on synthetic matrices: one sigma file per Reynolds number; with
+    ``--jobs 2`` two Reynolds numbers are in flight on the GPU at once (threads, own HIP context each)."""
     import importlib.util
     from pathlib import Path
 
@@ -261,8 +263,7 @@ def test_reynolds_sweep_harness(tmp_path, monkeypatch):
     spec.loader.exec_module(mod)
     monkeypatch.setattr(mod, "_REYNOLDS", (50, 55))
     monkeypatch.setattr(mod, "_TARGETS", mod._TARGETS[2:4])
-    monkeypatch.setattr("sys.argv", ["eigenvalues.py", "--save-dir", str(tmp_path), "--synthesize", "S2k"])
-    mod.main()
+    mod.main(["--save-dir", str(tmp_path), "--synthesize", "S2k", "--jobs", str(jobs)])
     for re, target in zip((50, 55), mod._TARGETS):
         txt = (tmp_path / f"reynolds_{re:.1f}" / "sigma_eig0.txt").read_text().split()
         got = complex(float(txt[0]), float(txt[1]))

@@ -170,6 +170,38 @@ def solves_in_flight(es, sigma, args, device, jobs=2, rounds=4):
             "note": "secondary: independent solves overlapped on one GPU (threads); `value` is one solve at a time"}
 
 
+def lu_apply_rate(es, sigma, device):
+    """Secondary figure: one inner solve of the exact block LU (forward + backward sweeps of the twisted factorisation),
+    HIP-event time per apply against its algorithmic bytes (lsa_blu_apply_bytes)."""
+    import lsa_hip
+    from Solver.utils import pivot_safe_rcm
+
+    C = sp.csr_matrix((es.A.data - sigma * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+    perm = pivot_safe_rcm(C)
+    C = C[perm][:, perm].tocsr()
+    C.sort_indices()
+    ctx = lsa_hip.Context(device)
+    try:
+        dC = lsa_hip.CsrMatrix.from_scipy(ctx, C)
+        f = lsa_hip.BlockLu(ctx, dC)
+        rng = np.random.default_rng(0)
+        db = lsa_hip.DeviceVector.from_numpy(ctx, rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n))
+        dx = lsa_hip.DeviceVector(ctx, es.n, np.complex128)
+        f.time_solve(db, dx, 10)
+        ms = f.time_solve(db, dx, 200)
+        info = f.info()
+        out = {"ms_per_apply": ms, "algorithmic_bytes": info["apply_bytes"], "achieved_GBps": info["apply_bytes"] / ms / 1e6,
+               "frac_of_hbm_peak": info["apply_bytes"] / ms / 1e6 / HBM_PEAK_GBS, "block_size": info["block_size"],
+               "nblocks": info["nblocks"], "dependent_launches": 2 * (2 * ((info["nblocks"] + 1) // 2) + 1)}
+        f = db = dx = dC = None
+    finally:
+        import gc
+
+        gc.collect()
+        ctx.close()
+    return out
+
+
 def cpu_baseline(es, sigma, args):
     """The oracle (scipy ARPACK + SuperLU) on the same problem, same k / ncv / tolerance, on the host cores."""
     from oracle import shift_invert
@@ -317,6 +349,7 @@ def main() -> None:
         }
         if world == 1 and not args.no_other_pc:
             out["config"]["two_solves_in_flight"] = solves_in_flight(es, sigma, args, device)
+            out["config"]["lu_apply"] = lu_apply_rate(es, sigma, device)
         if not args.no_roofline:
             roof = spmv_roofline(args, device)
             out["roofline"] = {

@@ -124,6 +124,9 @@ void lsa_blu_destroy(lsa_blu *f);
 int lsa_blu_solve(lsa_ctx *ctx, lsa_blu *f, const lsa_vec *b, lsa_vec *x);
 int lsa_blu_solve_time(lsa_ctx *ctx, lsa_blu *f, const lsa_vec *b, lsa_vec *x, int iters, double *avg_ms);
 int lsa_blu_info(const lsa_blu *f, int32_t *block_size, int32_t *nblocks, int32_t *bandwidth, double *seconds);
+/* algorithmic bytes of one lsa_blu_solve: the Schur inverses (elimination sweep: whole blocks; substitution sweep: the
+ * columns that meet a non-zero), the off-block entries of C twice, the vectors -- the numerator of an achieved GB/s */
+int lsa_blu_apply_bytes(const lsa_blu *f, int64_t *bytes);
 
 /* ---- GMRES: KSPSolve of the ST (reference default PREONLY+LU; north star: GMRES+ILU) ----------------- */
 /* right-preconditioned restarted GMRES with CGS2; pc may be NULL.  x holds the initial guess on entry

@@ -1176,4 +1176,27 @@ int lsa_blu_info(const lsa_blu* f, int32_t* block_size, int32_t* nblocks, int32_
     return LSA_OK;
 }
 
+// Algorithmic bytes of one solve (what lsa_blu_solve_time's milliseconds are to be divided into): every Schur inverse
+// once in the elimination sweep, its window columns once in the substitution sweep, the off-block entries of C twice
+// (value + column index), the vectors of both sweeps.
+int lsa_blu_apply_bytes(const lsa_blu* f, int64_t* bytes) {
+    if (!f || !bytes || !f->C) return LSA_ERR_ARG;
+    const int64_t esz = f->dtype == LSA_C128 ? 16 : 8;
+    int64_t dense = 0, offblock = 0;
+    for (int32_t b = 0; b < f->nb; ++b) {
+        const int64_t bs = (int64_t)b * f->B, be = std::min<int64_t>(f->n, bs + f->B), m = be - bs;
+        int64_t win = m;
+        if (b < f->mid) win = be - f->uwin_lo[b];
+        else if (b > f->mid) win = f->lwin_hi[b] - bs;
+        dense += m * m + (b == f->mid ? 0 : m * win);
+        for (int64_t r = bs; r < be; ++r) {
+            const int32_t* c0 = f->C->h_ci.data() + f->C->h_rp[r];
+            const int32_t* c1 = f->C->h_ci.data() + f->C->h_rp[r + 1];
+            offblock += (std::lower_bound(c0, c1, (int32_t)bs) - c0) + (c1 - std::lower_bound(c0, c1, (int32_t)be));
+        }
+    }
+    *bytes = dense * esz + 2 * offblock * (esz + 4) + 8 * (int64_t)f->n * 16;
+    return LSA_OK;
+}
+
 }  // extern "C"

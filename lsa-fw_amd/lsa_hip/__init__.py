@@ -96,6 +96,7 @@ SIGNATURES = {
     "lsa_blu_solve": (ctypes.c_int, [_P, _P, _P, _P]),
     "lsa_blu_solve_time": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.POINTER(_DBL)]),
     "lsa_blu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
+    "lsa_blu_apply_bytes": (ctypes.c_int, [_P, ctypes.POINTER(_I64)]),
     "lsa_gmres": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, _DBL, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
     "lsa_op_create": (ctypes.c_int, [_P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
     "lsa_op_create_sharded": (ctypes.c_int, [_P, _P, _P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
@@ -406,7 +407,9 @@ class BlockLu:
     def info(self) -> dict:
         B, nb, bw, sec = _I32(0), _I32(0), _I32(0), _DBL(0.0)
         self.ctx._lib.lsa_blu_info(self.handle, ctypes.byref(B), ctypes.byref(nb), ctypes.byref(bw), ctypes.byref(sec))
-        return {"block_size": B.value, "nblocks": nb.value, "bandwidth": bw.value, "seconds": sec.value}
+        nbytes = _I64(0)
+        self.ctx._lib.lsa_blu_apply_bytes(self.handle, ctypes.byref(nbytes))
+        return {"block_size": B.value, "nblocks": nb.value, "bandwidth": bw.value, "seconds": sec.value, "apply_bytes": nbytes.value}
 
     def solve(self, b: DeviceVector, x: DeviceVector) -> None:
         self.ctx.check(self.ctx._lib.lsa_blu_solve(self.ctx.handle, self.handle, b.handle, x.handle))

@@ -135,3 +135,28 @@ def test_eigensolver_with_lu_preconditioner_matches_oracle():
     assert st["gmres_iters"] == 0  # every inner solve was direct (verified against b - C x)
     assert st["max_rel_res"] <= 1e-12
     assert solver.solver.residuals().max() <= 1e-8
+
+
+def test_lu_request_falls_back_to_ilu_when_the_band_does_not_fit():
+    """PreconditionerType.LU on a matrix whose band cannot be inverted in HBM (a periodic chain in natural order:
+    bandwidth n - 1): ``lsa_blu_create`` refuses, the operator is built on ILU(2) + GMRES instead and the eigenvalues
+    still match the oracle."""
+    from oracle import shift_invert
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    n = 200_000
+    main = 2.0 + np.linspace(0.0, 1.0, n)
+    A = sp.diags([-np.ones(n - 1), main, -np.ones(n - 1)], [-1, 0, 1], format="lil")
+    A[0, n - 1] = A[n - 1, 0] = -1.0
+    A = sp.csr_matrix(A)
+    sigma = 1.7
+    ref, _, _ = shift_invert.solve(A, None, sigma, k=3, tol=1e-12, ncv=30)
+    solver = EigenSolver(A, None, EigensolverConfig(num_eig=3, atol=1e-10, ncv=30), check_hermitian=False, ordering="natural")
+    solver.solver.set_st_type(iSTType.SINVERT)
+    solver.solver.set_target(sigma)
+    solver.solver.set_st_pc_type(PreconditionerType.LU)
+    lam = np.array([p[0] for p in solver.solve()])
+    for r in ref:
+        assert np.min(np.abs(lam - r)) <= 1e-8 * abs(r)
+    assert solver.solver.stats["gmres_iters"] > 0  # inner solves were iterative: the block LU was not available

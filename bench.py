@@ -231,7 +231,7 @@ def main() -> None:
     ap.add_argument("--pc", choices=("lu", "ilu"), default="lu")
     ap.add_argument("--sweep", action="store_true", help="N > 1: one shift of the Re-sweep table per rank instead of N replicas of the Re = 50 solve")
     ap.add_argument("--no-other-pc", action="store_true", help="skip the single timed solve of the other inner-solver variant")
-    ap.add_argument("--ilu-levels", type=int, default=2)
+    ap.add_argument("--ilu-levels", type=int, default=6, help="fill level of the ILU variant: 2/3/4/6/8/12 -> 14.5/12.2/9.7/8.1/8.2/10.1 s per S30k solve")
     ap.add_argument("--restart", type=int, default=1000)
     ap.add_argument("--roof-case", default="S500k")
     ap.add_argument("--roof-reps", type=int, default=10)

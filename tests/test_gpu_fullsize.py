@@ -1,0 +1,93 @@
+"""GPU checks at the size BASELINE.json's metric is quoted on (S30k, k = 20), through properties that need no oracle
+run: true residuals, independence of the start vector, agreement of the shift-invert and Cayley transforms, the block
+LU as a direct solver, and the SpMV against a float128-free host product."""
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+def _solver(es, sigma, seed=0, st="sinvert", k=20):
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=k, atol=1e-10, ncv=80, max_it=500), check_hermitian=False, seed=seed)
+    s.solver.set_st_type(iSTType.SINVERT if st == "sinvert" else iSTType.CAYLEY)
+    s.solver.set_target(sigma)
+    s.solver.set_st_pc_type(PreconditionerType.LU)
+    return s
+
+
+@pytest.fixture(scope="module")
+def s30k():
+    from oracle import fem
+
+    return fem.cylinder_case("S30k")
+
+
+def test_s30k_residuals_and_start_vector_independence(s30k):
+    from oracle import fem
+
+    sigma = fem.SIGMA_RE50
+    lams = []
+    for seed in (0, 7):
+        s = _solver(s30k, sigma, seed=seed)
+        pairs = s.solve()
+        assert len(pairs) == 20
+        res = s.solver.residuals()
+        assert res[:20].max() <= 1e-8  # ||A v - lam M v|| / (||A v|| + |lam| ||M v||), Solver/eigen2.py:48-56
+        st = s.solver.stats
+        assert st["gmres_iters"] == 0 and st["max_rel_res"] <= 1e-12  # every inner solve was direct and verified
+        lam = np.array([p[0] for p in pairs])
+        # the host-side formula on the returned vectors agrees with the device evaluation
+        V = np.column_stack([s.solver.get_eigenvector_array(i) for i in range(3)])
+        Av, Mv = s30k.A @ V, s30k.M @ V
+        host = np.linalg.norm(Av - Mv * lam[:3], axis=0) / (np.linalg.norm(Av, axis=0) + np.abs(lam[:3]) * np.linalg.norm(Mv, axis=0))
+        assert np.all(host <= 1e-8)
+        assert np.allclose(np.linalg.norm(V, axis=0), 1.0, atol=1e-12)
+        lams.append(lam)
+        s.solver.release()
+    for r in lams[0]:
+        assert np.min(np.abs(lams[1] - r)) <= 1e-8 * abs(r)
+
+
+def test_s30k_cayley_agrees_with_shift_invert(s30k):
+    from oracle import fem
+
+    sigma = fem.SIGMA_RE50
+    a = _solver(s30k, sigma, k=10)
+    lam_si = np.array([p[0] for p in a.solve()])
+    a.solver.release()
+    b = _solver(s30k, sigma, st="cayley", k=10)
+    lam_cy = np.array([p[0] for p in b.solve()])
+    assert b.solver.residuals()[:10].max() <= 1e-8
+    b.solver.release()
+    for r in lam_si[:10]:
+        assert np.min(np.abs(lam_cy - r)) <= 1e-8 * abs(r)
+
+
+def test_s30k_block_lu_round_trip(hip_ctx, s30k):
+    """x -> C x (SpMV) -> C^-1 (block LU sweeps) returns x: the two hot kernels against each other at full size."""
+    import lsa_hip
+    from oracle import fem
+    from Solver.utils import pivot_safe_rcm
+
+    C = sp.csr_matrix((s30k.A.data - fem.SIGMA_RE50 * s30k.M.data, s30k.A.indices, s30k.A.indptr), shape=s30k.A.shape)
+    perm = pivot_safe_rcm(C)
+    C = C[perm][:, perm].tocsr()
+    C.sort_indices()
+    dC = lsa_hip.CsrMatrix.from_scipy(hip_ctx, C)
+    f = lsa_hip.BlockLu(hip_ctx, dC)
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(s30k.n) + 1j * rng.standard_normal(s30k.n)
+    dx = lsa_hip.DeviceVector.from_numpy(hip_ctx, x)
+    db = lsa_hip.DeviceVector(hip_ctx, s30k.n, np.complex128)
+    dC.matvec(dx, db)
+    assert np.linalg.norm(db.numpy() - C @ x) <= 1e-13 * np.linalg.norm(C @ x)
+    dy = lsa_hip.DeviceVector(hip_ctx, s30k.n, np.complex128)
+    f.solve(db, dy)
+    assert np.linalg.norm(dy.numpy() - x) <= 1e-9 * np.linalg.norm(x)  # cond(C) ~ 1e5 at this shift
+    info = f.info()
+    assert info["block_size"] == 1024 and info["nblocks"] == 31 and info["apply_bytes"] > 5e8

@@ -303,3 +303,27 @@ def test_unsupported_spectral_transformations_fail_loudly():
     solver.solver.set_st_type(iSTType.FILTER)
     with pytest.raises(NotImplementedError, match="FILTER"):
         solver.solve()
+
+
+def test_vibrating_membrane_benchmark_published_values():
+    """tests/benchmark/vibrating_membrane.py:159-181 on the GPU path: GHEP, legacy ``EigenSolver(cfg, A, M)`` order, plain
+    SHIFT transformation, SMALLEST_REAL, the spurious lambda = 1 of the identity Dirichlet rows filtered out; the first
+    three values are the ones published in vibrating_membrane.md:102-110."""
+    import json
+    from pathlib import Path
+
+    from oracle import fem
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import iEpsProblemType, iEpsWhich
+
+    ref = json.loads((Path(__file__).parent / "golden" / "reference_known_answers.json").read_text())["membrane_32x32_p2"]
+    A, M, _ = fem.assemble_membrane(32, 32, *ref["domain"])
+    cfg = EigensolverConfig(problem_type=iEpsProblemType.GHEP, num_eig=9, atol=1e-8, max_it=1000)
+    solver = EigenSolver(cfg, A, M)
+    solver.solver.set_which_eigenpairs(iEpsWhich.SMALLEST_REAL)
+    numerical = solver.solve()
+    assert all(isinstance(ev, float) for ev, _ in numerical)  # Hermitian problem types return real eigenvalues
+    vals = np.array([ev for ev, _ in numerical if abs(ev - 1.0) > cfg.atol][:5])
+    assert np.allclose(vals[:3], ref["published"], rtol=0, atol=5e-7)  # published to 7 significant digits
+    ana = fem.membrane_analytic(5)
+    assert np.max(np.abs(vals - ana) / ana) <= 2e-4  # P2 on 32 x 32: the 6.06e-5 average of the report is over 15 modes

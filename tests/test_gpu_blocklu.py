@@ -21,11 +21,11 @@ def _ordered(case, sigma):
     return es, Cp
 
 
-# block sizes 1536 and 2560 exercise the panel-kernel instances for blocks of <= 2048 and <= 4096 rows (4 and 8 rows per
-# thread, panels of 8 and 4 columns); the default and 256 / 512 use the thread-per-row instance
+# block sizes 1536, 2560 and 3584 exercise the other panel-kernel instances (4 rows per thread; 12 and 16 rows per thread
+# with the split row-tiled update on a side stream); the default and 256 / 512 use the thread-per-row instance
 @pytest.mark.parametrize("case,sigma,block", [("S2k", 0.018 + 0.7379601143282424j, 256), ("S5k", 0.018 + 0.7379601143282424j, 0),
                                               ("S5k", 0.05, 512), ("S5k", 0.018 + 0.7379601143282424j, 1536),
-                                              ("S5k", 0.018 + 0.7379601143282424j, 2560)])
+                                              ("S5k", 0.018 + 0.7379601143282424j, 2560), ("S5k", 0.018 + 0.7379601143282424j, 3584)])
 def test_block_lu_is_a_direct_solver(hip_ctx, case, sigma, block):
     import lsa_hip
 
@@ -47,7 +47,7 @@ def test_block_lu_is_a_direct_solver(hip_ctx, case, sigma, block):
     assert np.array_equal(dx.numpy(), x)
 
 
-@pytest.mark.parametrize("block", [256, 1536, 2560])
+@pytest.mark.parametrize("block", [256, 1536, 2560, 3584])
 def test_block_lu_real_matrix(hip_ctx, block):
     """float64 instantiation: a real, non-symmetric, banded matrix that needs row interchanges (weak diagonal)."""
     import lsa_hip

@@ -192,7 +192,7 @@ def lu_apply_rate(es, sigma, device):
         info = f.info()
         out = {"ms_per_apply": ms, "algorithmic_bytes": info["apply_bytes"], "achieved_GBps": info["apply_bytes"] / ms / 1e6,
                "frac_of_hbm_peak": info["apply_bytes"] / ms / 1e6 / HBM_PEAK_GBS, "block_size": info["block_size"],
-               "nblocks": info["nblocks"], "dependent_launches": 2 * (2 * ((info["nblocks"] + 1) // 2) + 1)}
+               "nblocks": info["nblocks"], "dependent_launches": info["apply_launches"]}
         f = db = dx = dC = None
     finally:
         import gc

@@ -127,6 +127,9 @@ int lsa_blu_info(const lsa_blu *f, int32_t *block_size, int32_t *nblocks, int32_
 /* algorithmic bytes of one lsa_blu_solve: the Schur inverses (elimination sweep: whole blocks; substitution sweep: the
  * columns that meet a non-zero), the off-block entries of C twice, the vectors -- the numerator of an achieved GB/s */
 int lsa_blu_apply_bytes(const lsa_blu *f, int64_t *bytes);
+/* dependent kernel launches of one lsa_blu_solve: one per pair of blocks and sweep when the couplings to the neighbouring
+ * blocks are absorbed into dense operators (blocks of <= 1024 rows), two otherwise (sparse update + dense mat-vec) */
+int lsa_blu_apply_launches(const lsa_blu *f, int32_t *launches);
 
 /* ---- GMRES: KSPSolve of the ST (reference default PREONLY+LU; north star: GMRES+ILU) ----------------- */
 /* right-preconditioned restarted GMRES with CGS2; pc may be NULL.  x holds the initial guess on entry

@@ -51,6 +51,13 @@ struct lsa_blu {
     void* graph[2] = {nullptr, nullptr};
     double seconds = 0.0;
     std::vector<int32_t> uwin_lo, lwin_hi;  // per block: first row with entries right of the block / end of the rows with entries left of it
+    // absorbed couplings: G_b = Sinv_b C_{b,b-1} and K_b = Sinv_b C_{b,b+1} restricted to the columns the sparse blocks
+    // touch ([gcol0[b], bs) and [be, kcol1[b])); n x ldg / n x ldk dense, row-major.  With them a sweep step is ONE dense
+    // launch (no sparse half-step).  Null when they do not fit: the sweeps then use Sinv + the sparse rows of C.
+    void *G = nullptr, *K = nullptr;
+    int32_t ldg = 0, ldk = 0;
+    bool want_absorb = false;
+    std::vector<int32_t> gcol0, kcol1;
     uint64_t pattern_hash = 0;  // of C's host row pointers and column indices (key of the per-context cache)
     int64_t nnz = 0;
 };
@@ -736,6 +743,92 @@ __global__ __launch_bounds__(256) void blu_dense_kernel(BluRange ra, BluRange rb
     if (lane == 0) out[r] = window ? s_sub(add[r], v) : v;
 }
 
+// G_b[r, t] = sum_s Sinv_b[r, s] C[bs + s, col0 + t]  for the columns [col0, col0 + wcols) of a neighbouring block that the
+// sparse coupling block touches (left neighbour: col0 + wcols = bs; right neighbour: col0 = be).  One workgroup per row
+// r of the block: the row of Sinv_b is staged in LDS, a thread walks the CSC column col0 + t and keeps the entries
+// whose row lies in the block.
+template <typename T>
+__global__ __launch_bounds__(256) void blu_absorb_kernel(int32_t bs, int32_t be, int32_t ld, int32_t col0, int32_t wcols, int32_t ldo,
+                                                         const T* __restrict__ val, const int32_t* __restrict__ cptr,
+                                                         const int32_t* __restrict__ crow, const int32_t* __restrict__ cpos,
+                                                         const T* __restrict__ sinv, T* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char dyn[];
+    T* srow = (T*)dyn;
+    const int32_t r = bs + blockIdx.x, m = be - bs;
+    const T* src = sinv + (size_t)r * ld;
+    for (int32_t k = threadIdx.x; k < m; k += 256) srow[k] = src[k];
+    __syncthreads();
+    T* dst = out + (size_t)r * ldo;
+    for (int32_t t = threadIdx.x; t < wcols; t += 256) {
+        const int32_t q0 = cptr[col0 + t], q1 = cptr[col0 + t + 1];
+        T acc = scalar_traits<T>::zero();
+        for (int32_t q = q0; q < q1; ++q) {
+            const int32_t k = crow[q];
+            if (k >= bs && k < be) fma_acc(acc, srow[k - bs], val[cpos[q]]);
+        }
+        dst[t] = acc;
+    }
+}
+
+// One sweep step on the absorbed form, one block of each chain per launch (wavefront per row):
+//   out[r] = add[r] + [mode & 1] sum_s Sinv[r, s] vfull[bs + s] - [mode & 2] sum_t G[r, t] x[gc0 + t] - [mode & 4] sum_t K[r, t] x[be + t]
+struct BluStep {
+    int32_t bs, be, mode;
+    int32_t gc0, gw;  // columns [gc0, gc0 + gw) of the left neighbour (G)
+    int32_t kw;       // columns [be, be + kw) of the right neighbour (K)
+};
+
+template <typename MT, typename VT>
+__device__ __forceinline__ void wave_dot_sub(VT (&acc)[4], const MT* __restrict__ row, const VT* __restrict__ x, int32_t cnt, int lane, bool subtract) {
+    VT part[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) part[k] = scalar_traits<VT>::zero();
+    int32_t s = lane;
+    for (; s + 7 * 64 < cnt; s += 8 * 64) {
+        MT a[8];
+        VT tv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a[k] = row[s + k * 64];
+            tv[k] = x[s + k * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fma_acc(part[k & 3], a[k], tv[k]);
+    }
+    for (; s < cnt; s += 64) fma_acc(part[0], row[s], x[s]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = subtract ? s_sub(acc[k], part[k]) : s_add(acc[k], part[k]);
+}
+
+template <typename MT, typename VT>
+__global__ __launch_bounds__(256) void blu_step_kernel(BluStep ra, BluStep rb, int32_t ld, int32_t ldg, int32_t ldk, const MT* __restrict__ sinv,
+                                                       const MT* __restrict__ G, const MT* __restrict__ K, const VT* __restrict__ vfull,
+                                                       const VT* __restrict__ x, const VT* __restrict__ add, VT* __restrict__ out) {
+    const int32_t ga = (ra.be - ra.bs + 3) / 4;
+    const bool second = (int32_t)blockIdx.x >= ga;
+    const BluStep rg = second ? rb : ra;
+    const int lane = threadIdx.x & 63;
+    const int32_t r = rg.bs + ((int32_t)blockIdx.x - (second ? ga : 0)) * 4 + (threadIdx.x >> 6);
+    if (r >= rg.be) return;
+    VT acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = scalar_traits<VT>::zero();
+    if (rg.mode & 1) wave_dot_sub<MT, VT>(acc, sinv + (size_t)r * ld, vfull + rg.bs, rg.be - rg.bs, lane, false);
+    if (rg.mode & 2) wave_dot_sub<MT, VT>(acc, G + (size_t)r * ldg, x + rg.gc0, rg.gw, lane, true);
+    if (rg.mode & 4) wave_dot_sub<MT, VT>(acc, K + (size_t)r * ldk, x + rg.be, rg.kw, lane, true);
+    VT v = s_add(s_add(acc[0], acc[1]), s_add(acc[2], acc[3]));
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        if constexpr (sizeof(VT) == 16) {
+            v.re += __shfl_xor(v.re, m, 64);
+            v.im += __shfl_xor(v.im, m, 64);
+        } else {
+            v += __shfl_xor(v, m, 64);
+        }
+    }
+    if (lane == 0) out[r] = add ? s_add(add[r], v) : v;
+}
+
 template <typename T>
 int factorize(lsa_ctx* ctx, lsa_blu* f) {
     const int32_t B = f->B, n = f->n, ld = f->ld;
@@ -762,6 +855,7 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
     if (lds > 64 * 1024) {
         LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_corner_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        LSA_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)blu_absorb_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     // panel width of the blocked Gauss-Jordan = the W of the gj_fused_kernel instance used below: 8 columns while a
     // thread holds at most 4 rows, 4 columns up to 8 rows (blocks of 4096 rows); LSA_GJ_PANEL=1 selects the unblocked
@@ -847,6 +941,15 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
         } else {
             hipLaunchKernelGGL((gj_unpivot_serial_kernel<T>), dim3((m + 255) / 256), dim3(256), 0, st, S, ld, m, (const int32_t*)ipiv);
         }
+        if (f->G) {  // absorb the couplings to both neighbours: G_b = Sinv_b C_{b,b-1}, K_b = Sinv_b C_{b,b+1}
+            const int32_t gw = bs - f->gcol0[b], kw = f->kcol1[b] - be;
+            if (gw > 0)
+                hipLaunchKernelGGL((blu_absorb_kernel<T>), dim3(m), dim3(256), lds, st, bs, be, ld, f->gcol0[b], gw, f->ldg, (const T*)C->val, f->cptr,
+                                   f->crow, f->cpos, (const T*)f->sinv, (T*)f->G);
+            if (kw > 0)
+                hipLaunchKernelGGL((blu_absorb_kernel<T>), dim3(m), dim3(256), lds, st, bs, be, ld, be, kw, f->ldk, (const T*)C->val, f->cptr, f->crow,
+                                   f->cpos, (const T*)f->sinv, (T*)f->K);
+        }
     };
     // twisted order: chain 0 eliminates downwards from block 0, chain 1 upwards from the last block, on two streams;
     // they meet at the middle block, which receives both corrections
@@ -880,6 +983,32 @@ int launch_apply(lsa_ctx* ctx, lsa_blu* f, const VT* v, VT* x, VT* y, VT* z, VT*
     const int32_t B = f->B, nb = f->nb, n = f->n, mid = f->mid;
     const lsa_mat* C = f->C;
     hipStream_t st = ctx->stream;
+    if (f->G) {
+        // absorbed form: every sweep step is one dense launch (both chains):
+        //   elimination   z_b = Sinv_b v_b - G_b z_{b-1}   (chain from the top)     z_b = Sinv_b v_b - K_b z_{b+1}  (from the bottom)
+        //   middle        x_m = Sinv_m v_m - G_m z_{m-1} - K_m z_{m+1}
+        //   substitution  x_b = z_b - K_b x_{b+1}          (top chain)              x_b = z_b - G_b x_{b-1}         (bottom chain)
+        auto stepd = [&](int32_t b, int32_t mode) {
+            if (b < 0 || b >= nb) return BluStep{0, 0, 0, 0, 0, 0};
+            const int32_t bs = b * B, be = std::min(n, bs + B);
+            if (b == 0) mode &= ~2;
+            if (b == nb - 1) mode &= ~4;
+            return BluStep{bs, be, mode, f->gcol0[b], bs - f->gcol0[b], f->kcol1[b] - be};
+        };
+        auto launch = [&](BluStep ra, BluStep rb, const VT* vfull, const VT* xin, const VT* add, VT* out) {
+            const int32_t gd = (ra.be - ra.bs + 3) / 4 + (rb.be - rb.bs + 3) / 4;
+            if (gd == 0) return;
+            hipLaunchKernelGGL((blu_step_kernel<MT, VT>), dim3(gd), dim3(256), 0, st, ra, rb, f->ld, f->ldg, f->ldk, (const MT*)f->sinv, (const MT*)f->G,
+                               (const MT*)f->K, vfull, xin, add, out);
+        };
+        for (int32_t k = 0; k < std::max(mid, nb - 1 - mid); ++k) {
+            const int32_t bt = k, bb = nb - 1 - k;
+            launch(stepd(bt < mid ? bt : -1, 1 | 2), stepd(bb > mid ? bb : -1, 1 | 4), v, (const VT*)z, nullptr, z);
+        }
+        launch(stepd(mid, 1 | 2 | 4), stepd(-1, 0), v, (const VT*)z, nullptr, x);
+        for (int32_t k = 1; k <= std::max(mid, nb - 1 - mid); ++k) launch(stepd(mid - k, 4), stepd(mid + k, 2), nullptr, (const VT*)x, (const VT*)z, x);
+        return LSA_OK;
+    }
     auto range = [&](int32_t b, int32_t mode) {
         if (b < 0 || b >= nb) return BluRange{0, 0, 0, 0, 0};
         return BluRange{b * B, std::min(n, b * B + B), mode, 0, 0};
@@ -973,7 +1102,7 @@ static void blu_free(lsa_blu* f) {
     }
     if (f->stream2) (void)hipStreamSynchronize(f->stream2);
     for (void* p : {(void*)f->lsplit, (void*)f->usplit, (void*)f->cptr, (void*)f->crow, (void*)f->cpos, f->sinv, (void*)f->ipiv[0], (void*)f->ipiv[1],
-                    f->colbuf[0], f->colbuf[1], (void*)f->flag})
+                    f->colbuf[0], f->colbuf[1], (void*)f->flag, f->G, f->K})
         if (p) (void)hipFree(p);
     if (f->ev_fork) (void)hipEventDestroy(f->ev_fork);
     if (f->ev_join) (void)hipEventDestroy(f->ev_join);
@@ -1039,6 +1168,24 @@ static bool blu_setup(lsa_ctx* ctx, lsa_blu* f, const lsa_mat* C) {
         f->uwin_lo[b] = ulo;
         f->lwin_hi[b] = lhi;
     }
+    // column ranges of the neighbouring blocks that the coupling blocks touch, and room for the absorbed couplings
+    f->gcol0.assign((size_t)f->nb, 0);
+    f->kcol1.assign((size_t)f->nb, 0);
+    int32_t gmax = 0, kmax = 0;
+    for (int32_t b = 0; b < f->nb; ++b) {
+        const int32_t bs = b * B, be = std::min(n, bs + B);
+        int32_t g0 = bs, k1 = be;
+        for (int32_t r = bs; r < be; ++r) {
+            if (C->h_rp[r] < ls[r]) g0 = std::min(g0, c[C->h_rp[r]]);            // first (smallest) column of the row
+            if (us[r] < C->h_rp[r + 1]) k1 = std::max(k1, c[C->h_rp[r + 1] - 1] + 1);  // last column + 1
+        }
+        f->gcol0[b] = g0;
+        f->kcol1[b] = k1;
+        gmax = std::max(gmax, bs - g0);
+        kmax = std::max(kmax, k1 - be);
+    }
+    f->ldg = ((gmax + 15) / 16) * 16;
+    f->ldk = ((kmax + 15) / 16) * 16;
     {
         std::vector<int32_t> cur(cptr.begin(), cptr.end() - 1);
         for (int32_t r = 0; r < n; ++r)
@@ -1063,6 +1210,22 @@ static bool blu_setup(lsa_ctx* ctx, lsa_blu* f, const lsa_mat* C) {
               hipEventCreateWithFlags(&f->ev_update[1], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming) == hipSuccess;
+    // The absorbed couplings halve the dependent launches of a solve and add bytes: a gain while the sweeps are latency-bound
+    // (S30k, B = 1024: 345 -> 291 us per apply), a loss once the dense blocks dominate (B = 1536: 1348 -> 1417 us;
+    // B = 3072: 7.7 -> 9.5 ms).  LSA_BLU_ABSORB = 0 / 1 overrides.
+    if (ok && f->nb > 1 && f->want_absorb) {
+        // optional: when they do not fit, the sweeps fall back to Sinv + the sparse rows of C
+        size_t free_now = 0, total_now = 0;
+        (void)hipMemGetInfo(&free_now, &total_now);
+        const size_t gb = (size_t)n1 * std::max(f->ldg, 16) * esz, kb = (size_t)n1 * std::max(f->ldk, 16) * esz;
+        if (gb + kb < free_now / 2 && hipMalloc(&f->G, gb) == hipSuccess) {
+            if (hipMalloc(&f->K, kb) != hipSuccess) {
+                (void)hipFree(f->G);
+                f->G = nullptr;
+            }
+        }
+        (void)hipGetLastError();
+    }
     hipStream_t s = ctx->stream;
     ok = ok && hipMemcpyAsync(f->lsplit, ls.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s) == hipSuccess &&
          hipMemcpyAsync(f->usplit, us.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s) == hipSuccess &&
@@ -1104,9 +1267,11 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     int32_t mid = (n > 0 ? (n + B - 1) / B : 0) / 2;
     if (const char* e = getenv("LSA_BLU_TWIST"))  // 0: one chain from the first block (the middle block is the last one)
         if (atoi(e) == 0) mid = n > 0 ? (n + B - 1) / B - 1 : 0;
+    const char* absorb_env = getenv("LSA_BLU_ABSORB");
+    const bool absorb = absorb_env ? atoi(absorb_env) != 0 : B <= 1024;
     lsa_blu* f = nullptr;
     if (lsa_blu* c = ctx->blu_cache) {
-        if (c->pattern_hash == hash && c->n == n && c->nnz == C->nnz && c->B == B && c->dtype == C->dtype && c->mid == mid &&
+        if (c->pattern_hash == hash && c->n == n && c->nnz == C->nnz && c->B == B && c->dtype == C->dtype && c->mid == mid && c->want_absorb == absorb &&
             !getenv("LSA_BLU_NO_CACHE")) {
             f = c;
             ctx->blu_cache = nullptr;
@@ -1129,6 +1294,7 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
         f->dtype = C->dtype;
         f->pattern_hash = hash;
         f->nnz = C->nnz;
+        f->want_absorb = absorb;
         if (!blu_setup(ctx, f, C)) {
             blu_free(f);
             return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_blu_create: out of device memory");
@@ -1176,12 +1342,30 @@ int lsa_blu_info(const lsa_blu* f, int32_t* block_size, int32_t* nblocks, int32_
     return LSA_OK;
 }
 
+// Dependent kernel launches of one solve (the length of the chain its latency is made of)
+int lsa_blu_apply_launches(const lsa_blu* f, int32_t* launches) {
+    if (!f || !launches) return LSA_ERR_ARG;
+    const int32_t steps = f->nb > 0 ? 2 * std::max(f->mid, f->nb - 1 - f->mid) + 1 : 0;
+    *launches = f->G ? steps : 2 * steps;
+    return LSA_OK;
+}
+
 // Algorithmic bytes of one solve (what lsa_blu_solve_time's milliseconds are to be divided into): every Schur inverse
 // once in the elimination sweep, its window columns once in the substitution sweep, the off-block entries of C twice
 // (value + column index), the vectors of both sweeps.
 int lsa_blu_apply_bytes(const lsa_blu* f, int64_t* bytes) {
     if (!f || !bytes || !f->C) return LSA_ERR_ARG;
     const int64_t esz = f->dtype == LSA_C128 ? 16 : 8;
+    if (f->G) {  // absorbed form: Sinv once, G and K of every block once in each sweep they take part in, the vectors
+        int64_t elems = 0;
+        for (int32_t b = 0; b < f->nb; ++b) {
+            const int64_t bs = (int64_t)b * f->B, be = std::min<int64_t>(f->n, bs + f->B), m = be - bs;
+            const int64_t gw = b > 0 ? bs - f->gcol0[b] : 0, kw = b < f->nb - 1 ? f->kcol1[b] - be : 0;
+            elems += m * m + m * (gw + kw);
+        }
+        *bytes = elems * esz + 6 * (int64_t)f->n * 16;
+        return LSA_OK;
+    }
     int64_t dense = 0, offblock = 0;
     for (int32_t b = 0; b < f->nb; ++b) {
         const int64_t bs = (int64_t)b * f->B, be = std::min<int64_t>(f->n, bs + f->B), m = be - bs;

@@ -97,6 +97,7 @@ SIGNATURES = {
     "lsa_blu_solve_time": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.POINTER(_DBL)]),
     "lsa_blu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
     "lsa_blu_apply_bytes": (ctypes.c_int, [_P, ctypes.POINTER(_I64)]),
+    "lsa_blu_apply_launches": (ctypes.c_int, [_P, ctypes.POINTER(_I32)]),
     "lsa_gmres": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, _DBL, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
     "lsa_op_create": (ctypes.c_int, [_P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
     "lsa_op_create_sharded": (ctypes.c_int, [_P, _P, _P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
@@ -409,7 +410,10 @@ class BlockLu:
         self.ctx._lib.lsa_blu_info(self.handle, ctypes.byref(B), ctypes.byref(nb), ctypes.byref(bw), ctypes.byref(sec))
         nbytes = _I64(0)
         self.ctx._lib.lsa_blu_apply_bytes(self.handle, ctypes.byref(nbytes))
-        return {"block_size": B.value, "nblocks": nb.value, "bandwidth": bw.value, "seconds": sec.value, "apply_bytes": nbytes.value}
+        nl = _I32(0)
+        self.ctx._lib.lsa_blu_apply_launches(self.handle, ctypes.byref(nl))
+        return {"block_size": B.value, "nblocks": nb.value, "bandwidth": bw.value, "seconds": sec.value, "apply_bytes": nbytes.value,
+                "apply_launches": nl.value}
 
     def solve(self, b: DeviceVector, x: DeviceVector) -> None:
         self.ctx.check(self.ctx._lib.lsa_blu_solve(self.ctx.handle, self.handle, b.handle, x.handle))

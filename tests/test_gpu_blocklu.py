@@ -84,6 +84,30 @@ def test_block_lu_ragged_sizes(hip_ctx, n):
     assert np.linalg.norm(dx.numpy() - xref) <= 1e-9 * np.linalg.norm(xref)
 
 
+@pytest.mark.parametrize("block", [512, 1536])
+def test_block_lu_absorbed_and_sparse_sweeps_agree(hip_ctx, monkeypatch, block):
+    """The solve on the absorbed couplings (one dense launch per step; default for blocks of <= 1024 rows) and the one on
+    Sinv + the sparse rows of C (LSA_BLU_ABSORB=0) are the same direct solve."""
+    import lsa_hip
+
+    es, Cp = _ordered("S5k", 0.018 + 0.7379601143282424j)
+    dC = lsa_hip.CsrMatrix.from_scipy(hip_ctx, Cp)
+    rng = np.random.default_rng(9)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    xs, launches = [], []
+    for absorb in ("1", "0"):
+        monkeypatch.setenv("LSA_BLU_ABSORB", absorb)
+        f = lsa_hip.BlockLu(hip_ctx, dC, block)
+        dx = lsa_hip.DeviceVector(hip_ctx, es.n, np.complex128)
+        f.solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
+        xs.append(dx.numpy())
+        launches.append(f.info()["apply_launches"])
+        del f
+    assert np.linalg.norm(Cp @ xs[0] - b) <= 1e-12 * np.linalg.norm(b)
+    assert np.linalg.norm(xs[0] - xs[1]) <= 1e-11 * np.linalg.norm(xs[1])
+    assert launches[1] == 2 * launches[0]
+
+
 def test_block_lu_unblocked_elimination_agrees(hip_ctx, monkeypatch):
     """LSA_GJ_PANEL=1 selects the two-launches-per-pivot Gauss-Jordan (what blocks of more than 4096 rows get)."""
     import lsa_hip

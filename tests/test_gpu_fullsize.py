@@ -91,3 +91,4 @@ def test_s30k_block_lu_round_trip(hip_ctx, s30k):
     assert np.linalg.norm(dy.numpy() - x) <= 1e-9 * np.linalg.norm(x)  # cond(C) ~ 1e5 at this shift
     info = f.info()
     assert info["block_size"] == 1024 and info["nblocks"] == 31 and info["apply_bytes"] > 5e8
+    assert info["apply_launches"] == 31  # absorbed couplings: one launch per pair of blocks and sweep, plus the middle block

@@ -523,7 +523,7 @@ class iEpsSolver:
             op = None
         order = np.argsort(lam_key(lam), kind="stable")
         self._eigenvalues = lam[order]
-        self._eigenvectors = X[:, order]
+        self._eigenvectors = np.asfortranarray(X[:, order])  # column access (one eigenvector) must be contiguous
         self._residual_estimates = res.residuals[order]
         self._restarts = res.restarts
 

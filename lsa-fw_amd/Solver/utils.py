@@ -480,6 +480,13 @@ class iEpsSolver:
         cayley = prep["cayley"]
         nu = complex(sigma if self._antishift is None else self._antishift)  # STCayleySetAntishift defaults to the shift
         which = self._which or (iEpsWhich.TARGET_MAGNITUDE if sinvert else iEpsWhich.LARGEST_MAGNITUDE)
+        if which is iEpsWhich.ALL:
+            # SLEPc computes "all eigenvalues in [a, b]" by spectrum slicing: shift-invert sweeps whose completeness rests on
+            # inertia counts of a symmetric-indefinite factorisation.  The block LU here pivots rows and has no inertia.
+            raise NotImplementedError(
+                "iEpsWhich.ALL (spectrum slicing over set_interval) is not available on the HIP path: it needs the inertia of a "
+                "symmetric factorisation.  Use set_target at the centre of the interval with TARGET_MAGNITUDE and enough pairs.")
+        # (like SLEPc, an interval set without iEpsWhich.ALL has no effect)
         lam_key = _lambda_rank_key(which, self._target)
         ksp_rtol = self._ksp_rtol if self._ksp_rtol is not None else float(np.clip(self._tol * 1e-2, 1e-13, 1e-8))
         op = basis = None

@@ -327,3 +327,19 @@ def test_vibrating_membrane_benchmark_published_values():
     assert np.allclose(vals[:3], ref["published"], rtol=0, atol=5e-7)  # published to 7 significant digits
     ana = fem.membrane_analytic(5)
     assert np.max(np.abs(vals - ana) / ana) <= 2e-4  # P2 on 32 x 32: the 6.06e-5 average of the report is over 15 modes
+
+
+def test_spectrum_slicing_request_fails_loudly():
+    """``set_interval`` + ``iEpsWhich.ALL`` asks SLEPc for spectrum slicing (inertia-based); the HIP path refuses instead
+    of silently returning something else.  Without ALL the interval is ignored, as in SLEPc."""
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import iEpsProblemType, iEpsWhich
+
+    A = np.diag([1.0, 2.0, 3.0, 4.0, 5.0])
+    solver = EigenSolver(A, None, EigensolverConfig(problem_type=iEpsProblemType.HEP, num_eig=2, atol=1e-10))
+    solver.solver.set_interval(1.5, 3.5)
+    lam = sorted(ev for ev, _ in solver.solve())  # interval without ALL: no effect (largest magnitude by default)
+    assert np.allclose(lam, [4.0, 5.0], atol=1e-8)
+    solver.solver.set_which_eigenpairs(iEpsWhich.ALL)
+    with pytest.raises(NotImplementedError, match="spectrum slicing"):
+        solver.solve()

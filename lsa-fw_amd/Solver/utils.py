@@ -184,17 +184,29 @@ def delay_zero_diagonal_rows(C: sp.csr_matrix, block_starts: np.ndarray | None =
     blk = None if block_starts is None else np.searchsorted(block_starts, np.arange(n), side="right") - 1
     key = np.arange(n, dtype=np.float64)
     indptr, indices, data = C.indptr, C.indices, C.data
-    for z in zero_diag:
-        cols = indices[indptr[z] : indptr[z + 1]]
-        keep = (data[indptr[z] : indptr[z + 1]] != 0) & (cols != z)
-        if blk is not None:
-            keep &= blk[cols] == blk[z]
-        nb = np.sort(cols[keep])
-        if nb.size == 0:
-            continue
-        target = nb[max(int(np.ceil(fraction * nb.size)) - 1, 0)]
-        if target > z:
-            key[z] = target + 0.5
+    # all entries of the zero-diagonal rows at once (no Python loop over rows: 3 480 of them at S30k)
+    starts = indptr[zero_diag].astype(np.int64)
+    lens = (indptr[zero_diag + 1] - indptr[zero_diag]).astype(np.int64)
+    total = int(lens.sum())
+    if total == 0:
+        return np.arange(n, dtype=np.int64)
+    pos = np.repeat(starts - (np.cumsum(lens) - lens), lens) + np.arange(total)
+    rid = np.repeat(np.arange(zero_diag.size), lens)  # which zero-diagonal row an entry belongs to
+    cols = indices[pos].astype(np.int64)
+    keep = (data[pos] != 0) & (cols != zero_diag[rid])
+    if blk is not None:
+        keep &= blk[cols] == blk[zero_diag[rid]]
+    cols, rid = cols[keep], rid[keep]
+    order = np.lexsort((cols, rid))  # by row, neighbours ascending inside a row
+    cols, rid = cols[order], rid[order]
+    cnt = np.bincount(rid, minlength=zero_diag.size)
+    first = np.cumsum(cnt) - cnt
+    has = cnt > 0
+    pick = first[has] + np.maximum(np.ceil(fraction * cnt[has]).astype(np.int64) - 1, 0)
+    target = cols[pick]
+    z = zero_diag[has]
+    later = target > z
+    key[z[later]] = target[later] + 0.5
     return np.argsort(key, kind="stable").astype(np.int64)
 
 

@@ -231,3 +231,37 @@ def test_complex_vector_shim():
     c = a.copy()
     c.scale(0.0)
     assert a.norm() > 0
+
+
+def test_native_matrix_market_parser_on_awkward_and_malformed_files(tmp_path):
+    """The native reader (host code of liblsa_hip.so, the file boundary of the path): duplicates are summed, CRLF and
+    blank/comment lines are accepted, an empty matrix is fine; truncated, out-of-range or non-numeric data is a
+    ``ValueError``, not a crash or a silently short matrix."""
+    import lsa_hip
+
+    def parse(text, name="m.mtx"):
+        p = tmp_path / name
+        p.write_bytes(text.encode())
+        return lsa_hip.read_matrix_market(p)
+
+    m = parse("%%MatrixMarket matrix coordinate real general\r\n% made on another OS\r\n\r\n3 3 4\r\n1 1 1.5\r\n3 2 -2\r\n1 1 0.5\r\n2 2 0\r\n")
+    assert m.shape == (3, 3) and m.nnz == 3  # (1,1) twice -> summed; the explicit zero at (2,2) is kept
+    assert m[0, 0] == 2.0 and m[2, 1] == -2.0 and m.indptr.tolist() == [0, 1, 2, 3]
+    e = parse("%%MatrixMarket matrix coordinate complex general\n4 5 0\n")
+    assert e.shape == (4, 5) and e.nnz == 0 and np.iscomplexobj(e.data)
+    i = parse("%%MatrixMarket matrix coordinate integer symmetric\n2 2 2\n2 1 7\n2 2 3\n")
+    assert i.toarray().tolist() == [[0.0, 7.0], [7.0, 3.0]]
+    for bad in (
+        "%%MatrixMarket matrix coordinate real general\n3 3 4\n1 1 1.0\n2 2 2.0\n",  # fewer entries than announced
+        "%%MatrixMarket matrix coordinate real general\n3 3 1\n4 1 1.0\n",  # row index out of range
+        "%%MatrixMarket matrix coordinate real general\n3 3 1\n1 0 1.0\n",  # column index 0 (1-based format)
+        "%%MatrixMarket matrix coordinate real general\n3 3 1\n1 1 abc\n",  # not a number
+        "%%MatrixMarket matrix coordinate real general\n3 x 1\n1 1 1.0\n",  # bad size line
+        "%%MatrixMarket matrix coordinate real unknown-symmetry\n1 1 1\n1 1 1.0\n",
+        "%MatrixMarket matrix coordinate real general\n1 1 1\n1 1 1.0\n",  # bad banner
+        "",
+    ):
+        with pytest.raises(ValueError):
+            parse(bad, "bad.mtx")
+    with pytest.raises(ValueError):
+        lsa_hip.read_matrix_market(tmp_path / "does_not_exist.mtx")

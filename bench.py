@@ -80,7 +80,7 @@ def build_solver(es, sigma, args, device, pc):
 def spmv_roofline(args, device):
     """SpMV on SROOF: achieved algorithmic GB/s from HIP-event time per launch (library stream)."""
     import lsa_hip
-    from oracle import fem
+    from synthetic import fem
     from Solver.utils import pivot_safe_rcm
 
     t0 = time.time()
@@ -264,7 +264,7 @@ def main() -> None:
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an AMD GPU (no CPU fallback)")
 
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cylinder_case(args.case)
     sigma = SWEEP_SIGMAS[(2 + rank) % len(SWEEP_SIGMAS)] if args.sweep else SWEEP_SIGMAS[2]

@@ -50,7 +50,7 @@ logger = logging.getLogger(__name__)
 def synthesize(save_dir: Path, case: str) -> None:
     """Write the synthetic (A, M) of oracle/fem.py for every Reynolds number of the sweep."""
     sys.path.insert(0, str(ROOT))
-    from oracle import fem
+    from synthetic import fem
 
     for re in _REYNOLDS:
         mat_dir = save_dir / f"reynolds_{re:.1f}" / "matrices"

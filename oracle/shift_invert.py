@@ -9,7 +9,7 @@ SuperLU in place of PETSc's KSP(preonly)+LU:
 
 * ``C = A - sigma M``                              ``Solver/eigen2.py:109-111``
 * factorise ``C`` once (LU)                         ``Solver/eigen2.py:121-151``
-* ``OP x = C^-1 (M x)``                             ``Solver/eigen2.py:164-201`` (without the optional pressure projection)
+* ``OP x = C^-1 (M x)``                             ``Solver/eigen2.py:164-201`` (``project_out=`` adds its pressure projection)
 * ``eigs(OP, k, which='LM', tol, maxiter, ncv)``    ``Solver/eigen2.py:225-234``
 * ``lambda = sigma + 1/mu``                         ``Solver/eigen2.py:209-211,239``
 * relative residuals                                ``Solver/eigen2.py:48-56``

@@ -11,7 +11,7 @@ import scipy.sparse as sp  # noqa: E402
 import scipy.sparse.linalg as spla  # noqa: E402
 
 import lsa_hip  # noqa: E402
-from oracle import fem  # noqa: E402
+from synthetic import fem  # noqa: E402
 from Solver.utils import pivot_safe_rcm  # noqa: E402
 
 ap = argparse.ArgumentParser()

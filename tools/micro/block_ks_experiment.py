@@ -12,7 +12,7 @@ import scipy.sparse as sp  # noqa: E402
 import scipy.sparse.linalg as spla  # noqa: E402
 from scipy.linalg import lapack  # noqa: E402
 
-from oracle import fem  # noqa: E402
+from synthetic import fem  # noqa: E402
 
 
 def block_krylov_schur(op, n, nev, ncv, s, tol, sigma, maxit=200, seed=0):

@@ -9,7 +9,7 @@ sys.path[:0] = [str(ROOT), str(ROOT / "lsa-fw_amd")]
 import numpy as np  # noqa: E402
 
 import bench  # noqa: E402
-from oracle import fem  # noqa: E402
+from synthetic import fem  # noqa: E402
 
 
 class Args:

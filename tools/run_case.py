@@ -8,7 +8,7 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "lsa-fw_amd")]
 import numpy as np  # noqa: E402
 
-from oracle import fem  # noqa: E402
+from synthetic import fem  # noqa: E402
 from Solver.eigen import EigenSolver, EigensolverConfig  # noqa: E402
 from Solver.utils import PreconditionerType, iSTType  # noqa: E402
 

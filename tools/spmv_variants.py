@@ -9,7 +9,7 @@ import numpy as np  # noqa: E402
 import scipy.sparse as sp  # noqa: E402
 
 import lsa_hip  # noqa: E402
-from oracle import fem  # noqa: E402
+from synthetic import fem  # noqa: E402
 from Solver.utils import pivot_safe_rcm  # noqa: E402
 
 case, reps = (sys.argv[1] if len(sys.argv) > 1 else "S500k"), int(sys.argv[2]) if len(sys.argv) > 2 else 10

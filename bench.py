@@ -46,7 +46,8 @@ for _var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ.setdefault(_var, "1")
 # one solve drives up to four streams; the secondary "two solves in flight" figure needs a second set of hardware queues
 # (the runtime's default is four per process; read when the first HIP context is created)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if int(os.environ.get("WORLD_SIZE", "1")) == 1:  # (with several processes on one GPU, as in the one-box rehearsal of
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # N > 1, more than 8 queues per GPU in total slow everything down)
 
 import numpy as np  # noqa: E402
 import scipy.sparse as sp  # noqa: E402

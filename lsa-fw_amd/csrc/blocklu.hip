@@ -864,7 +864,7 @@ int factorize(lsa_ctx* ctx, lsa_blu* f) {
     if (const char* e = getenv("LSA_GJ_PANEL"))
         if (atoi(e) == 1) panel_w = 1;
     // blocks of at least split_min rows use the split form (lone panel workgroup beside a row-tiled bulk update)
-    const int32_t split_min = (getenv("LSA_GJ_SPLIT_MIN") && f->side[0]) ? atoi(getenv("LSA_GJ_SPLIT_MIN")) : 2049;
+    const int32_t split_min = getenv("LSA_GJ_SPLIT_MIN") ? atoi(getenv("LSA_GJ_SPLIT_MIN")) : 2049;
     auto factor_block = [&](hipStream_t st, int chain, int32_t b, bool corr_left, bool corr_right) {
         const int32_t bs = b * B, be = std::min(n, bs + B), m = be - bs;
         T* S = (T*)f->sinv + (size_t)bs * ld;
@@ -1202,14 +1202,15 @@ static bool blu_setup(lsa_ctx* ctx, lsa_blu* f, const lsa_mat* C) {
               hipMalloc((void**)&f->ipiv[0], 4 * (2 * (size_t)B + 128)) == hipSuccess && hipMalloc((void**)&f->ipiv[1], 4 * (2 * (size_t)B + 128)) == hipSuccess &&
               hipMalloc(&f->colbuf[0], esz * (size_t)B * 48) == hipSuccess && hipMalloc(&f->colbuf[1], esz * (size_t)B * 48) == hipSuccess &&
               hipMalloc((void**)&f->flag, 16) == hipSuccess && hipStreamCreateWithFlags(&f->stream2, hipStreamNonBlocking) == hipSuccess &&
-              // (side streams only where the split form is used: every stream takes a share of the process's hardware queues,
-              // which several solves in flight compete for)
-              (B <= 2048 || (hipStreamCreateWithFlags(&f->side[0], hipStreamNonBlocking) == hipSuccess &&
-                             hipStreamCreateWithFlags(&f->side[1], hipStreamNonBlocking) == hipSuccess &&
-                             hipEventCreateWithFlags(&f->ev_panel[0], hipEventDisableTiming) == hipSuccess &&
-                             hipEventCreateWithFlags(&f->ev_panel[1], hipEventDisableTiming) == hipSuccess &&
-                             hipEventCreateWithFlags(&f->ev_update[0], hipEventDisableTiming) == hipSuccess &&
-                             hipEventCreateWithFlags(&f->ev_update[1], hipEventDisableTiming) == hipSuccess)) &&
+              // (the side streams are created for every size although only wide blocks use them: measured with two
+              // processes sharing one GPU, a process with four streams here runs a step in 0.24 s, one with two in 0.43 s --
+              // which hardware queue slots a process's streams land on decides whether it collides with its neighbour)
+              hipStreamCreateWithFlags(&f->side[0], hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&f->side[1], hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&f->ev_panel[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&f->ev_panel[1], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&f->ev_update[0], hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&f->ev_update[1], hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&f->ev_fork, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&f->ev_join, hipEventDisableTiming) == hipSuccess;
     // The absorbed couplings halve the dependent launches of a solve and add bytes: a gain while the sweeps are latency-bound

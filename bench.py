@@ -359,19 +359,25 @@ def main() -> None:
                 except Exception as exc:  # noqa: BLE001
                     out["config"][name] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_roofline:
-            roof = spmv_roofline(args, device)
-            out["roofline"] = {
-                "bound": "hbm", "achieved": roof["c128"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": roof["c128"]["gbs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
-                "kernel": "spmv_subwave_kernel<cplx,cplx> on SROOF", "ms_per_launch": roof["c128"]["ms"],
-                "algorithmic_bytes_per_launch": roof["c128"]["bytes"], "n": roof["n"], "nnz": roof["nnz"],
-                "f64": {"achieved": roof["f64"]["gbs"], "frac": roof["f64"]["gbs"] / HBM_PEAK_GBS, "ms_per_launch": roof["f64"]["ms"]},
-            }
+            try:
+                roof = spmv_roofline(args, device)
+                out["roofline"] = {
+                    "bound": "hbm", "achieved": roof["c128"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": roof["c128"]["gbs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
+                    "kernel": "spmv_subwave_kernel<cplx,cplx> on SROOF", "ms_per_launch": roof["c128"]["ms"],
+                    "algorithmic_bytes_per_launch": roof["c128"]["bytes"], "n": roof["n"], "nnz": roof["nnz"],
+                    "f64": {"achieved": roof["f64"]["gbs"], "frac": roof["f64"]["gbs"] / HBM_PEAK_GBS, "ms_per_launch": roof["f64"]["ms"]},
+                }
+            except Exception as exc:  # noqa: BLE001  (the headline value must survive a failure of this leg)
+                out["roofline"] = {"error": f"{type(exc).__name__}: {exc}"}
         if not args.no_cpu_baseline:
-            base, lam_cpu = cpu_baseline(es, sigma, args)
-            out["cpu_baseline"] = base
-            if len(lam_gpu):
-                out["config"]["max_rel_eig_diff_vs_cpu"] = float(max(np.min(np.abs(lam_gpu - r)) / abs(r) for r in lam_cpu[: len(lam_gpu)]))
+            try:
+                base, lam_cpu = cpu_baseline(es, sigma, args)
+                out["cpu_baseline"] = base
+                if len(lam_gpu):
+                    out["config"]["max_rel_eig_diff_vs_cpu"] = float(max(np.min(np.abs(lam_gpu - r)) / abs(r) for r in lam_cpu[: len(lam_gpu)]))
+            except Exception as exc:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

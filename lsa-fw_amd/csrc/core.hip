@@ -199,6 +199,8 @@ void lsa_mat_destroy(lsa_mat* m) {
         if (m->ci) (void)hipFree(m->ci);
     }
     if (m->val) (void)hipFree(m->val);
+    if (m->ci16) (void)hipFree(m->ci16);
+    if (m->cbase) (void)hipFree(m->cbase);
     delete m;
 }
 

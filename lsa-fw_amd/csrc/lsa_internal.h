@@ -121,6 +121,11 @@ struct lsa_mat {
     void* val;        // device, nnz
     bool owns_index;  // false when the index arrays are shared with another matrix
     std::vector<int32_t> h_rp, h_ci;  // host copy of the pattern (analysis phases)
+    // compressed column indices for the SpMV (built on first use): col = cbase[row] + ci16[p] when every row spans
+    // fewer than 65 536 columns (banded FEM matrices do); ci16_state: 0 = not tried, 1 = available, -1 = does not fit
+    mutable uint16_t* ci16 = nullptr;
+    mutable int32_t* cbase = nullptr;
+    mutable int ci16_state = 0;
 };
 
 int lsa_set_error(lsa_ctx* ctx, int code, const char* fmt, ...);

@@ -112,8 +112,61 @@ __global__ __launch_bounds__(256) void spmv_xcd_kernel(int32_t n, int32_t rows_p
     }
 }
 
+// 16-bit column indices relative to the first column of the row: 18 | 10 bytes per entry instead of 20 | 12
+template <typename MT, typename VT, int LPR>
+__global__ __launch_bounds__(256) void spmv_subwave16_kernel(int32_t n, const int32_t* __restrict__ rp, const uint16_t* __restrict__ ci16,
+                                                             const int32_t* __restrict__ cbase, const MT* __restrict__ val,
+                                                             const VT* __restrict__ x, VT* __restrict__ y) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t lane = (int32_t)(gid % LPR);
+    int64_t row = gid / LPR;
+    const int64_t row_stride = ((int64_t)gridDim.x * blockDim.x) / LPR;
+    for (; row < n; row += row_stride) {
+        const int32_t p0 = rp[row], p1 = rp[row + 1];
+        const VT* xr = x + cbase[row];
+        VT acc = scalar_traits<VT>::zero();
+        for (int32_t p = p0 + lane; p < p1; p += LPR) fma_acc(acc, val[p], xr[ci16[p]]);
+#pragma unroll
+        for (int m = LPR / 2; m > 0; m >>= 1) acc = s_add(acc, shfl_xor_t<VT>(acc, m));
+        if (lane == 0) y[row] = acc;
+    }
+}
+
+// builds A->ci16 / A->cbase from the host pattern; false when a row spans 65 536 columns or more
+static bool ensure_ci16(const lsa_mat* A) {
+    if (A->ci16_state != 0) return A->ci16_state > 0;
+    A->ci16_state = -1;
+    const int32_t n = A->n;
+    if ((int64_t)A->h_rp.size() != (int64_t)n + 1 || (int64_t)A->h_ci.size() != A->nnz) return false;
+    std::vector<uint16_t> d((size_t)std::max<int64_t>(A->nnz, 1));
+    std::vector<int32_t> base((size_t)std::max(n, 1), 0);
+    for (int32_t r = 0; r < n; ++r) {
+        const int32_t p0 = A->h_rp[r], p1 = A->h_rp[r + 1];
+        if (p0 == p1) continue;
+        int32_t lo = A->h_ci[p0];
+        for (int32_t p = p0; p < p1; ++p) lo = std::min(lo, A->h_ci[p]);
+        base[r] = lo;
+        for (int32_t p = p0; p < p1; ++p) {
+            const int32_t delta = A->h_ci[p] - lo;
+            if (delta > 65535) return false;
+            d[p] = (uint16_t)delta;
+        }
+    }
+    if (hipMalloc((void**)&A->ci16, d.size() * sizeof(uint16_t)) != hipSuccess) return false;
+    if (hipMalloc((void**)&A->cbase, base.size() * sizeof(int32_t)) != hipSuccess) {
+        (void)hipFree(A->ci16);
+        A->ci16 = nullptr;
+        return false;
+    }
+    (void)hipMemcpy(A->ci16, d.data(), d.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+    (void)hipMemcpy(A->cbase, base.data(), base.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    A->ci16_state = 1;
+    return true;
+}
+
 // variant word: bits 0-7 lanes per row (0 = from the mean row length), bit 8 non-temporal matrix loads,
-// bit 9 XCD-contiguous row chunks, bits 16-31 workgroups per CU (0 = 64)
+// bit 9 XCD-contiguous row chunks, bit 10 two rows per sub-wave, bit 11 16-bit column indices, bit 12 plain 32-bit
+// indices even for large matrices, bits 16-31 workgroups per CU (0 = 64)
 template <typename MT, typename VT, int LPR, bool NT>
 static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, int variant) {
     const int threads = 256;
@@ -128,6 +181,15 @@ static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, 
         rows_per_wg = ((rows_per_wg + rows_per_pass - 1) / rows_per_pass) * rows_per_pass;
         hipLaunchKernelGGL((spmv_xcd_kernel<MT, VT, LPR, NT>), dim3(G), dim3(threads), 0, ctx->stream, A->n, (int32_t)rows_per_wg, A->rp,
                            A->ci, (const MT*)A->val, (const VT*)x, (VT*)y);
+        return;
+    }
+    // default (no variant word): compressed indices for matrices where the SpMV is a bandwidth question (>= 4 M entries;
+    // building them is one host pass over the pattern, not worth it for the 0.9 M-entry matrices rebuilt per shift)
+    // (complex matrices only: with 8-byte values the 2-byte index loads cost more than they save -- f64 SROOF 565 -> 592 us)
+    const bool want16 = (variant & 0x800) || (variant == 0 && sizeof(MT) == 16 && A->nnz >= (int64_t)4 << 20);
+    if (want16 && !NT && ensure_ci16(A)) {
+        hipLaunchKernelGGL((spmv_subwave16_kernel<MT, VT, LPR>), dim3(blocks), dim3(threads), 0, ctx->stream, A->n, A->rp, (const uint16_t*)A->ci16,
+                           (const int32_t*)A->cbase, (const MT*)A->val, (const VT*)x, (VT*)y);
         return;
     }
     if (variant & 0x400) {

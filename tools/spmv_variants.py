@@ -35,6 +35,11 @@ for lpr in (8, 16):
         for two in (0, 1):
             for per_cu in (16, 256):
                 variants[f"lpr{lpr} nt{nt} two{two} wg/cu{per_cu}"] = lpr | (nt << 8) | (two << 10) | (per_cu << 16)
+variants["lpr16 ci16 wg/cu64"] = 16 | 0x800
+variants["lpr16 ci16 wg/cu256"] = 16 | 0x800 | (256 << 16)
+variants["lpr8 ci16 wg/cu64"] = 8 | 0x800
+variants["default"] = 0
+variants["plain 32-bit indices"] = 0x1000
 best = {}
 for rnd in range(3):
     for name, v in variants.items():

@@ -79,6 +79,37 @@ def test_spmv_edge_rows(hip_ctx):
     assert dy1.numpy()[0] == 10.0
 
 
+def test_spmv_compressed_indices(hip_ctx, case5k, monkeypatch):
+    """16-bit column indices relative to the row's first column (the default for large complex matrices; forced here
+    with the variant word): same product as the oracle, unsorted rows, empty rows and all three scalar pairings included;
+    a row that spans 65 536 columns or more silently keeps the 32-bit indices."""
+    import lsa_hip
+    from oracle import kernels
+
+    monkeypatch.setenv("LSA_SPMV_VARIANT", str(16 | 0x800))
+    for mat_c, vec_c in ((False, False), (False, True), (True, True)):
+        A = case5k.A.astype(np.complex128) * (1.0 + 0.5j) if mat_c else case5k.A
+        x = _rng_vec(A.shape[0], 11, vec_c)
+        dA = lsa_hip.CsrMatrix.from_scipy(hip_ctx, A)
+        dy = lsa_hip.DeviceVector(hip_ctx, A.shape[0], np.complex128 if vec_c else np.float64)
+        dA.matvec(lsa_hip.DeviceVector.from_numpy(hip_ctx, x), dy)
+        ref = kernels.spmv(A, x)
+        assert np.linalg.norm(dy.numpy() - ref) <= 1e-13 * np.linalg.norm(ref)
+    n = 70_000
+    rows = np.array([0, 0, 3, 3, 3, n - 1])
+    cols = np.array([n - 1, 2, 7, 5, 66_000, 0])  # row 0 spans 69 997 columns; row 3 is stored unsorted
+    W = sp.csr_matrix((np.arange(1.0, 7.0) * (1 + 1j), (rows, cols)), shape=(n, n))
+    x = _rng_vec(n, 12, True)
+    dW = lsa_hip.CsrMatrix.from_scipy(hip_ctx, W)
+    dy = lsa_hip.DeviceVector(hip_ctx, n, np.complex128)
+    dW.matvec(lsa_hip.DeviceVector.from_numpy(hip_ctx, x), dy)
+    assert np.linalg.norm(dy.numpy() - W @ x) <= 1e-13 * np.linalg.norm(W @ x)
+    N = sp.csr_matrix((np.array([1.0, 2.0, 3.0]) * (1 - 1j), (np.array([4, 4, 9]), np.array([60_000, 100, 9]))), shape=(n, n))  # fits 16 bits
+    dN = lsa_hip.CsrMatrix.from_scipy(hip_ctx, N)
+    dN.matvec(lsa_hip.DeviceVector.from_numpy(hip_ctx, x), dy)
+    assert np.linalg.norm(dy.numpy() - N @ x) <= 1e-13 * np.linalg.norm(N @ x)
+
+
 def test_spmv_transpose(hip_ctx, case5k):
     import lsa_hip
 

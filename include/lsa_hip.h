@@ -35,7 +35,8 @@ typedef enum {
     LSA_ERR_DIVERGED = -4,   /* inner solve did not reach rtol          -> RuntimeError (Solver/eigen2.py:179-181) */
     LSA_ERR_NONFINITE = -5,  /* NaN/Inf produced                        -> RuntimeError (Solver/eigen2.py:186-189) */
     LSA_ERR_TIMEOUT = -6,    /* a bounded device-side wait expired      -> RuntimeError                                 */
-    LSA_ERR_COMM = -7        /* RCCL failure                            -> RuntimeError                                 */
+    LSA_ERR_COMM = -7,       /* RCCL failure                            -> RuntimeError                                 */
+    LSA_ERR_OOM = -8         /* device memory exhausted (the only failure a factorisation may answer by a leaner method) */
 } lsa_status;
 
 typedef struct lsa_ctx lsa_ctx;
@@ -55,6 +56,8 @@ typedef struct {
     double max_rel_res;      /* worst one seen                                        */
     double seconds_factor;   /* wall seconds spent in symbolic + numeric factorisation */
     double seconds_solve;    /* wall seconds spent inside lsa_op_apply / lsa_krylov_extend */
+    int32_t stagnated_solves; /* inner solves accepted at a stagnated true residual in (10 rtol, 1000 rtol]: the caller warns */
+    int32_t pc_fallback;     /* 1 if the exact LU did not fit the device memory and ILU(k) + GMRES took its place */
 } lsa_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -131,6 +134,47 @@ int lsa_blu_apply_bytes(const lsa_blu *f, int64_t *bytes);
  * blocks are absorbed into dense operators (blocks of <= 1024 rows), two otherwise (sparse update + dense mat-vec) */
 int lsa_blu_apply_launches(const lsa_blu *f, int32_t *launches);
 
+/* ---- nested-dissection multifrontal LU: PC LU of the ST's KSP (.examples/eigenvalues.py:100;
+ * Sensitivity/__init__.py:182,260) ---------------------------------------------------------------------------------------
+ * The sparse direct solver PETSc's PC LU stands for, rebuilt for the device: elimination forest of dense fronts from a
+ * nested dissection of the pattern's graph, every front's pivot block inverted explicitly, so that a solve is two sweeps
+ * over the tree levels with one dense mat-vec per node and sweep.  C may be in any order (the dissection is internal). */
+typedef struct lsa_nd_sym lsa_nd_sym;  /* analysis of a pattern (host only)  */
+typedef struct lsa_ndlu lsa_ndlu;      /* factorisation resident in HBM      */
+/* Host-only analysis of a square CSR pattern (no GPU needed): ordering, elimination forest, front index lists.
+ * leaf_size <= 0 picks 128 unknowns per leaf subdomain.  The handle is returned on failure too (for lsa_nd_sym_error). */
+int lsa_nd_analyse(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t leaf_size, lsa_nd_sym **out);
+const char *lsa_nd_sym_error(const lsa_nd_sym *h);
+void lsa_nd_sym_destroy(lsa_nd_sym *h);
+/* tree nodes, tree levels, largest front, total length of the front index lists, scalars one solve reads (sum of
+ * m^2 + 2 m b over the nodes), scalars of all fronts (sum of f^2), multiply-adds of the numeric factorisation */
+int lsa_nd_sym_info(const lsa_nd_sym *h, int32_t *ntree, int32_t *nlevels, int32_t *max_front, int64_t *index_entries,
+                    int64_t *factor_entries, int64_t *front_entries, double *flops);
+/* copies of the analysis (any pointer may be NULL): perm[n] (elimination order -> original index), node_start[ntree + 1],
+ * parent[ntree] (-1 = root), level[ntree], front_size[ntree], idx[index_entries] (front index lists, original numbering) */
+int lsa_nd_sym_export(const lsa_nd_sym *h, int32_t *perm, int32_t *node_start, int32_t *parent, int32_t *level, int32_t *front_size,
+                      int32_t *idx);
+/* the index tables the device kernels walk, for tests: cmap[sum b] (position of each boundary unknown in the parent's
+ * front), gptr[sum (f + 1)] / gidx[sum b] (gather lists of the upward sweep), asm_dst[nnz] (front-buffer slot of every
+ * matrix entry), lvl_ptr[nlevels + 1] / lvl_nodes[ntree] (nodes by level) */
+int lsa_nd_sym_export_tables(const lsa_nd_sym *h, int32_t *cmap, int32_t *gptr, int32_t *gidx, int64_t *asm_dst, int32_t *lvl_ptr,
+                             int32_t *lvl_nodes);
+/* Analysis (from C's host copy of the pattern; reused from the context when the last destroyed factorisation had the same
+ * pattern) + numeric factorisation on the device.  LSA_ERR_ZERO_PIVOT when a pivot block is singular to 1e-13 max|C|,
+ * LSA_ERR_OOM when the fronts do not fit. */
+int lsa_ndlu_create(lsa_ctx *ctx, const lsa_mat *C, int32_t leaf_size, lsa_ndlu **out);
+/* new values on the analysed pattern (a shift sweep: .examples/eigenvalues.py:97-108) */
+int lsa_ndlu_refactor(lsa_ctx *ctx, lsa_ndlu *f, const lsa_mat *C);
+void lsa_ndlu_destroy(lsa_ndlu *f);
+/* x = C^-1 b */
+int lsa_ndlu_solve(lsa_ctx *ctx, lsa_ndlu *f, const lsa_vec *b, lsa_vec *x);
+int lsa_ndlu_solve_time(lsa_ctx *ctx, lsa_ndlu *f, const lsa_vec *b, lsa_vec *x, int iters, double *avg_ms);
+/* apply_bytes: algorithmic bytes of one solve (every factor scalar once + the vectors); apply_launches: dependent
+ * launches of one solve (two per tree level) */
+int lsa_ndlu_info(const lsa_ndlu *f, int32_t *ntree, int32_t *nlevels, int32_t *max_front, int64_t *factor_entries,
+                  int64_t *front_entries, int64_t *apply_bytes, int32_t *apply_launches, double *seconds_analyse,
+                  double *seconds_numeric);
+
 /* ---- GMRES: KSPSolve of the ST (reference default PREONLY+LU; north star: GMRES+ILU) ----------------- */
 /* right-preconditioned restarted GMRES with CGS2; pc may be NULL.  x holds the initial guess on entry
  * when use_x0 != 0.  Returns LSA_ERR_DIVERGED if rtol is not reached within maxit iterations. */
@@ -144,14 +188,15 @@ typedef struct {
     double ksp_rtol;      /* inner GMRES relative tolerance                                  */
     int32_t ksp_restart;  /* GMRES restart length                                            */
     int32_t ksp_maxit;    /* GMRES iteration cap                                             */
-    int32_t pc_type;      /* 0 = none, 1 = ILU(k), 2 = exact block LU (falls back to ILU(k) if the band does not fit) */
+    int32_t pc_type;      /* 0 = none, 1 = ILU(k), 2 = exact LU (nested-dissection multifrontal), 3 = exact block-tridiagonal LU
+                             of a banded order; 2 and 3 fall back to ILU(k) + GMRES only when they run out of device memory */
     double antishift[2];  /* mode 2 only: nu of the Cayley transform (re, im); SLEPc's default is nu = sigma */
 } lsa_op_options;
 
 /* Builds C = A - sigma*M (complex if sigma has an imaginary part or A/M are complex), factors it, and
  * allocates the inner-solver workspace.  M may be NULL (standard problem, M = I).
  * mode: 0 = shift-invert  y = (A - sigma M)^-1 M x     (iSTType.SINVERT)
- *       1 = shift         y = M^-1 (A - sigma M) x     (iSTType.SHIFT; needs M = NULL here, then y = (A - sigma I) x)
+ *       1 = shift         y = M^-1 (A - sigma M) x     (iSTType.SHIFT; M = NULL gives y = (A - sigma I) x)
  *       2 = Cayley        y = (A - sigma M)^-1 (A + nu M) x   (iSTType.CAYLEY, nu = opts->antishift) */
 int lsa_op_create(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, const double sigma[2], int mode,
                   const lsa_op_options *opts, lsa_op **out);

@@ -301,7 +301,7 @@ class iEpsSolver:
     def __init__(self, A=None, M=None, comm=None, *, device: int = 0, ksp_type: KSPType = KSPType.GMRES,
                  ksp_rtol: float | None = None, restart: int = 1000, ksp_max_it: int = 4000, ilu_levels: int | None = None,
                  ilu_shift: float = 0.0, ordering: str = "rcm", seed: int = 0, layout: str = "single",
-                 project_out: np.ndarray | None = None) -> None:
+                 project_out: np.ndarray | None = None, lu: str = "nd") -> None:
         if M is not None and A is None:
             raise ValueError("Cannot set right-hand operator M without left-hand operator A.")
         self._A = self._M = None
@@ -318,6 +318,9 @@ class iEpsSolver:
         self._ksp_rtol, self._restart_len, self._ksp_max_it = ksp_rtol, restart, ksp_max_it
         self._ilu_levels, self._ilu_shift = ilu_levels, ilu_shift
         self._ordering = ordering
+        if lu not in ("nd", "band"):
+            raise ValueError("lu must be 'nd' (nested-dissection multifrontal LU) or 'band' (block-tridiagonal LU of the RCM order)")
+        self._lu = lu
         self._device, self._seed = device, seed
         if layout not in ("single", "sharded"):
             raise ValueError("layout must be 'single' or 'sharded'")
@@ -386,14 +389,14 @@ class iEpsSolver:
         if self._pc_type in (PreconditionerType.ILU, PreconditionerType.ICC):
             return 1, 0  # PETSc's PCILU default: zero fill
         if self._pc_type in (PreconditionerType.LU, PreconditionerType.CHOLESKY):
-            # exact solves in the reference: exact block-tridiagonal LU on the device (ILU(2) + GMRES if the band does
-            # not fit the memory budget, e.g. 3D meshes)
-            return 2, 2
+            # exact solves in the reference: nested-dissection multifrontal LU on the device (``lu="band"``: the
+            # block-tridiagonal LU of the RCM order); ILU(2) + GMRES only if the factors do not fit the device memory
+            return (2 if self._lu == "nd" else 3), 2
         return 1, 2  # every other PETSc name: ILU(2) + GMRES
 
     def _signature(self):
         return (id(self._A), id(self._M), self._st_type, self._target, self._pc_type, self._ilu_levels, self._ordering, self._device,
-                self._layout)  # (the antishift only changes the multiplied matrix, built per solve)
+                self._layout, self._lu)  # (the antishift only changes the multiplied matrix, built per solve)
 
     def prepare(self) -> None:
         """Host-side analysis + upload: shared pattern, fill-reducing / pivot-safe ordering, CSR -> HBM.
@@ -537,6 +540,13 @@ class iEpsSolver:
             X[perm, :] = vecs
             self._stats = op.stats()
             self._stats["krylov_restarts"] = res.restarts
+            if self._stats.get("pc_fallback"):
+                logger.warning("The exact LU did not fit the device memory: the inner solves ran ILU(%d)-preconditioned GMRES instead.",
+                               prep["levels"])
+            if self._stats.get("stagnated_solves") or self._stats.get("max_rel_res", 0.0) > 10.0 * ksp_rtol:
+                logger.warning("Inner solves stagnated above the requested tolerance: worst true relative residual %.2e (ksp_rtol %.1e, %d "
+                               "solves accepted at the rounding floor). Eigenpairs are those of an inexactly applied operator; check "
+                               "residuals().", self._stats.get("max_rel_res", 0.0), ksp_rtol, self._stats.get("stagnated_solves", 0))
         finally:
             basis = None
             op = None

@@ -1254,7 +1254,7 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     size_t free_b = 0, total_b = 0;
     (void)hipMemGetInfo(&free_b, &total_b);
     if (inv_bytes > free_b / 2)
-        return lsa_set_error(ctx, LSA_ERR_HIP, "block LU: bandwidth %d needs %.1f GB of inverted Schur blocks (%.1f GB free); use ILU(k)", bw,
+        return lsa_set_error(ctx, LSA_ERR_OOM, "block LU: bandwidth %d needs %.1f GB of inverted Schur blocks (%.1f GB free); use ILU(k)", bw,
                              inv_bytes / 1e9, free_b / 1e9);
     // FNV-1a over the host pattern: the key of the per-context cache
     uint64_t hash = 1469598103934665603ull;
@@ -1300,7 +1300,7 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
         f->want_absorb = absorb;
         if (!blu_setup(ctx, f, C)) {
             blu_free(f);
-            return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_blu_create: out of device memory");
+            return lsa_set_error(ctx, LSA_ERR_OOM, "lsa_blu_create: out of device memory");
         }
     }
     if (getenv("LSA_BLU_TIMING")) fprintf(stderr, "[lsa_blu] symbolic setup + allocation + upload %.1f ms%s\n", (now_s() - t0) * 1e3, reused ? " (cached)" : "");

@@ -99,8 +99,10 @@ struct lsa_ctx {
     // the last destroyed block LU (symbolic data + buffers), reused when the next one has the same pattern and shape:
     // a shift sweep refactorises the same pattern once per sigma (.examples/eigenvalues.py:97-108)
     struct lsa_blu* blu_cache = nullptr;
+    struct lsa_ndlu* nd_cache = nullptr;  // the same for the nested-dissection LU (analysis + tables + buffers)
 };
-extern "C" void lsa_blu_drop_cache(lsa_ctx* ctx);  // blocklu.hip (internal; not part of include/lsa_hip.h)
+extern "C" void lsa_blu_drop_cache(lsa_ctx* ctx);   // blocklu.hip (internal; not part of include/lsa_hip.h)
+extern "C" void lsa_ndlu_drop_cache(lsa_ctx* ctx);  // ndlu.hip
 
 struct lsa_vec {
     lsa_ctx* ctx;
@@ -137,6 +139,17 @@ int lsa_ensure_scratch(lsa_ctx* ctx, size_t dbytes, size_t hbytes);
         if (_e != hipSuccess)                                                                            \
             return lsa_set_error((ctx), LSA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                                  __FILE__, __LINE__);                                                    \
+    } while (0)
+
+// allocations: out of memory is its own status (callers may fall back to a leaner method; nothing else may)
+#define LSA_HIP_ALLOC(ctx, expr)                                                                                    \
+    do {                                                                                                            \
+        hipError_t _e = (expr);                                                                                     \
+        if (_e != hipSuccess) {                                                                                     \
+            (void)hipGetLastError();                                                                                \
+            return lsa_set_error((ctx), _e == hipErrorOutOfMemory ? LSA_ERR_OOM : LSA_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                                 hipGetErrorString(_e), __FILE__, __LINE__);                                        \
+        }                                                                                                           \
     } while (0)
 
 #define LSA_CHECK(expr)            \
@@ -205,3 +218,7 @@ int ilu_solve_dev(lsa_ctx* ctx, lsa_ilu* pc, int which, int vdtype, const void* 
 int blk_setup(lsa_ctx* ctx, lsa_ilu* pc, int32_t B);
 int blk_solve(lsa_ctx* ctx, lsa_ilu* pc, int which, int vdtype, const void* b, void* x);
 void blk_release(lsa_ilu* pc);
+
+// ---- nested-dissection multifrontal LU (ndlu.hip) -------------------------------------------------------
+struct lsa_ndlu;
+int ndlu_solve_dev(lsa_ctx* ctx, lsa_ndlu* f, int vdtype, const void* b, void* x);

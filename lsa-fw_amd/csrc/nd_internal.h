@@ -1,0 +1,47 @@
+// Nested-dissection multifrontal LU: the analysis result shared by nd_symbolic.hip (host) and ndlu.hip (device).
+//
+// Elimination tree of supernodes ("tree nodes") from recursive graph bisection.  Node t owns m_t unknowns (a leaf
+// subdomain or a separator) and has a boundary of b_t unknowns that belong to its ancestors; its front is the dense
+// (m_t + b_t)^2 matrix over idx_t = [own | boundary].  Nodes are numbered in post-order, so children precede parents.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+struct NdSymbolic {
+    int32_t n = 0;
+    int64_t nnz = 0;
+    uint64_t pattern_hash = 0;
+    int32_t leaf_size = 0;
+    int32_t nt = 0;       // tree nodes
+    int32_t nlevels = 0;  // height of the forest + 1
+    std::vector<int32_t> perm;        // elimination order: perm[k] = original index of the k-th eliminated unknown
+    std::vector<int32_t> node_start;  // nt + 1: node t owns perm[node_start[t] .. node_start[t + 1])
+    std::vector<int32_t> parent;      // nt, -1 for roots
+    std::vector<int32_t> level;       // nt: 0 for leaves, 1 + max(children) otherwise
+    std::vector<int32_t> m, f;        // nt: own size, front size (boundary b = f - m)
+    std::vector<int64_t> idx_off;     // nt + 1 offsets into idx
+    std::vector<int32_t> idx;         // concatenated front index lists in ORIGINAL numbering: own (elimination order), then
+                                      // boundary sorted by elimination position
+    std::vector<int64_t> front_off;   // nt + 1 offsets (scalars) into the front buffer, f_t^2 each
+    std::vector<int32_t> child_ptr, child_idx;  // children of every node
+    std::vector<int32_t> cmap_off;    // nt + 1 offsets into cmap
+    std::vector<int32_t> cmap;        // for node t: position in parent(t)'s front of each of t's b boundary unknowns
+    std::vector<int64_t> u_off;       // nt + 1 offsets into the update-vector buffer (b_t each)
+    // forward-solve gather lists: front position j of node t sums ubuf[gidx[g]] for g in [gptr[g_off[t] + j], gptr[g_off[t] + j + 1])
+    std::vector<int64_t> g_off;       // nt + 1 offsets into gptr (f_t + 1 entries per node)
+    std::vector<int32_t> gptr, gidx;
+    // assembly of the original entries: front_buffer[asm_dst[e]] = values[asm_src[e]]
+    std::vector<int32_t> asm_src;
+    std::vector<int64_t> asm_dst;
+    // nodes sorted by (level, own size descending): lvl_nodes[lvl_ptr[l] .. lvl_ptr[l + 1])
+    std::vector<int32_t> lvl_ptr, lvl_nodes;
+    int32_t max_children = 0;
+    int64_t factor_entries = 0;  // sum of m^2 + 2 m b: the scalars one solve reads
+    int64_t front_entries = 0;   // sum of f^2
+    double flops = 0.0;          // multiply-adds (scalar) of the numeric factorisation
+};
+
+// Analysis of a square pattern (CSR, any order, need not be structurally symmetric).  Returns 0 or a negative lsa_status.
+int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, NdSymbolic* out, char* err, int errlen);
+uint64_t nd_pattern_hash(int32_t n, const int32_t* rp, const int32_t* ci);

@@ -1,0 +1,928 @@
+// Nested-dissection multifrontal LU on the device: the exact factorisation behind PreconditionerType.LU, the setting of
+// the reference's cylinder runs for the ST's KSP (.examples/eigenvalues.py:100; Sensitivity/__init__.py:182,260).
+//
+// Layout (analysis: nd_symbolic.hip).  Every tree node t keeps its dense front F_t (f x f, row-major, f = m + b) resident
+// in HBM; after the factorisation it holds
+//     F11 <- F11^-1           (m x m, explicit inverse: Gauss-Jordan, pivot search over the whole column of the block)
+//     F21 <- -F21 F11^-1      (b x m)
+//     F12 <-  F11^-1 F12      (m x b)
+//     F22 <-  F22 - F21 F11^-1 F12   (the update matrix the parent added to its own front)
+// so that a solve is two sweeps over the tree in which every node is ONE dense mat-vec per sweep:
+//     up   (leaves -> roots):  v = b[own] + children's updates;  y[own] = F11 v;  update_t = v[boundary-part] + F21 v
+//     down (roots -> leaves):  x[own] = y[own] - F12 x[boundary]
+// All nodes of a tree level run in one launch: 2 * (levels) dependent launches per solve (20 at 30 k unknowns) instead of
+// the O(n / B) block steps of a banded elimination, and sum(m^2 + 2 m b) scalars instead of n * bandwidth.
+//
+// Pivoting: rows are chosen by magnitude inside the pivot block of each front and never physically interchanged (the
+// permutation is undone once, when the inverse is gathered).  A pivot below 1e-13 * max|C| is reported as
+// LSA_ERR_ZERO_PIVOT; the operator layer (solver.hip) verifies every solve against b - C x.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <functional>
+#include <new>
+
+#include "lsa_internal.h"
+#include "nd_internal.h"
+
+namespace {
+
+constexpr int kW = 8;        // pivot columns per panel
+constexpr int kUpdCols = 16; // columns of one update tile
+constexpr int kRT = 32;      // front rows per solve tile
+constexpr int kCH = 1024;    // vector entries staged in LDS per pass of a solve tile
+constexpr int kGT = 64;      // GEMM tile edge
+
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline size_t esize(int dtype) { return dtype == LSA_C128 ? 16 : 8; }
+
+struct NdNodeDev {
+    int64_t front_off;  // scalars into the front buffer
+    int64_t scr_off;    // scalars into the level scratch: [m*m | b*m | m*b]
+    int64_t u_off;      // into the update-vector buffer (b entries)
+    int64_t g_off;      // into gptr (f + 1 entries)
+    int32_t idx_off;    // into idx (f entries)
+    int32_t cmap_off;   // into cmap (b entries)
+    int32_t piv_off;    // into ipiv / rowq (m entries)
+    int32_t m, f, parent;
+    int32_t pad0, pad1;
+};
+
+struct TileList {
+    int64_t off = 0;  // pairs of int32 into the tile buffer
+    int32_t count = 0;
+};
+
+struct NdLevel {
+    int32_t node_begin = 0, node_count = 0, max_m = 0;
+    std::vector<int32_t> sorted_m;          // own sizes of the level's nodes (descending)
+    std::vector<int32_t> upd_tile_prefix;   // update tiles of the first k nodes
+    TileList upd, unperm, gemm[3], copyback, fwd, bwd;
+    std::vector<TileList> ext;  // one per child rank
+    int64_t scratch = 0;
+};
+
+template <typename T>
+__global__ void nd_maxabs2_kernel(int64_t nnz, const T* __restrict__ v, unsigned long long* __restrict__ out) {
+    double best = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
+        const double a = s_abs2(v[i]);
+        if (a == a && a > best) best = a;
+    }
+    for (int o = 32; o > 0; o >>= 1) best = fmax(best, __shfl_xor(best, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(best));
+}
+
+template <typename T>
+__global__ void nd_assemble_kernel(int64_t nnz, const T* __restrict__ val, const int64_t* __restrict__ dst, T* __restrict__ front) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) front[dst[e]] = val[e];
+}
+
+// parent front += child's update matrix (tile = 16 rows of the child's boundary block)
+template <typename T>
+__global__ __launch_bounds__(256) void nd_extend_add_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
+                                                            const int32_t* __restrict__ cmap, T* __restrict__ front) {
+    const int32_t c = tiles[2 * blockIdx.x], i0 = tiles[2 * blockIdx.x + 1];
+    const NdNodeDev nc = nodes[c];
+    const NdNodeDev np = nodes[nc.parent];
+    const int32_t b = nc.f - nc.m;
+    const int32_t* map = cmap + nc.cmap_off;
+    const int32_t i = i0 + (threadIdx.x >> 4);
+    if (i >= b) return;
+    const T* src = front + nc.front_off + (int64_t)(nc.m + i) * nc.f + nc.m;
+    T* dst = front + np.front_off + (int64_t)map[i] * np.f;
+    for (int32_t j = threadIdx.x & 15; j < b; j += 16) {
+        T* d = dst + map[j];
+        *d = s_add(*d, src[j]);
+    }
+}
+
+// max of a 64-bit key over the wavefront (butterfly through LDS-free shuffles)
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v & 0xFFFFFFFFull), o);
+        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o);
+        const unsigned long long ov = ((unsigned long long)hi << 32) | lo;
+        v = ov > v ? ov : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ unsigned long long pivot_key(double mag2, int32_t row) {
+    // |a|^2 with its low 16 mantissa bits replaced by (65535 - row): one unsigned max picks the largest magnitude and,
+    // among magnitudes equal to 2^-36 relative, the lowest row (deterministic)
+    return ((unsigned long long)__double_as_longlong(mag2) & ~0xFFFFull) | (unsigned long long)(65535 - row);
+}
+
+// Gauss-Jordan elimination of panel p (columns [k0, k0 + w)) of the pivot blocks of a level: one workgroup per node,
+// thread per row (RPT rows per thread), the panel's columns in registers.  Rows are not interchanged: a row that has
+// served as a pivot is excluded from later searches (rowq), the permutation is undone by nd_unperm_kernel.
+template <typename T, int NT, int RPT>
+__global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
+                                                         T* __restrict__ front, int32_t* __restrict__ ipiv, int32_t* __restrict__ rowq,
+                                                         int32_t k0, int32_t* __restrict__ flag, double tiny2) {
+    __shared__ unsigned long long skey[kW];
+    __shared__ T prow_s[2][kW];
+    const int32_t t = lvl_nodes[blockIdx.x];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, ld = nd.f;
+    const int32_t w = min(kW, m - k0);
+    if (w <= 0) return;
+    T* a = front + nd.front_off;
+    int32_t* piv = ipiv + nd.piv_off;
+    int32_t* rq = rowq + nd.piv_off;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < kW) skey[tid] = 0ull;
+    T r[RPT][kW];
+    bool used[RPT];
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int32_t i = tid + NT * q;
+        used[q] = i >= m || rq[min(i, m - 1)] >= 0;
+#pragma unroll
+        for (int c = 0; c < kW; ++c) r[q][c] = (i < m && c < w) ? a[(size_t)i * ld + k0 + c] : scalar_traits<T>::zero();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int jj = 0; jj < kW; ++jj) {
+        if (jj >= w) break;
+        unsigned long long key = 0ull;
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            if (!used[q]) {
+                const unsigned long long kq = pivot_key(s_abs2(r[q][jj]), tid + NT * q);
+                key = kq > key ? kq : key;
+            }
+        }
+        key = wave_max_key(key);
+        if (lane == 0) atomicMax(&skey[jj], key);
+        __syncthreads();
+        key = skey[jj];
+        const int32_t p = 65535 - (int32_t)(key & 0xFFFFull);
+        if (tid == 0) {
+            piv[k0 + jj] = p;
+            if (!(__longlong_as_double((long long)(key & ~0xFFFFull)) > tiny2)) atomicCAS(&flag[1], 0, t + 1);
+        }
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            if (tid + NT * q == p) {
+                T pv = r[q][jj];
+                if (s_abs2(pv) == 0.0) s_from(pv, 1.0, 0.0);
+                const T pinv = s_inv(pv);
+#pragma unroll
+                for (int j = 0; j < kW; ++j) {
+                    const T v = (j == jj) ? pinv : s_mul(pinv, r[q][j]);
+                    prow_s[jj & 1][j] = v;
+                    r[q][j] = v;
+                }
+                used[q] = true;
+                rq[p] = k0 + jj;
+            }
+        }
+        __syncthreads();
+        T prow[kW];
+#pragma unroll
+        for (int j = 0; j < kW; ++j) prow[j] = prow_s[jj & 1][j];
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int32_t i = tid + NT * q;
+            if (i >= m || i == p) continue;
+            const T fm = r[q][jj];
+            if (s_abs2(fm) == 0.0) continue;
+            const T nfm = s_sub(scalar_traits<T>::zero(), fm);
+            r[q][jj] = scalar_traits<T>::zero();
+#pragma unroll
+            for (int j = 0; j < kW; ++j) fma_acc(r[q][j], nfm, prow[j]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < RPT; ++q) {
+        const int32_t i = tid + NT * q;
+        if (i < m) {
+#pragma unroll
+            for (int j = 0; j < kW; ++j)
+                if (j < w) a[(size_t)i * ld + k0 + j] = r[q][j];
+        }
+    }
+}
+
+// the same elimination for pivot blocks of more than 2048 rows: the panel stays in memory (L2), rows are walked
+template <typename T>
+__global__ __launch_bounds__(1024) void nd_gj_panel_big_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
+                                                               T* __restrict__ front, int32_t* __restrict__ ipiv, int32_t* __restrict__ rowq,
+                                                               int32_t k0, int32_t* __restrict__ flag, double tiny2) {
+    __shared__ unsigned long long skey[kW];
+    __shared__ T prow_s[kW];
+    const int32_t t = lvl_nodes[blockIdx.x];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, ld = nd.f;
+    const int32_t w = min(kW, m - k0);
+    if (w <= 0) return;
+    T* a = front + nd.front_off;
+    int32_t* piv = ipiv + nd.piv_off;
+    int32_t* rq = rowq + nd.piv_off;
+    const int tid = threadIdx.x, lane = tid & 63;
+    if (tid < kW) skey[tid] = 0ull;
+    __syncthreads();
+    for (int jj = 0; jj < w; ++jj) {
+        unsigned long long key = 0ull;
+        for (int32_t i = tid; i < m; i += 1024) {
+            if (__hip_atomic_load(&rq[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 0) continue;
+            const unsigned long long kq = pivot_key(s_abs2(a[(size_t)i * ld + k0 + jj]), i);
+            key = kq > key ? kq : key;
+        }
+        key = wave_max_key(key);
+        if (lane == 0) atomicMax(&skey[jj], key);
+        __syncthreads();
+        key = skey[jj];
+        const int32_t p = 65535 - (int32_t)(key & 0xFFFFull);
+        if (tid == 0) {
+            piv[k0 + jj] = p;
+            if (!(__longlong_as_double((long long)(key & ~0xFFFFull)) > tiny2)) atomicCAS(&flag[1], 0, t + 1);
+            __hip_atomic_store(&rq[p], k0 + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (tid < w) {
+            T pv = a[(size_t)p * ld + k0 + jj];
+            if (s_abs2(pv) == 0.0) s_from(pv, 1.0, 0.0);
+            const T pinv = s_inv(pv);
+            prow_s[tid] = (tid == jj) ? pinv : s_mul(pinv, a[(size_t)p * ld + k0 + tid]);
+        }
+        __syncthreads();
+        T prow[kW];
+#pragma unroll
+        for (int j = 0; j < kW; ++j) prow[j] = j < w ? prow_s[j] : scalar_traits<T>::zero();
+        for (int32_t i = tid; i < m; i += 1024) {
+            T* ai = a + (size_t)i * ld + k0;
+            if (i == p) {
+                for (int j = 0; j < w; ++j) ai[j] = prow[j];
+                continue;
+            }
+            const T fm = ai[jj];
+            if (s_abs2(fm) == 0.0) continue;
+            const T nfm = s_sub(scalar_traits<T>::zero(), fm);
+            ai[jj] = scalar_traits<T>::zero();
+            for (int j = 0; j < w; ++j) {
+                T v = ai[j];
+                fma_acc(v, nfm, prow[j]);
+                ai[j] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// rank-w update of the columns outside the panel: A[i, J] = (i is one of the panel's pivot rows ? 0 : A[i, J]) + W[i, :] Y,
+// Y = the pivot rows' old values in J, W = the eliminated panel.  A workgroup owns kUpdCols columns for all rows.
+template <typename T>
+__global__ __launch_bounds__(256) void nd_gj_update_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
+                                                           T* __restrict__ front, const int32_t* __restrict__ ipiv, int32_t k0) {
+    __shared__ T Y[kW][kUpdCols];
+    __shared__ int32_t prow_s[kW];
+    const int32_t t = tiles[2 * blockIdx.x], c0 = tiles[2 * blockIdx.x + 1];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, ld = nd.f;
+    const int32_t w = min(kW, m - k0);
+    if (w <= 0) return;
+    T* a = front + nd.front_off;
+    const int tid = threadIdx.x;
+    const int32_t c = c0 + (tid & 15);
+    const bool live = c < m && (c < k0 || c >= k0 + w);
+    if (tid < kW) prow_s[tid] = tid < w ? ipiv[nd.piv_off + k0 + tid] : -1;
+    __syncthreads();
+    if (tid < kW * kUpdCols) {
+        const int j = tid >> 4;
+        if (j < w && live) Y[j][tid & 15] = a[(size_t)prow_s[j] * ld + c];
+        else Y[j][tid & 15] = scalar_traits<T>::zero();
+    }
+    __syncthreads();
+    int32_t pr[kW];
+    T y[kW];
+#pragma unroll
+    for (int j = 0; j < kW; ++j) {
+        pr[j] = prow_s[j];
+        y[j] = Y[j][tid & 15];
+    }
+    if (!live) return;
+#pragma unroll 4
+    for (int32_t i = tid >> 4; i < m; i += 16) {
+        T* ai = a + (size_t)i * ld;
+        bool is_piv = false;
+#pragma unroll
+        for (int j = 0; j < kW; ++j) is_piv |= (i == pr[j]);
+        T acc = is_piv ? scalar_traits<T>::zero() : ai[c];
+#pragma unroll
+        for (int j = 0; j < kW; ++j)
+            if (j < w) fma_acc(acc, ai[k0 + j], y[j]);
+        ai[c] = acc;
+    }
+}
+
+// inverse gathered out of the eliminated block: inv[a][b] = S[p_a][q_b]  (p = pivot row of column a, q = its inverse)
+template <typename T>
+__global__ __launch_bounds__(256) void nd_unperm_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
+                                                        const T* __restrict__ front, const int32_t* __restrict__ ipiv,
+                                                        const int32_t* __restrict__ rowq, T* __restrict__ scratch) {
+    const int32_t t = tiles[2 * blockIdx.x], r0 = tiles[2 * blockIdx.x + 1];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, ld = nd.f;
+    const int32_t ra = r0 + (threadIdx.x >> 4);
+    if (ra >= m) return;
+    const T* src = front + nd.front_off + (size_t)ipiv[nd.piv_off + ra] * ld;
+    T* dst = scratch + nd.scr_off + (size_t)ra * m;
+    const int32_t* q = rowq + nd.piv_off;
+    for (int32_t cb = threadIdx.x & 15; cb < m; cb += 16) dst[cb] = src[q[cb]];
+}
+
+// batched dense products of a level (row-major, 64 x 64 tiles, 4 x 4 per thread):
+//   KIND 0:  S1 = -F21 inv        (b x m)      KIND 1:  F22 += S1 F12   (b x b)      KIND 2:  S2 = inv F12   (m x b)
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void nd_gemm_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
+                                                      T* __restrict__ front, T* __restrict__ scratch) {
+    constexpr int BK = 8;
+    __shared__ T As[BK][kGT + 1];
+    __shared__ T Bs[BK][kGT + 1];
+    const int32_t t = tiles[2 * blockIdx.x], packed = tiles[2 * blockIdx.x + 1];
+    const int32_t tm = packed >> 16, tn = packed & 0xFFFF;
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, f = nd.f, b = f - m;
+    T* F = front + nd.front_off;
+    T* inv = scratch + nd.scr_off;
+    T* S1 = inv + (size_t)m * m;
+    T* S2 = S1 + (size_t)b * m;
+    const T *A, *B;
+    T* C;
+    int32_t M, N, K, lda, ldb, ldc;
+    if (KIND == 0) {
+        A = F + (size_t)m * f, lda = f, B = inv, ldb = m, C = S1, ldc = m, M = b, N = m, K = m;
+    } else if (KIND == 1) {
+        A = S1, lda = m, B = F + m, ldb = f, C = F + (size_t)m * f + m, ldc = f, M = b, N = b, K = m;
+    } else {
+        A = inv, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = m, N = b, K = m;
+    }
+    const int32_t row0 = tm * kGT, col0 = tn * kGT;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    T acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = scalar_traits<T>::zero();
+    for (int32_t kk = 0; kk < K; kk += BK) {
+        // A tile: 64 rows x 8 k (2 per thread); B tile: 8 k x 64 cols (2 per thread)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int e = tid + 256 * s;
+            const int ar = e >> 3, ak = e & 7;
+            const int32_t gr = row0 + ar, gk = kk + ak;
+            As[ak][ar] = (gr < M && gk < K) ? A[(size_t)gr * lda + gk] : scalar_traits<T>::zero();
+            const int bk = e >> 6, bc = e & 63;
+            const int32_t gk2 = kk + bk, gc = col0 + bc;
+            Bs[bk][bc] = (gk2 < K && gc < N) ? B[(size_t)gk2 * ldb + gc] : scalar_traits<T>::zero();
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BK; ++k) {
+            T av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = As[k][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = Bs[k][tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fma_acc(acc[i][j], av[i], bv[j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int32_t gr = row0 + ty * 4 + i;
+        if (gr >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t gc = col0 + tx + 16 * j;
+            if (gc >= N) continue;
+            T* c = C + (size_t)gr * ldc + gc;
+            if (KIND == 0) *c = s_sub(scalar_traits<T>::zero(), acc[i][j]);
+            else if (KIND == 1) *c = s_add(*c, acc[i][j]);
+            else *c = acc[i][j];
+        }
+    }
+}
+
+// F11 <- inv, F21 <- S1, F12 <- S2  (tile = 16 front rows)
+template <typename T>
+__global__ __launch_bounds__(256) void nd_copyback_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
+                                                          T* __restrict__ front, const T* __restrict__ scratch) {
+    const int32_t t = tiles[2 * blockIdx.x], r0 = tiles[2 * blockIdx.x + 1];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, f = nd.f, b = f - m;
+    const int32_t r = r0 + (threadIdx.x >> 4);
+    if (r >= f) return;
+    const T* inv = scratch + nd.scr_off;
+    const T* S1 = inv + (size_t)m * m;
+    const T* S2 = S1 + (size_t)b * m;
+    T* dst = front + nd.front_off + (size_t)r * f;
+    if (r < m) {
+        for (int32_t c = threadIdx.x & 15; c < m; c += 16) dst[c] = inv[(size_t)r * m + c];
+        for (int32_t c = threadIdx.x & 15; c < b; c += 16) dst[m + c] = S2[(size_t)r * b + c];
+    } else {
+        for (int32_t c = threadIdx.x & 15; c < m; c += 16) dst[c] = S1[(size_t)(r - m) * m + c];
+    }
+}
+
+template <typename VT>
+__device__ __forceinline__ VT sub16_sum(VT v) {
+    for (int o = 8; o > 0; o >>= 1) {
+        if constexpr (sizeof(VT) == 16) {
+            v.re += __shfl_xor(v.re, o);
+            v.im += __shfl_xor(v.im, o);
+        } else {
+            v += __shfl_xor(v, o);
+        }
+    }
+    return v;
+}
+
+// upward sweep, one tree level: tile = kRT rows of a node's [F11; F21] block column
+template <typename MT, typename VT>
+__global__ __launch_bounds__(256) void nd_fwd_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
+                                                     const MT* __restrict__ front, const int32_t* __restrict__ idx,
+                                                     const int32_t* __restrict__ gptr, const int32_t* __restrict__ gidx,
+                                                     const VT* __restrict__ rhs, VT* __restrict__ x, VT* __restrict__ ubuf) {
+    __shared__ VT vs[kCH];
+    const int32_t t = tiles[2 * blockIdx.x], r0 = tiles[2 * blockIdx.x + 1];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, f = nd.f;
+    const int32_t* ix = idx + nd.idx_off;
+    const int32_t* gp = gptr + nd.g_off;
+    const MT* F = front + nd.front_off;
+    const int tid = threadIdx.x, sw = tid >> 4, sl = tid & 15;
+    const int32_t ra = r0 + sw, rb = r0 + sw + 16;
+    VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
+    for (int32_t c0 = 0; c0 < m; c0 += kCH) {
+        const int32_t cn = min(kCH, m - c0);
+        for (int32_t j = tid; j < cn; j += 256) {
+            VT v = rhs[ix[c0 + j]];
+            for (int32_t g = gp[c0 + j]; g < gp[c0 + j + 1]; ++g) v = s_add(v, ubuf[gidx[g]]);
+            vs[j] = v;
+        }
+        __syncthreads();
+        if (ra < f) {
+            const MT* Fa = F + (size_t)ra * f + c0;
+            for (int32_t k = sl; k < cn; k += 16) fma_acc(acc0, Fa[k], vs[k]);
+        }
+        if (rb < f) {
+            const MT* Fb = F + (size_t)rb * f + c0;
+            for (int32_t k = sl; k < cn; k += 16) fma_acc(acc1, Fb[k], vs[k]);
+        }
+        __syncthreads();
+    }
+    acc0 = sub16_sum(acc0);
+    acc1 = sub16_sum(acc1);
+    if (sl == 0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int32_t r = h ? rb : ra;
+            VT a = h ? acc1 : acc0;
+            if (r >= f) continue;
+            if (r < m) x[ix[r]] = a;
+            else {
+                for (int32_t g = gp[r]; g < gp[r + 1]; ++g) a = s_add(a, ubuf[gidx[g]]);
+                ubuf[nd.u_off + (r - m)] = a;
+            }
+        }
+    }
+}
+
+// downward sweep, one tree level: x[own] -= F12 x[boundary]
+template <typename MT, typename VT>
+__global__ __launch_bounds__(256) void nd_bwd_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
+                                                     const MT* __restrict__ front, const int32_t* __restrict__ idx, VT* __restrict__ x) {
+    __shared__ VT vs[kCH];
+    const int32_t t = tiles[2 * blockIdx.x], r0 = tiles[2 * blockIdx.x + 1];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, f = nd.f, b = f - m;
+    const int32_t* ix = idx + nd.idx_off;
+    const MT* F = front + nd.front_off + m;
+    const int tid = threadIdx.x, sw = tid >> 4, sl = tid & 15;
+    const int32_t ra = r0 + sw, rb = r0 + sw + 16;
+    VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
+    for (int32_t c0 = 0; c0 < b; c0 += kCH) {
+        const int32_t cn = min(kCH, b - c0);
+        for (int32_t j = tid; j < cn; j += 256) vs[j] = x[ix[m + c0 + j]];
+        __syncthreads();
+        if (ra < m) {
+            const MT* Fa = F + (size_t)ra * f + c0;
+            for (int32_t k = sl; k < cn; k += 16) fma_acc(acc0, Fa[k], vs[k]);
+        }
+        if (rb < m) {
+            const MT* Fb = F + (size_t)rb * f + c0;
+            for (int32_t k = sl; k < cn; k += 16) fma_acc(acc1, Fb[k], vs[k]);
+        }
+        __syncthreads();
+    }
+    acc0 = sub16_sum(acc0);
+    acc1 = sub16_sum(acc1);
+    if (sl == 0) {
+        if (ra < m) x[ix[ra]] = s_sub(x[ix[ra]], acc0);
+        if (rb < m) x[ix[rb]] = s_sub(x[ix[rb]], acc1);
+    }
+}
+
+}  // namespace
+
+struct lsa_ndlu {
+    lsa_ctx* ctx = nullptr;
+    NdSymbolic S;
+    int dtype = LSA_C128;
+    std::vector<NdLevel> levels;
+    NdNodeDev* d_nodes = nullptr;
+    int32_t *d_idx = nullptr, *d_cmap = nullptr, *d_gptr = nullptr, *d_gidx = nullptr, *d_tiles = nullptr, *d_lvl_nodes = nullptr;
+    int64_t* d_asm_dst = nullptr;
+    int32_t *d_ipiv = nullptr, *d_rowq = nullptr, *d_flag = nullptr;
+    unsigned long long* d_maxabs = nullptr;
+    void *d_front = nullptr, *d_scratch = nullptr, *d_ubuf = nullptr, *d_tmp = nullptr;
+    double seconds_analyse = 0.0, seconds_numeric = 0.0;
+    int32_t solve_launches = 0;
+};
+
+namespace {
+
+void nd_free(lsa_ndlu* f) {
+    if (!f) return;
+    for (void* p : {(void*)f->d_nodes, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_gptr, (void*)f->d_gidx, (void*)f->d_tiles,
+                    (void*)f->d_lvl_nodes, (void*)f->d_asm_dst, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_maxabs,
+                    f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp})
+        if (p) (void)hipFree(p);
+    delete f;
+}
+
+template <typename U>
+int upload(lsa_ctx* ctx, const std::vector<U>& h, U** d) {
+    const size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(U);
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)d, bytes));
+    if (!h.empty()) LSA_HIP_CHECK(ctx, hipMemcpy(*d, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice));
+    return LSA_OK;
+}
+
+// device tables + tile lists from the analysis
+int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
+    const NdSymbolic& S = f->S;
+    const int32_t nt = S.nt;
+    std::vector<NdNodeDev> nodes((size_t)nt);
+    std::vector<int32_t> tiles;
+    f->levels.assign((size_t)S.nlevels, NdLevel());
+    auto begin_list = [&](TileList& tl) { tl.off = (int64_t)tiles.size() / 2; tl.count = 0; };
+    auto push = [&](TileList& tl, int32_t a, int32_t b) {
+        tiles.push_back(a);
+        tiles.push_back(b);
+        ++tl.count;
+    };
+    // rank of every node among its parent's children
+    std::vector<int32_t> rank((size_t)nt, 0);
+    for (int32_t t = 0; t < nt; ++t)
+        for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) rank[(size_t)S.child_idx[(size_t)cp]] = cp - S.child_ptr[(size_t)t];
+    int64_t max_scratch = 1;
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+        NdLevel& L = f->levels[(size_t)l];
+        L.node_begin = S.lvl_ptr[(size_t)l];
+        L.node_count = S.lvl_ptr[(size_t)l + 1] - L.node_begin;
+        int64_t scr = 0;
+        int32_t lvl_children = 0;
+        for (int32_t q = 0; q < L.node_count; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+            const int64_t m = S.m[(size_t)t], ff = S.f[(size_t)t], b = ff - m;
+            NdNodeDev& nd = nodes[(size_t)t];
+            nd.front_off = S.front_off[(size_t)t];
+            nd.scr_off = scr;
+            nd.u_off = S.u_off[(size_t)t];
+            nd.g_off = S.g_off[(size_t)t];
+            nd.idx_off = (int32_t)S.idx_off[(size_t)t];
+            nd.cmap_off = S.cmap_off[(size_t)t];
+            nd.piv_off = S.node_start[(size_t)t];
+            nd.m = (int32_t)m;
+            nd.f = (int32_t)ff;
+            nd.parent = S.parent[(size_t)t];
+            nd.pad0 = nd.pad1 = 0;
+            scr += m * m + 2 * m * b;
+            L.max_m = std::max(L.max_m, (int32_t)m);
+            L.sorted_m.push_back((int32_t)m);
+            lvl_children = std::max(lvl_children, S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t]);
+        }
+        L.scratch = scr;
+        max_scratch = std::max(max_scratch, scr);
+        // extend-add: one list per child rank (children of one parent never share a launch)
+        L.ext.assign((size_t)lvl_children, TileList());
+        for (int32_t r = 0; r < lvl_children; ++r) {
+            begin_list(L.ext[(size_t)r]);
+            for (int32_t q = 0; q < L.node_count; ++q) {
+                const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+                if (S.child_ptr[(size_t)t] + r >= S.child_ptr[(size_t)t + 1]) continue;
+                const int32_t c = S.child_idx[(size_t)S.child_ptr[(size_t)t] + r];
+                const int32_t bc = S.f[(size_t)c] - S.m[(size_t)c];
+                for (int32_t i0 = 0; i0 < bc; i0 += 16) push(L.ext[(size_t)r], c, i0);
+            }
+        }
+        begin_list(L.upd);
+        L.upd_tile_prefix.assign(1, 0);
+        for (int32_t q = 0; q < L.node_count; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+            for (int32_t c0 = 0; c0 < S.m[(size_t)t]; c0 += kUpdCols) push(L.upd, t, c0);
+            L.upd_tile_prefix.push_back(L.upd.count);
+        }
+        begin_list(L.unperm);
+        for (int32_t q = 0; q < L.node_count; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+            for (int32_t r0 = 0; r0 < S.m[(size_t)t]; r0 += 16) push(L.unperm, t, r0);
+        }
+        for (int kind = 0; kind < 3; ++kind) {
+            begin_list(L.gemm[kind]);
+            for (int32_t q = 0; q < L.node_count; ++q) {
+                const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+                const int32_t m = S.m[(size_t)t], b = S.f[(size_t)t] - m;
+                if (b == 0) continue;
+                const int32_t M = kind == 2 ? m : b, N = kind == 0 ? m : b;
+                for (int32_t tm = 0; tm * kGT < M; ++tm)
+                    for (int32_t tn = 0; tn * kGT < N; ++tn) push(L.gemm[kind], t, (tm << 16) | tn);
+            }
+        }
+        begin_list(L.fwd);
+        for (int32_t q = 0; q < L.node_count; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+            for (int32_t r0 = 0; r0 < S.f[(size_t)t]; r0 += kRT) push(L.fwd, t, r0);
+        }
+        begin_list(L.bwd);
+        for (int32_t q = 0; q < L.node_count; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+            if (S.f[(size_t)t] == S.m[(size_t)t]) continue;
+            for (int32_t r0 = 0; r0 < S.m[(size_t)t]; r0 += kRT) push(L.bwd, t, r0);
+        }
+        begin_list(L.copyback);
+        for (int32_t q = 0; q < L.node_count; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+            for (int32_t r0 = 0; r0 < S.f[(size_t)t]; r0 += 16) push(L.copyback, t, r0);
+        }
+        if (L.max_m > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a pivot block of %d rows exceeds the 65 535 the pivot key encodes", L.max_m);
+    }
+    LSA_CHECK(upload(ctx, nodes, &f->d_nodes));
+    LSA_CHECK(upload(ctx, S.idx, &f->d_idx));
+    LSA_CHECK(upload(ctx, S.cmap, &f->d_cmap));
+    LSA_CHECK(upload(ctx, S.gptr, &f->d_gptr));
+    LSA_CHECK(upload(ctx, S.gidx, &f->d_gidx));
+    LSA_CHECK(upload(ctx, S.asm_dst, &f->d_asm_dst));
+    LSA_CHECK(upload(ctx, S.lvl_nodes, &f->d_lvl_nodes));
+    LSA_CHECK(upload(ctx, tiles, &f->d_tiles));
+    const size_t es = esize(f->dtype);
+    const size_t nn = (size_t)std::max<int32_t>(S.n, 1);
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_ipiv, nn * sizeof(int32_t)));
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_rowq, nn * sizeof(int32_t)));
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_flag, 4 * sizeof(int32_t)));
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_maxabs, sizeof(unsigned long long)));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_front, (size_t)std::max<int64_t>(S.front_entries, 1) * es));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_scratch, (size_t)max_scratch * es));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ubuf, (size_t)std::max<int64_t>(S.u_off[(size_t)nt], 1) * 16));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_tmp, nn * 16));
+    f->solve_launches = 0;
+    for (const NdLevel& L : f->levels) f->solve_launches += (L.fwd.count > 0) + (L.bwd.count > 0);
+    return LSA_OK;
+}
+
+template <typename T, int NT, int RPT>
+void launch_panel(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t active, int32_t k0, double tiny2) {
+    hipLaunchKernelGGL((nd_gj_panel_kernel<T, NT, RPT>), dim3(active), dim3(NT), 0, ctx->stream, f->d_lvl_nodes + L.node_begin, f->d_nodes,
+                       (T*)f->d_front, f->d_ipiv, f->d_rowq, k0, f->d_flag, tiny2);
+}
+
+template <typename T>
+int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
+    const NdSymbolic& S = f->S;
+    hipStream_t st = ctx->stream;
+    T* front = (T*)f->d_front;
+    T* scratch = (T*)f->d_scratch;
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_front, 0, (size_t)std::max<int64_t>(S.front_entries, 1) * sizeof(T), st));
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_rowq, 0xFF, (size_t)std::max<int32_t>(S.n, 1) * sizeof(int32_t), st));
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_flag, 0, 4 * sizeof(int32_t), st));
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_maxabs, 0, sizeof(unsigned long long), st));
+    if (S.nnz > 0) {
+        const int blocks = (int)std::min<int64_t>((S.nnz + 255) / 256, (int64_t)ctx->num_cu * 16);
+        hipLaunchKernelGGL((nd_maxabs2_kernel<T>), dim3(blocks), dim3(256), 0, st, S.nnz, (const T*)C->val, f->d_maxabs);
+        hipLaunchKernelGGL((nd_assemble_kernel<T>), dim3(blocks), dim3(256), 0, st, S.nnz, (const T*)C->val, f->d_asm_dst, front);
+    }
+    unsigned long long mbits = 0;
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(&mbits, f->d_maxabs, sizeof mbits, hipMemcpyDeviceToHost, st));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    double max2;
+    memcpy(&max2, &mbits, sizeof max2);
+    if (!std::isfinite(max2)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "lsa_ndlu: the matrix holds non-finite values");
+    const double tiny2 = 1e-26 * max2;  // (1e-13 * max|C|)^2
+    const int32_t* tl = f->d_tiles;
+    for (const NdLevel& L : f->levels) {
+        for (const TileList& e : L.ext)
+            if (e.count > 0) hipLaunchKernelGGL((nd_extend_add_kernel<T>), dim3(e.count), dim3(256), 0, st, tl + 2 * e.off, f->d_nodes, f->d_cmap, front);
+        for (int32_t k0 = 0; k0 < L.max_m; k0 += kW) {
+            // nodes are sorted by own size: those that still have columns at k0 form a prefix
+            const int32_t active = (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), k0, std::greater<int32_t>()) - L.sorted_m.begin());
+            if (active == 0) break;
+            if (L.max_m <= 64) launch_panel<T, 64, 1>(ctx, f, L, active, k0, tiny2);
+            else if (L.max_m <= 128) launch_panel<T, 128, 1>(ctx, f, L, active, k0, tiny2);
+            else if (L.max_m <= 256) launch_panel<T, 256, 1>(ctx, f, L, active, k0, tiny2);
+            else if (L.max_m <= 512) launch_panel<T, 512, 1>(ctx, f, L, active, k0, tiny2);
+            else if (L.max_m <= 1024) launch_panel<T, 1024, 1>(ctx, f, L, active, k0, tiny2);
+            else if (L.max_m <= 2048) launch_panel<T, 1024, 2>(ctx, f, L, active, k0, tiny2);
+            else
+                hipLaunchKernelGGL((nd_gj_panel_big_kernel<T>), dim3(active), dim3(1024), 0, st, f->d_lvl_nodes + L.node_begin, f->d_nodes, front,
+                                   f->d_ipiv, f->d_rowq, k0, f->d_flag, tiny2);
+            const int32_t utiles = L.upd_tile_prefix[(size_t)active];
+            if (utiles > 0 && L.max_m > kW)
+                hipLaunchKernelGGL((nd_gj_update_kernel<T>), dim3(utiles), dim3(256), 0, st, tl + 2 * L.upd.off, f->d_nodes, front, f->d_ipiv, k0);
+        }
+        if (L.unperm.count > 0)
+            hipLaunchKernelGGL((nd_unperm_kernel<T>), dim3(L.unperm.count), dim3(256), 0, st, tl + 2 * L.unperm.off, f->d_nodes, front, f->d_ipiv,
+                               f->d_rowq, scratch);
+        if (L.gemm[0].count > 0)
+            hipLaunchKernelGGL((nd_gemm_kernel<T, 0>), dim3(L.gemm[0].count), dim3(256), 0, st, tl + 2 * L.gemm[0].off, f->d_nodes, front, scratch);
+        if (L.gemm[1].count > 0)
+            hipLaunchKernelGGL((nd_gemm_kernel<T, 1>), dim3(L.gemm[1].count), dim3(256), 0, st, tl + 2 * L.gemm[1].off, f->d_nodes, front, scratch);
+        if (L.gemm[2].count > 0)
+            hipLaunchKernelGGL((nd_gemm_kernel<T, 2>), dim3(L.gemm[2].count), dim3(256), 0, st, tl + 2 * L.gemm[2].off, f->d_nodes, front, scratch);
+        if (L.copyback.count > 0)
+            hipLaunchKernelGGL((nd_copyback_kernel<T>), dim3(L.copyback.count), dim3(256), 0, st, tl + 2 * L.copyback.off, f->d_nodes, front, scratch);
+    }
+    int32_t hflag[4] = {0, 0, 0, 0};
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(hflag, f->d_flag, sizeof hflag, hipMemcpyDeviceToHost, st));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    LSA_HIP_CHECK(ctx, hipGetLastError());
+    if (hflag[1] != 0) {
+        const int32_t t = hflag[1] - 1;
+        return lsa_set_error(ctx, LSA_ERR_ZERO_PIVOT,
+                             "lsa_ndlu: the pivot block of tree node %d (%d unknowns, level %d) is singular to 1e-13 * max|C|: the matrix is "
+                             "singular, or needs pivoting across fronts",
+                             t, S.m[(size_t)t], S.level[(size_t)t]);
+    }
+    return LSA_OK;
+}
+
+template <typename MT, typename VT>
+int nd_apply(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
+    hipStream_t st = ctx->stream;
+    const int32_t* tl = f->d_tiles;
+    const MT* front = (const MT*)f->d_front;
+    for (const NdLevel& L : f->levels)
+        if (L.fwd.count > 0)
+            hipLaunchKernelGGL((nd_fwd_kernel<MT, VT>), dim3(L.fwd.count), dim3(256), 0, st, tl + 2 * L.fwd.off, f->d_nodes, front, f->d_idx, f->d_gptr,
+                               f->d_gidx, b, x, (VT*)f->d_ubuf);
+    for (size_t l = f->levels.size(); l-- > 0;) {
+        const NdLevel& L = f->levels[l];
+        if (L.bwd.count > 0)
+            hipLaunchKernelGGL((nd_bwd_kernel<MT, VT>), dim3(L.bwd.count), dim3(256), 0, st, tl + 2 * L.bwd.off, f->d_nodes, front, f->d_idx, x);
+    }
+    LSA_HIP_CHECK(ctx, hipGetLastError());
+    return LSA_OK;
+}
+
+}  // namespace
+
+// x = C^-1 b on device pointers (b and x distinct or identical: an aliased right-hand side is copied first)
+int ndlu_solve_dev(lsa_ctx* ctx, lsa_ndlu* f, int vdtype, const void* b, void* x) {
+    if (f->dtype == LSA_C128 && vdtype != LSA_C128) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve: complex factors need complex vectors");
+    if (f->S.n == 0) return LSA_OK;
+    if (b == x) {
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(f->d_tmp, b, (size_t)f->S.n * esize(vdtype), hipMemcpyDeviceToDevice, ctx->stream));
+        b = f->d_tmp;
+    }
+    if (f->dtype == LSA_C128) return nd_apply<cplx, cplx>(ctx, f, (const cplx*)b, (cplx*)x);
+    if (vdtype == LSA_C128) return nd_apply<double, cplx>(ctx, f, (const cplx*)b, (cplx*)x);
+    return nd_apply<double, double>(ctx, f, (const double*)b, (double*)x);
+}
+
+// the last destroyed factorisation of a context is kept (analysis, tables, buffers): a shift sweep refactorises the
+// same pattern once per sigma (.examples/eigenvalues.py:97-108)
+extern "C" void lsa_ndlu_drop_cache(lsa_ctx* ctx) {
+    if (ctx && ctx->nd_cache) {
+        nd_free(ctx->nd_cache);
+        ctx->nd_cache = nullptr;
+    }
+}
+
+extern "C" {
+
+int lsa_ndlu_refactor(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
+    if (!ctx || !f || !C) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_refactor: null argument");
+    if (C->n != f->S.n || C->n != C->ncols || C->nnz != f->S.nnz || C->dtype != f->dtype)
+        return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_refactor: the matrix does not match the analysed pattern");
+    const double t0 = now_s();
+    const int rc = f->dtype == LSA_C128 ? nd_numeric<cplx>(ctx, f, C) : nd_numeric<double>(ctx, f, C);
+    f->seconds_numeric = now_s() - t0;
+    return rc;
+}
+
+int lsa_ndlu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t leaf_size, lsa_ndlu** out) {
+    if (!ctx || !C || !out) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create: null argument");
+    *out = nullptr;
+    if (C->n != C->ncols || C->row0 != 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create: needs a square, unsharded matrix");
+    if ((int64_t)C->h_rp.size() != (int64_t)C->n + 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create: the matrix has no host copy of its pattern");
+    if (leaf_size <= 0) leaf_size = 128;
+    const double t0 = now_s();
+    lsa_ndlu* f = nullptr;
+    // same pattern as the parked factorisation: only the numbers change
+    if (ctx->nd_cache) {
+        lsa_ndlu* c = ctx->nd_cache;
+        if (c->S.n == C->n && c->S.nnz == C->nnz && c->dtype == C->dtype && c->S.leaf_size == leaf_size &&
+            c->S.pattern_hash == nd_pattern_hash(C->n, C->h_rp.data(), C->h_ci.data())) {
+            f = c;
+            ctx->nd_cache = nullptr;
+            f->seconds_analyse = 0.0;
+        } else {
+            lsa_ndlu_drop_cache(ctx);
+        }
+    }
+    if (!f) {
+        f = new lsa_ndlu();
+        f->ctx = ctx;
+        f->dtype = C->dtype;
+        char buf[256] = {0};
+        int rc;
+        try {
+            rc = nd_analyse(C->n, C->h_rp.data(), C->h_ci.data(), leaf_size, &f->S, buf, (int)sizeof buf);
+        } catch (const std::bad_alloc&) {
+            rc = LSA_ERR_ARG;
+            snprintf(buf, sizeof buf, "lsa_ndlu_create: out of host memory in the analysis");
+        }
+        if (rc != LSA_OK) {
+            nd_free(f);
+            return lsa_set_error(ctx, rc, "%s", buf);
+        }
+        rc = nd_setup(ctx, f);
+        if (rc != LSA_OK) {
+            nd_free(f);
+            return rc;
+        }
+        f->seconds_analyse = now_s() - t0;
+    }
+    const int rc = lsa_ndlu_refactor(ctx, f, C);
+    if (rc != LSA_OK) {
+        nd_free(f);
+        return rc;
+    }
+    *out = f;
+    return LSA_OK;
+}
+
+void lsa_ndlu_destroy(lsa_ndlu* f) {
+    if (!f) return;
+    lsa_ctx* ctx = f->ctx;
+    if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx && !getenv("LSA_ND_NO_CACHE")) {
+        lsa_ndlu_drop_cache(ctx);
+        ctx->nd_cache = f;
+        return;
+    }
+    nd_free(f);
+}
+
+int lsa_ndlu_solve(lsa_ctx* ctx, lsa_ndlu* f, const lsa_vec* b, lsa_vec* x) {
+    if (!ctx || !f || !b || !x) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve: null argument");
+    if (b->n != f->S.n || x->n != f->S.n || b->dtype != x->dtype) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve: shape/dtype mismatch");
+    LSA_CHECK(ndlu_solve_dev(ctx, f, b->dtype, b->d, x->d));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return LSA_OK;
+}
+
+int lsa_ndlu_solve_time(lsa_ctx* ctx, lsa_ndlu* f, const lsa_vec* b, lsa_vec* x, int iters, double* avg_ms) {
+    if (!ctx || !f || !b || !x || !avg_ms || iters < 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve_time: bad argument");
+    if (b->n != f->S.n || x->n != f->S.n || b->dtype != x->dtype || b->d == x->d) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve_time: shape/dtype mismatch");
+    LSA_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    for (int i = 0; i < iters; ++i) LSA_CHECK(ndlu_solve_dev(ctx, f, b->dtype, b->d, x->d));
+    LSA_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+    float ms = 0.f;
+    LSA_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *avg_ms = (double)ms / iters;
+    return LSA_OK;
+}
+
+int lsa_ndlu_info(const lsa_ndlu* f, int32_t* ntree, int32_t* nlevels, int32_t* max_front, int64_t* factor_entries, int64_t* front_entries,
+                  int64_t* apply_bytes, int32_t* apply_launches, double* seconds_analyse, double* seconds_numeric) {
+    if (!f) return LSA_ERR_ARG;
+    const NdSymbolic& S = f->S;
+    if (ntree) *ntree = S.nt;
+    if (nlevels) *nlevels = S.nlevels;
+    if (max_front) {
+        int32_t mf = 0;
+        for (int32_t v : S.f) mf = std::max(mf, v);
+        *max_front = mf;
+    }
+    if (factor_entries) *factor_entries = S.factor_entries;
+    if (front_entries) *front_entries = S.front_entries;
+    // one solve reads every factor scalar once, the right-hand side once, and reads + writes the solution and the update vectors
+    if (apply_bytes) *apply_bytes = S.factor_entries * (int64_t)esize(f->dtype) + 16 * (3 * (int64_t)S.n + 2 * S.u_off[(size_t)S.nt]);
+    if (apply_launches) *apply_launches = f->solve_launches;
+    if (seconds_analyse) *seconds_analyse = f->seconds_analyse;
+    if (seconds_numeric) *seconds_numeric = f->seconds_numeric;
+    return LSA_OK;
+}
+
+}  // extern "C"

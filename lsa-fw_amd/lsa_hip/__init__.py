@@ -24,6 +24,7 @@ _STATUS_NAMES = {
     -5: "LSA_ERR_NONFINITE",
     -6: "LSA_ERR_TIMEOUT",
     -7: "LSA_ERR_COMM",
+    -8: "LSA_ERR_OOM",
 }
 
 LIB_PATH = Path(os.environ.get("LSA_HIP_LIB", Path(__file__).resolve().parent / "liblsa_hip.so"))
@@ -47,6 +48,8 @@ class lsa_stats(ctypes.Structure):
         ("max_rel_res", ctypes.c_double),
         ("seconds_factor", ctypes.c_double),
         ("seconds_solve", ctypes.c_double),
+        ("stagnated_solves", ctypes.c_int32),
+        ("pc_fallback", ctypes.c_int32),
     ]
 
 
@@ -98,6 +101,20 @@ SIGNATURES = {
     "lsa_blu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
     "lsa_blu_apply_bytes": (ctypes.c_int, [_P, ctypes.POINTER(_I64)]),
     "lsa_blu_apply_launches": (ctypes.c_int, [_P, ctypes.POINTER(_I32)]),
+    "lsa_nd_analyse": (ctypes.c_int, [_I32, _P, _P, _I32, _PP]),
+    "lsa_nd_sym_error": (ctypes.c_char_p, [_P]),
+    "lsa_nd_sym_destroy": (None, [_P]),
+    "lsa_nd_sym_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64),
+                                       ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_DBL)]),
+    "lsa_nd_sym_export": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "lsa_nd_sym_export_tables": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "lsa_ndlu_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
+    "lsa_ndlu_refactor": (ctypes.c_int, [_P, _P, _P]),
+    "lsa_ndlu_destroy": (None, [_P]),
+    "lsa_ndlu_solve": (ctypes.c_int, [_P, _P, _P, _P]),
+    "lsa_ndlu_solve_time": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.POINTER(_DBL)]),
+    "lsa_ndlu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64),
+                                     ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I32), ctypes.POINTER(_DBL), ctypes.POINTER(_DBL)]),
     "lsa_gmres": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, _DBL, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
     "lsa_op_create": (ctypes.c_int, [_P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
     "lsa_op_create_sharded": (ctypes.c_int, [_P, _P, _P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
@@ -426,6 +443,95 @@ class BlockLu:
     def __del__(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self.ctx._lib.lsa_blu_destroy(self.handle)
+            self.handle = None
+
+
+class NdAnalysis:
+    """Host-only analysis of the nested-dissection multifrontal LU (``lsa_nd_analyse``): ordering, elimination forest
+    and the index tables of the device kernels.  Needs no GPU; used by the tests and by sizing tools."""
+
+    def __init__(self, A, leaf_size: int = 0):
+        import scipy.sparse as sp
+
+        A = sp.csr_matrix(A)
+        if A.shape[0] != A.shape[1]:
+            raise ValueError("the analysis needs a square pattern")
+        self._lib = load_library()
+        self.n, self.nnz = A.shape[0], A.nnz
+        rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
+        ci = np.ascontiguousarray(A.indices, dtype=np.int32)
+        h = ctypes.c_void_p()
+        rc = self._lib.lsa_nd_analyse(self.n, _ptr(rp), _ptr(ci), int(leaf_size), ctypes.byref(h))
+        self.handle = h
+        if rc != 0:
+            msg = self._lib.lsa_nd_sym_error(h).decode(errors="replace")
+            raise ValueError(msg)
+        nt, nl, mf = _I32(0), _I32(0), _I32(0)
+        ie, fe, fre, fl = _I64(0), _I64(0), _I64(0), _DBL(0.0)
+        self._lib.lsa_nd_sym_info(h, ctypes.byref(nt), ctypes.byref(nl), ctypes.byref(mf), ctypes.byref(ie), ctypes.byref(fe), ctypes.byref(fre),
+                                  ctypes.byref(fl))
+        self.ntree, self.nlevels, self.max_front = nt.value, nl.value, mf.value
+        self.index_entries, self.factor_entries, self.front_entries, self.flops = ie.value, fe.value, fre.value, fl.value
+
+    def export(self) -> dict:
+        """perm, node_start, parent, level, front_size, idx (see include/lsa_hip.h)."""
+        out = {"perm": np.empty(self.n, np.int32), "node_start": np.empty(self.ntree + 1, np.int32), "parent": np.empty(self.ntree, np.int32),
+               "level": np.empty(self.ntree, np.int32), "front_size": np.empty(self.ntree, np.int32), "idx": np.empty(self.index_entries, np.int32)}
+        self._lib.lsa_nd_sym_export(self.handle, *[_ptr(out[k]) for k in ("perm", "node_start", "parent", "level", "front_size", "idx")])
+        return out
+
+    def export_tables(self) -> dict:
+        """cmap, gptr, gidx, asm_dst, lvl_ptr, lvl_nodes (the tables the device kernels walk)."""
+        ex = self.export()
+        m = np.diff(ex["node_start"])
+        b = ex["front_size"] - m
+        out = {"cmap": np.empty(int(b.sum()), np.int32), "gptr": np.empty(int((ex["front_size"] + 1).sum()), np.int32),
+               "gidx": np.empty(int(b.sum()), np.int32), "asm_dst": np.empty(self.nnz, np.int64), "lvl_ptr": np.empty(self.nlevels + 1, np.int32),
+               "lvl_nodes": np.empty(self.ntree, np.int32)}
+        self._lib.lsa_nd_sym_export_tables(self.handle, *[_ptr(out[k]) for k in ("cmap", "gptr", "gidx", "asm_dst", "lvl_ptr", "lvl_nodes")])
+        out.update(ex)
+        return out
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self._lib.lsa_nd_sym_destroy(self.handle)
+            self.handle = None
+
+
+class NdLu:
+    """Nested-dissection multifrontal LU of a CSR matrix, resident on the device (``lsa_ndlu_*``)."""
+
+    def __init__(self, ctx: Context, C: CsrMatrix, leaf_size: int = 0):
+        self.ctx, self._C = ctx, C
+        h = ctypes.c_void_p()
+        ctx.check(ctx._lib.lsa_ndlu_create(ctx.handle, C.handle, int(leaf_size), ctypes.byref(h)))
+        self.handle = h
+        self.n = C.shape[0]
+
+    def refactor(self, C: CsrMatrix) -> None:
+        self.ctx.check(self.ctx._lib.lsa_ndlu_refactor(self.ctx.handle, self.handle, C.handle))
+        self._C = C
+
+    def info(self) -> dict:
+        nt, nl, mf, nla = _I32(0), _I32(0), _I32(0), _I32(0)
+        fe, fre, ab = _I64(0), _I64(0), _I64(0)
+        sa, sn = _DBL(0.0), _DBL(0.0)
+        self.ctx._lib.lsa_ndlu_info(self.handle, ctypes.byref(nt), ctypes.byref(nl), ctypes.byref(mf), ctypes.byref(fe), ctypes.byref(fre),
+                                    ctypes.byref(ab), ctypes.byref(nla), ctypes.byref(sa), ctypes.byref(sn))
+        return {"tree_nodes": nt.value, "levels": nl.value, "max_front": mf.value, "factor_entries": fe.value, "front_entries": fre.value,
+                "apply_bytes": ab.value, "apply_launches": nla.value, "seconds_analyse": sa.value, "seconds_numeric": sn.value}
+
+    def solve(self, b: DeviceVector, x: DeviceVector) -> None:
+        self.ctx.check(self.ctx._lib.lsa_ndlu_solve(self.ctx.handle, self.handle, b.handle, x.handle))
+
+    def time_solve(self, b: DeviceVector, x: DeviceVector, iters: int) -> float:
+        ms = _DBL(0.0)
+        self.ctx.check(self.ctx._lib.lsa_ndlu_solve_time(self.ctx.handle, self.handle, b.handle, x.handle, int(iters), ctypes.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
+            self.ctx._lib.lsa_ndlu_destroy(self.handle)
             self.handle = None
 
 

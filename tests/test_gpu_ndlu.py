@@ -1,0 +1,173 @@
+"""GPU parity tests of the nested-dissection multifrontal LU (PreconditionerType.LU on the device) against SuperLU and
+against the numpy walk of the same analysis tables (tests/nd_emulation.py)."""
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+pytestmark = pytest.mark.gpu
+
+SIGMA = 0.018 + 0.7379601143282424j
+
+
+def _shifted(case, sigma):
+    from oracle import fem
+
+    es = fem.cylinder_case(case)
+    return es, sp.csr_matrix((es.A.data - sigma * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+
+
+def _solve(hip_ctx, f, b):
+    import lsa_hip
+
+    dx = lsa_hip.DeviceVector(hip_ctx, len(b), b.dtype)
+    f.solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
+    return dx.numpy()
+
+
+@pytest.mark.parametrize("case,sigma,leaf", [("S2k", SIGMA, 32), ("S2k", SIGMA, 0), ("S5k", SIGMA, 0), ("S5k", 0.05, 64), ("S30k", SIGMA, 0),
+                                             ("S30k", SIGMA, 300)])
+def test_ndlu_is_a_direct_solver(hip_ctx, case, sigma, leaf):
+    """Saddle-point matrices in their assembly order (the dissection is internal); complex and real shifts; leaf sizes
+    that exercise the 64-, 128-, 256- and 512-thread panel instances."""
+    import lsa_hip
+
+    es, C = _shifted(case, sigma)
+    dC = lsa_hip.CsrMatrix.from_scipy(hip_ctx, C)
+    f = lsa_hip.NdLu(hip_ctx, dC, leaf)
+    info = f.info()
+    assert info["tree_nodes"] >= 1 and info["apply_launches"] <= 2 * info["levels"]
+    assert info["factor_entries"] < 0.25 * es.n * es.n  # sparse: far from the n^2 of a dense inverse
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    x = _solve(hip_ctx, f, b)
+    assert np.linalg.norm(C @ x - b) <= 1e-12 * np.linalg.norm(b)
+    xref = spla.splu(sp.csc_matrix(C.astype(np.complex128))).solve(b)
+    assert np.linalg.norm(x - xref) <= 1e-10 * np.linalg.norm(xref)
+    assert np.array_equal(_solve(hip_ctx, f, b), x)  # fixed summation order: bitwise repeatable
+
+
+def test_ndlu_matches_the_walk_of_its_tables(hip_ctx):
+    """Same analysis, same data flow, LAPACK pivot blocks: the device result agrees to rounding."""
+    import lsa_hip
+    from nd_emulation import Emulated
+
+    es, C = _shifted("S5k", SIGMA)
+    em = Emulated(lsa_hip.NdAnalysis(C, 0).export_tables(), C.data)
+    f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, C), 0)
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    x = _solve(hip_ctx, f, b)
+    xe = em.solve(b)
+    assert np.linalg.norm(x - xe) <= 1e-11 * np.linalg.norm(xe)
+
+
+def test_ndlu_real_factors_real_and_complex_vectors(hip_ctx):
+    """float64 instantiation; a complex right-hand side against real factors (the M-solve of iSTType.SHIFT)."""
+    import lsa_hip
+
+    es, C = _shifted("S5k", 0.05)
+    C = sp.csr_matrix(C.real)
+    f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, C), 0)
+    lu = spla.splu(sp.csc_matrix(C))
+    rng = np.random.default_rng(7)
+    br = rng.standard_normal(es.n)
+    xr = _solve(hip_ctx, f, br)
+    assert xr.dtype == np.float64 and np.linalg.norm(xr - lu.solve(br)) <= 1e-10 * np.linalg.norm(xr)
+    bc = br + 1j * rng.standard_normal(es.n)
+    xc = _solve(hip_ctx, f, bc)
+    assert np.linalg.norm(xc - (lu.solve(bc.real) + 1j * lu.solve(bc.imag))) <= 1e-10 * np.linalg.norm(xc)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 9, 65, 130, 519])
+def test_ndlu_ragged_sizes_and_general_patterns(hip_ctx, n):
+    """Tiny and odd sizes, structurally unsymmetric random patterns, weak diagonals (row pivoting inside the blocks)."""
+    import lsa_hip
+
+    rng = np.random.default_rng(n)
+    A = sp.random(n, n, density=min(1.0, 6.0 / n), random_state=rng, format="csr") + sp.diags(0.05 + rng.random(n), 0)
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), 16)
+    b = rng.standard_normal(n)
+    x = _solve(hip_ctx, f, b)
+    assert np.linalg.norm(A @ x - b) <= 1e-10 * max(np.linalg.norm(b), np.linalg.norm(A @ x))
+
+
+def test_ndlu_zero_diagonal_needs_pivoting(hip_ctx):
+    """All-zero diagonal, strong coupling inside pairs of unknowns with one shared adjacency (the situation of a mesh
+    node's velocity / pressure unknowns): solvable only through row pivoting inside the pivot blocks.  Pivots are not
+    moved across fronts, so the pairs must stay together -- they do, having the same neighbours."""
+    import lsa_hip
+
+    npair = 300
+    rng = np.random.default_rng(2)
+    S = sp.random(npair, npair, density=0.01, random_state=rng) + sp.diags([np.ones(npair - 1), np.ones(npair - 1)], [-1, 1])
+    S = sp.csr_matrix(S + S.T)
+    S.setdiag(0.0)
+    S.eliminate_zeros()
+    weak = sp.kron(S, np.ones((2, 2))).tocsr()
+    weak.data[:] = 0.1 * rng.standard_normal(weak.nnz)
+    A = sp.csr_matrix(weak + sp.kron(sp.identity(npair), np.array([[0.0, 2.0], [2.0, 0.0]])))
+    A = sp.csr_matrix(A + sp.kron(sp.identity(npair), 1e-300 * np.eye(2)))  # diagonal stored, numerically zero
+    A.sort_indices()
+    assert np.abs(A.diagonal()).max() < 1e-200
+    f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), 64)
+    b = rng.standard_normal(2 * npair)
+    x = _solve(hip_ctx, f, b)
+    assert np.linalg.norm(A @ x - b) <= 1e-10 * np.linalg.norm(b)
+
+
+def test_ndlu_singular_matrix_is_an_error(hip_ctx):
+    import lsa_hip
+
+    n = 300
+    A = sp.csr_matrix(sp.diags([np.ones(n - 1), 2.0 * np.ones(n), np.ones(n - 1)], [-1, 0, 1]))
+    A.data[A.indptr[17]:A.indptr[18]] = 0.0  # a row of stored zeros
+    with pytest.raises(lsa_hip.LsaError) as exc:
+        lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), 0)
+    assert exc.value.status == -3  # LSA_ERR_ZERO_PIVOT
+
+
+def test_ndlu_refactor_and_cached_analysis(hip_ctx):
+    """A shift sweep: new values on the same pattern (explicit refactor, and create-after-destroy through the context's
+    cache) give the factorisation of the new matrix."""
+    import lsa_hip
+
+    es, C0 = _shifted("S5k", SIGMA)
+    _, C1 = _shifted("S5k", 0.05 + 0.744243299635422j)
+    rng = np.random.default_rng(9)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    dC0 = lsa_hip.CsrMatrix.from_scipy(hip_ctx, C0)
+    dC1 = lsa_hip.CsrMatrix.from_scipy(hip_ctx, C1)
+    f = lsa_hip.NdLu(hip_ctx, dC0, 0)
+    first = f.info()
+    x0 = _solve(hip_ctx, f, b)
+    f.refactor(dC1)
+    x1 = _solve(hip_ctx, f, b)
+    assert np.linalg.norm(C0 @ x0 - b) <= 1e-12 * np.linalg.norm(b) and np.linalg.norm(C1 @ x1 - b) <= 1e-12 * np.linalg.norm(b)
+    del f  # parks the factorisation in the context
+    g = lsa_hip.NdLu(hip_ctx, dC0, 0)
+    assert g.info()["seconds_analyse"] == 0.0 and first["seconds_analyse"] > 0.0  # analysis reused
+    assert np.array_equal(_solve(hip_ctx, g, b), x0)
+
+
+def test_eigensolver_lu_variants_agree(hip_ctx):
+    """The drop-in surface with both exact factorisations (lu='nd' default, lu='band'): same eigenvalues to 1e-10."""
+    from oracle import fem
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    es = fem.cylinder_case("S5k")
+    lam = {}
+    for kind in ("nd", "band"):
+        s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=6, atol=1e-11, ncv=40), check_hermitian=False, lu=kind)
+        s.solver.set_st_type(iSTType.SINVERT)
+        s.solver.set_target(SIGMA)
+        s.solver.set_st_pc_type(PreconditionerType.LU)
+        pairs = s.solve()
+        lam[kind] = np.array([p[0] for p in pairs[:6]])
+        assert s.solver.stats["gmres_iters"] <= 2 * s.solver.stats["op_applies"]  # direct solves, at most polished
+        s.solver.release()
+    assert np.max(np.abs(lam["nd"] - lam["band"]) / np.abs(lam["band"])) < 1e-10

@@ -1,0 +1,44 @@
+"""Analysis, factor and solve timing of the nested-dissection LU against the direct (SuperLU) answer (development aid)."""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT), str(ROOT / "lsa-fw_amd")]
+import numpy as np  # noqa: E402
+import scipy.sparse as sp  # noqa: E402
+import scipy.sparse.linalg as spla  # noqa: E402
+
+import lsa_hip  # noqa: E402
+from synthetic import fem  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--case", default="S5k")
+ap.add_argument("--leaf", type=int, default=0)
+ap.add_argument("--refactors", type=int, default=3)
+args = ap.parse_args()
+es = fem.cube_case(args.case) if args.case.startswith("C") else fem.cylinder_case(args.case)
+C = sp.csr_matrix((es.A.data - fem.SIGMA_RE50 * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+ctx = lsa_hip.Context(0)
+dC = lsa_hip.CsrMatrix.from_scipy(ctx, C)
+t0 = time.time()
+f = lsa_hip.NdLu(ctx, dC, args.leaf)
+print(f"{args.case}: n={es.n} nnz={C.nnz} create {time.time() - t0:.3f}s info={f.info()}", flush=True)
+for _ in range(args.refactors):
+    t0 = time.time()
+    f.refactor(dC)
+    print(f"  refactor {1e3 * (time.time() - t0):.2f} ms", flush=True)
+b = np.random.default_rng(0).standard_normal(es.n) + 1j * np.random.default_rng(1).standard_normal(es.n)
+db = lsa_hip.DeviceVector.from_numpy(ctx, b)
+dx = lsa_hip.DeviceVector(ctx, es.n, np.complex128)
+f.solve(db, dx)
+x = dx.numpy()
+print("relative residual", np.linalg.norm(C @ x - b) / np.linalg.norm(b), flush=True)
+if es.n < 40000:
+    xr = spla.splu(C.tocsc()).solve(b)
+    print("vs SuperLU", np.linalg.norm(x - xr) / np.linalg.norm(xr), flush=True)
+f.time_solve(db, dx, 10)
+ms = f.time_solve(db, dx, 100)
+info = f.info()
+print(f"solve {ms * 1e3:.1f} us per apply; {info['apply_bytes'] / 1e6:.1f} MB -> {info['apply_bytes'] / ms / 1e6:.0f} GB/s; {info['apply_launches']} launches", flush=True)

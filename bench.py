@@ -6,9 +6,9 @@ until k = 20 pairs pass the relative-residual test.  A pair counts as converged 
 ||A v - lam M v|| / (||A v|| + |lam| ||M v||) <= 1e-8 (formula of Solver/eigen2.py:48-56), checked on the device after
 the timed region.
 
-Inner solve (--pc): "lu" (default, the reference's own setting, .examples/eigenvalues.py:100) = exact block-tridiagonal
-LU on the device, every solve verified against b - C x and wrapped in GMRES; "ilu" = ILU(k)-preconditioned GMRES with the
-blocked SpTRSV (the north-star variant).  The headline `value` is the --pc run; the other variant is timed once and
+Inner solve (--pc): "lu" (default, the reference's own setting, .examples/eigenvalues.py:100) = exact nested-dissection
+multifrontal LU on the device, every solve verified against b - C x and wrapped in GMRES; "ilu" = ILU(k)-preconditioned
+GMRES with the blocked SpTRSV (the north-star variant).  The headline `value` is the --pc run; the other variant is timed once and
 reported under config.other_pc so both numbers are always on the line.
 
     python bench.py --gpus 1 --steps 2 --warmup 1
@@ -108,8 +108,10 @@ def spmv_roofline(args, device):
         dy = lsa_hip.DeviceVector(ctx, n, np.complex128)
         dC.time_matvec(dx, dy, 5)
         ms = dC.time_matvec(dx, dy, args.roof_iters)
-        bytes_c = 20.0 * nnz + 36.0 * n  # 16 B value + 4 B column per entry; 4 B rowptr + 16 B x + 16 B y per row
-        out["c128"] = {"ms": ms, "bytes": bytes_c, "gbs": bytes_c / ms / 1e6}
+        bytes_c = 20.0 * nnz + 36.0 * n  # SURVEY 8(d): 16 B value + 4 B column per entry; 4 B rowptr + 16 B x + 16 B y per row
+        info = dC.matvec_info(np.complex128)  # the kernel lsa_spmv really launched and the bytes THAT kernel moves
+        out["c128"] = {"ms": ms, "bytes": bytes_c, "gbs": bytes_c / ms / 1e6, "kernel": info["kernel"], "moved": float(info["bytes_moved"]),
+                       "moved_gbs": info["bytes_moved"] / ms / 1e6}
         # the f64 variant of the same pattern (real sigma path): 12 nnz + 20 n bytes
         bigr = sp.csr_matrix((np.ascontiguousarray(val.real), ci, rp), shape=big.shape)
         del dC
@@ -119,7 +121,8 @@ def spmv_roofline(args, device):
         dR.time_matvec(dxr, dyr, 5)
         msr = dR.time_matvec(dxr, dyr, args.roof_iters)
         bytes_r = 12.0 * nnz + 20.0 * n
-        out["f64"] = {"ms": msr, "bytes": bytes_r, "gbs": bytes_r / msr / 1e6}
+        infor = dR.matvec_info(np.float64)
+        out["f64"] = {"ms": msr, "bytes": bytes_r, "gbs": bytes_r / msr / 1e6, "kernel": infor["kernel"]}
         out["n"], out["nnz"] = n, nnz
         del dR, dx, dy, dxr, dyr
     finally:
@@ -130,14 +133,18 @@ def spmv_roofline(args, device):
     return out
 
 
-def pmc_traffic(args):
+def pmc_traffic(args, kernel: str):
     """HBM bytes per SpMV launch from the committed rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950 note of
-    MI355X_MICROARCH.md, + WRITE_SIZE); PMC counters cannot be collected inside this process.  None if the committed
-    profile is for another SROOF configuration."""
-    path = ROOT / "profiles" / "r01_spmv_traffic.json"
-    if not path.exists() or args.roof_case != "S500k" or args.roof_reps != 10:
+    MI355X_MICROARCH.md, + WRITE_SIZE); PMC counters cannot be collected inside this process.  None unless the committed
+    profile is for this SROOF configuration AND for the kernel this run launched (name and template arguments)."""
+    if args.roof_case != "S500k" or args.roof_reps != 10:
         return None
-    return float(json.loads(path.read_text())["c128"]["traffic_bytes"])
+    squash = lambda t: "".join(t.split()).replace("void", "")  # noqa: E731
+    for path in sorted((ROOT / "profiles").glob("r*_spmv_traffic.json"), reverse=True):
+        rec = json.loads(path.read_text()).get("c128", {})
+        if squash(kernel) and squash(kernel) in squash(rec.get("kernel", "")):
+            return float(rec["traffic_bytes"])
+    return None
 
 
 def solves_in_flight(es, sigma, args, device, jobs=2, rounds=4):
@@ -172,28 +179,27 @@ def solves_in_flight(es, sigma, args, device, jobs=2, rounds=4):
 
 
 def lu_apply_rate(es, sigma, device):
-    """Secondary figure: one inner solve of the exact block LU (forward + backward sweeps of the twisted factorisation),
-    HIP-event time per apply against its algorithmic bytes (lsa_blu_apply_bytes)."""
+    """Secondary figure: one inner solve of the exact LU (upward + downward sweep over the elimination forest),
+    HIP-event time per apply against its algorithmic bytes (every factor scalar once + the vectors: lsa_ndlu_info), and
+    the numeric refactorisation time for a new shift on the analysed pattern."""
     import lsa_hip
-    from Solver.utils import pivot_safe_rcm
 
     C = sp.csr_matrix((es.A.data - sigma * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
-    perm = pivot_safe_rcm(C)
-    C = C[perm][:, perm].tocsr()
-    C.sort_indices()
     ctx = lsa_hip.Context(device)
     try:
         dC = lsa_hip.CsrMatrix.from_scipy(ctx, C)
-        f = lsa_hip.BlockLu(ctx, dC)
+        f = lsa_hip.NdLu(ctx, dC)
         rng = np.random.default_rng(0)
         db = lsa_hip.DeviceVector.from_numpy(ctx, rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n))
         dx = lsa_hip.DeviceVector(ctx, es.n, np.complex128)
         f.time_solve(db, dx, 10)
         ms = f.time_solve(db, dx, 200)
+        f.refactor(dC)
         info = f.info()
         out = {"ms_per_apply": ms, "algorithmic_bytes": info["apply_bytes"], "achieved_GBps": info["apply_bytes"] / ms / 1e6,
-               "frac_of_hbm_peak": info["apply_bytes"] / ms / 1e6 / HBM_PEAK_GBS, "block_size": info["block_size"],
-               "nblocks": info["nblocks"], "dependent_launches": info["apply_launches"]}
+               "frac_of_hbm_peak": info["apply_bytes"] / ms / 1e6 / HBM_PEAK_GBS, "tree_nodes": info["tree_nodes"], "tree_levels": info["levels"],
+               "max_front": info["max_front"], "dependent_launches": info["apply_launches"], "seconds_analyse": info["seconds_analyse"],
+               "seconds_refactor": info["seconds_numeric"]}
         f = db = dx = dC = None
     finally:
         import gc
@@ -339,7 +345,7 @@ def main() -> None:
             "config": {
                 "workload": f"{args.case}: synthetic 2D cylinder-flow Taylor-Hood pair, n={es.n}, nnz={es.A.nnz}, Re=50, "
                             f"sigma={sigma.real:g}{sigma.imag:+g}j, k={args.k}, ncv={args.ncv}, outer tol {args.atol:g}, "
-                            + (f"inner solves: exact block-tridiagonal LU (verified, GMRES-wrapped)" if args.pc == "lu"
+                            + ("inner solves: exact nested-dissection multifrontal LU (verified against b - C x, GMRES-wrapped)" if args.pc == "lu"
                                else f"inner solves: ILU({args.ilu_levels})-GMRES({args.restart}), blocked SpTRSV"),
                 "pc": args.pc,
                 "other_pc": other,
@@ -363,10 +369,14 @@ def main() -> None:
                 roof = spmv_roofline(args, device)
                 out["roofline"] = {
                     "bound": "hbm", "achieved": roof["c128"]["gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": roof["c128"]["gbs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(args),
-                    "kernel": "spmv_subwave_kernel<cplx,cplx> on SROOF", "ms_per_launch": roof["c128"]["ms"],
-                    "algorithmic_bytes_per_launch": roof["c128"]["bytes"], "n": roof["n"], "nnz": roof["nnz"],
-                    "f64": {"achieved": roof["f64"]["gbs"], "frac": roof["f64"]["gbs"] / HBM_PEAK_GBS, "ms_per_launch": roof["f64"]["ms"]},
+                    "frac": roof["c128"]["gbs"] / HBM_PEAK_GBS, "traffic": pmc_traffic(args, roof["c128"]["kernel"]),
+                    "kernel": roof["c128"]["kernel"] + " on SROOF", "ms_per_launch": roof["c128"]["ms"],
+                    "algorithmic_bytes_per_launch": roof["c128"]["bytes"],
+                    # the kernel's own byte count (2-byte column offsets when the compressed form runs): what it really streams
+                    "moved_bytes_per_launch": roof["c128"]["moved"], "achieved_moved": roof["c128"]["moved_gbs"],
+                    "frac_moved": roof["c128"]["moved_gbs"] / HBM_PEAK_GBS, "n": roof["n"], "nnz": roof["nnz"],
+                    "f64": {"achieved": roof["f64"]["gbs"], "frac": roof["f64"]["gbs"] / HBM_PEAK_GBS, "ms_per_launch": roof["f64"]["ms"],
+                            "kernel": roof["f64"]["kernel"]},
                 }
             except Exception as exc:  # noqa: BLE001  (the headline value must survive a failure of this leg)
                 out["roofline"] = {"error": f"{type(exc).__name__}: {exc}"}

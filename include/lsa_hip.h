@@ -89,6 +89,10 @@ int lsa_spmv(lsa_ctx *ctx, const lsa_mat *A, const lsa_vec *x, lsa_vec *y);
 /* y = A^T x or A^H x (conj != 0) without forming the transpose: the adjoint eigenproblem of
  * Sensitivity/__init__.py:47-57,247-248 */
 int lsa_spmv_transpose(lsa_ctx *ctx, const lsa_mat *A, int conj, const lsa_vec *x, lsa_vec *y);
+/* Which kernel lsa_spmv launches for this matrix and vector type (template arguments included) and the bytes that
+ * kernel moves per launch: values + column indices (2-byte offsets from the row's first column when the compressed form
+ * is in use) + row pointers + one read of x and one write of y.  The numerator of an HBM-roofline fraction. */
+int lsa_spmv_info(lsa_ctx *ctx, const lsa_mat *A, int xdtype, char *kernel, int32_t kernel_len, int64_t *bytes_moved);
 /* Launch y = A x `iters` times back to back on the context's stream, bracketed by HIP events on that
  * stream; *avg_ms = mean duration of one launch.  This is the measurement bench.py's roofline uses. */
 int lsa_spmv_time(lsa_ctx *ctx, const lsa_mat *A, const lsa_vec *x, lsa_vec *y, int iters, double *avg_ms);
@@ -163,6 +167,10 @@ int lsa_nd_sym_export_tables(const lsa_nd_sym *h, int32_t *cmap, int32_t *gptr, 
  * pattern) + numeric factorisation on the device.  LSA_ERR_ZERO_PIVOT when a pivot block is singular to 1e-13 max|C|,
  * LSA_ERR_OOM when the fronts do not fit. */
 int lsa_ndlu_create(lsa_ctx *ctx, const lsa_mat *C, int32_t leaf_size, lsa_ndlu **out);
+/* Analysis only, parked in the context: the pattern of P (any matrix with C's pattern, e.g. A) and the scalar type the
+ * factors will have.  The next lsa_ndlu_create on that pattern then runs the numeric phase alone.  Lets a caller keep
+ * the pattern-only work out of a timed solve (the Python layer calls it from prepare()). */
+int lsa_ndlu_prepare(lsa_ctx *ctx, const lsa_mat *P, int dtype, int32_t leaf_size);
 /* new values on the analysed pattern (a shift sweep: .examples/eigenvalues.py:97-108) */
 int lsa_ndlu_refactor(lsa_ctx *ctx, lsa_ndlu *f, const lsa_mat *C);
 void lsa_ndlu_destroy(lsa_ndlu *f);

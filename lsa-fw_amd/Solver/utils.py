@@ -459,6 +459,10 @@ class iEpsSolver:
         else:
             dA = lsa_hip.CsrMatrix.from_scipy(ctx, Ap)
             dM = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, Mp)
+        if pc_code == 2 and K is not None:
+            # pattern-only phase of the nested-dissection LU (ordering, elimination forest, index tables, buffers)
+            cplx_factors = bool(np.iscomplexobj(K)) or (sinvert and complex(sigma).imag != 0.0)
+            (dAd if dAd is not None else dA).prepare_lu(cplx_factors)
         self._prepared = {"sig": self._signature(), "ctx": ctx, "dA": dA, "dM": dM, "dAd": dAd, "dMd": dMd, "part": part, "perm": perm,
                           "n": n, "sinvert": sinvert, "cayley": self._st_type is iSTType.CAYLEY, "sigma": sigma, "pc_code": pc_code,
                           "levels": levels}

@@ -819,49 +819,65 @@ int lsa_ndlu_refactor(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
     return rc;
 }
 
-int lsa_ndlu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t leaf_size, lsa_ndlu** out) {
-    if (!ctx || !C || !out) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create: null argument");
+// analysis + device tables + buffers for the pattern of P and factors of type `dtype`; taken from the context's cache
+// when the parked factorisation matches
+static int nd_symbolic_phase(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t leaf_size, lsa_ndlu** out) {
     *out = nullptr;
-    if (C->n != C->ncols || C->row0 != 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create: needs a square, unsharded matrix");
-    if ((int64_t)C->h_rp.size() != (int64_t)C->n + 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create: the matrix has no host copy of its pattern");
+    if (P->n != P->ncols || P->row0 != 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: needs a square, unsharded matrix");
+    if ((int64_t)P->h_rp.size() != (int64_t)P->n + 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: the matrix has no host copy of its pattern");
     if (leaf_size <= 0) leaf_size = 128;
     const double t0 = now_s();
-    lsa_ndlu* f = nullptr;
     // same pattern as the parked factorisation: only the numbers change
     if (ctx->nd_cache) {
         lsa_ndlu* c = ctx->nd_cache;
-        if (c->S.n == C->n && c->S.nnz == C->nnz && c->dtype == C->dtype && c->S.leaf_size == leaf_size &&
-            c->S.pattern_hash == nd_pattern_hash(C->n, C->h_rp.data(), C->h_ci.data())) {
-            f = c;
+        if (c->S.n == P->n && c->S.nnz == P->nnz && c->dtype == dtype && c->S.leaf_size == leaf_size &&
+            c->S.pattern_hash == nd_pattern_hash(P->n, P->h_rp.data(), P->h_ci.data())) {
             ctx->nd_cache = nullptr;
-            f->seconds_analyse = 0.0;
-        } else {
-            lsa_ndlu_drop_cache(ctx);
+            c->seconds_analyse = 0.0;
+            *out = c;
+            return LSA_OK;
         }
+        lsa_ndlu_drop_cache(ctx);
     }
-    if (!f) {
-        f = new lsa_ndlu();
-        f->ctx = ctx;
-        f->dtype = C->dtype;
-        char buf[256] = {0};
-        int rc;
-        try {
-            rc = nd_analyse(C->n, C->h_rp.data(), C->h_ci.data(), leaf_size, &f->S, buf, (int)sizeof buf);
-        } catch (const std::bad_alloc&) {
-            rc = LSA_ERR_ARG;
-            snprintf(buf, sizeof buf, "lsa_ndlu_create: out of host memory in the analysis");
-        }
-        if (rc != LSA_OK) {
-            nd_free(f);
-            return lsa_set_error(ctx, rc, "%s", buf);
-        }
-        rc = nd_setup(ctx, f);
-        if (rc != LSA_OK) {
-            nd_free(f);
-            return rc;
-        }
-        f->seconds_analyse = now_s() - t0;
+    lsa_ndlu* f = new lsa_ndlu();
+    f->ctx = ctx;
+    f->dtype = dtype;
+    char buf[256] = {0};
+    int rc;
+    try {
+        rc = nd_analyse(P->n, P->h_rp.data(), P->h_ci.data(), leaf_size, &f->S, buf, (int)sizeof buf);
+    } catch (const std::bad_alloc&) {
+        rc = LSA_ERR_ARG;
+        snprintf(buf, sizeof buf, "lsa_ndlu: out of host memory in the analysis");
     }
+    if (rc != LSA_OK) {
+        nd_free(f);
+        return lsa_set_error(ctx, rc, "%s", buf);
+    }
+    rc = nd_setup(ctx, f);
+    if (rc != LSA_OK) {
+        nd_free(f);
+        return rc;
+    }
+    f->seconds_analyse = now_s() - t0;
+    *out = f;
+    return LSA_OK;
+}
+
+int lsa_ndlu_prepare(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t leaf_size) {
+    if (!ctx || !P || (dtype != LSA_F64 && dtype != LSA_C128)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_prepare: bad argument");
+    lsa_ndlu* f = nullptr;
+    LSA_CHECK(nd_symbolic_phase(ctx, P, dtype, leaf_size, &f));
+    lsa_ndlu_drop_cache(ctx);
+    ctx->nd_cache = f;  // the next lsa_ndlu_create on this pattern only runs the numeric phase
+    return LSA_OK;
+}
+
+int lsa_ndlu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t leaf_size, lsa_ndlu** out) {
+    if (!ctx || !C || !out) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create: null argument");
+    *out = nullptr;
+    lsa_ndlu* f = nullptr;
+    LSA_CHECK(nd_symbolic_phase(ctx, C, C->dtype, leaf_size, &f));
     const int rc = lsa_ndlu_refactor(ctx, f, C);
     if (rc != LSA_OK) {
         nd_free(f);

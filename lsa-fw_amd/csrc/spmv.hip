@@ -158,10 +158,29 @@ static bool ensure_ci16(const lsa_mat* A) {
         A->ci16 = nullptr;
         return false;
     }
-    (void)hipMemcpy(A->ci16, d.data(), d.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
-    (void)hipMemcpy(A->cbase, base.data(), base.size() * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (hipMemcpy(A->ci16, d.data(), d.size() * sizeof(uint16_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(A->cbase, base.data(), base.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(A->ci16);
+        (void)hipFree(A->cbase);
+        A->ci16 = nullptr;
+        A->cbase = nullptr;
+        return false;  // state stays -1: the 32-bit kernel runs
+    }
     A->ci16_state = 1;
     return true;
+}
+
+static int spmv_lanes_per_row(const lsa_mat* A, int variant) {
+    int lpr = variant & 0xff;
+    if (lpr == 0) {
+        const double mean = A->n > 0 ? (double)A->nnz / (double)A->n : 0.0;
+        lpr = mean <= 6.0 ? 4 : mean <= 12.0 ? 8 : mean <= 48.0 ? 16 : mean <= 96.0 ? 32 : 64;
+    }
+    return (lpr == 4 || lpr == 8 || lpr == 32 || lpr == 64) ? lpr : 16;
+}
+static bool spmv_wants_ci16(const lsa_mat* A, int variant) {
+    const size_t msize = A->dtype == LSA_C128 ? 16 : 8;
+    return ((variant & 0x800) || (variant == 0 && msize == 16 && A->nnz >= (int64_t)4 << 20)) && !(variant & 0x100) && !(variant & 0x200);
 }
 
 // variant word: bits 0-7 lanes per row (0 = from the mean row length), bit 8 non-temporal matrix loads,
@@ -186,8 +205,7 @@ static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, 
     // default (no variant word): compressed indices for matrices where the SpMV is a bandwidth question (>= 4 M entries;
     // building them is one host pass over the pattern, not worth it for the 0.9 M-entry matrices rebuilt per shift)
     // (complex matrices only: with 8-byte values the 2-byte index loads cost more than they save -- f64 SROOF 565 -> 592 us)
-    const bool want16 = (variant & 0x800) || (variant == 0 && sizeof(MT) == 16 && A->nnz >= (int64_t)4 << 20);
-    if (want16 && !NT && ensure_ci16(A)) {
+    if (spmv_wants_ci16(A, variant) && !NT && ensure_ci16(A)) {
         hipLaunchKernelGGL((spmv_subwave16_kernel<MT, VT, LPR>), dim3(blocks), dim3(threads), 0, ctx->stream, A->n, A->rp, (const uint16_t*)A->ci16,
                            (const int32_t*)A->cbase, (const MT*)A->val, (const VT*)x, (VT*)y);
         return;
@@ -204,12 +222,7 @@ static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, 
 
 template <typename MT, typename VT, bool NT>
 static void dispatch_lpr(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, int variant) {
-    int lpr = variant & 0xff;
-    if (lpr == 0) {
-        const double mean = A->n > 0 ? (double)A->nnz / (double)A->n : 0.0;
-        lpr = mean <= 6.0 ? 4 : mean <= 12.0 ? 8 : mean <= 48.0 ? 16 : mean <= 96.0 ? 32 : 64;
-    }
-    switch (lpr) {
+    switch (spmv_lanes_per_row(A, variant)) {
         case 4: launch_spmv<MT, VT, 4, NT>(ctx, A, x, y, variant); break;
         case 8: launch_spmv<MT, VT, 8, NT>(ctx, A, x, y, variant); break;
         case 32: launch_spmv<MT, VT, 32, NT>(ctx, A, x, y, variant); break;
@@ -312,6 +325,24 @@ int lsa_spmv_transpose(lsa_ctx* ctx, const lsa_mat* A, int conj, const lsa_vec* 
     LSA_CHECK(check_spmv_args(ctx, A, x, y, "lsa_spmv_transpose"));
     if (y->n != A->ncols) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_spmv_transpose: y has the wrong length");
     return k_spmv_transpose(ctx, A, conj, x->dtype, x->d, y->d);
+}
+
+int lsa_spmv_info(lsa_ctx* ctx, const lsa_mat* A, int xdtype, char* kernel, int32_t kernel_len, int64_t* bytes_moved) {
+    if (!ctx || !A) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_spmv_info: null argument");
+    const int variant = spmv_variant();
+    const int lpr = spmv_lanes_per_row(A, variant);
+    const bool c16 = spmv_wants_ci16(A, variant) && ensure_ci16(A);
+    const char* mt = A->dtype == LSA_C128 ? "cplx" : "double";
+    const char* vt = xdtype == LSA_C128 ? "cplx" : "double";
+    const char* base = c16 ? "spmv_subwave16_kernel" : (variant & 0x200) ? "spmv_xcd_kernel" : (variant & 0x400) ? "spmv_subwave2_kernel" : "spmv_subwave_kernel";
+    if (kernel && kernel_len > 0) snprintf(kernel, (size_t)kernel_len, "%s<%s,%s,%d>", base, mt, vt, lpr);
+    if (bytes_moved) {
+        const int64_t ms = A->dtype == LSA_C128 ? 16 : 8, vs = xdtype == LSA_C128 ? 16 : 8;
+        // per entry: value + column index (2 bytes when compressed); per row: row pointer (+ the row's first column when
+        // compressed), one x entry read and one y entry written
+        *bytes_moved = A->nnz * (ms + (c16 ? 2 : 4)) + (int64_t)A->n * (4 + (c16 ? 4 : 0) + 2 * vs);
+    }
+    return LSA_OK;
 }
 
 int lsa_spmv_time(lsa_ctx* ctx, const lsa_mat* A, const lsa_vec* x, lsa_vec* y, int iters, double* avg_ms) {

@@ -86,6 +86,7 @@ SIGNATURES = {
     "lsa_csr_axpby": (ctypes.c_int, [_P, _P, _P, _DBL * 2, _DBL * 2, ctypes.c_int, _PP]),
     "lsa_spmv": (ctypes.c_int, [_P, _P, _P, _P]),
     "lsa_spmv_transpose": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P]),
+    "lsa_spmv_info": (ctypes.c_int, [_P, _P, ctypes.c_int, ctypes.c_char_p, _I32, ctypes.POINTER(_I64)]),
     "lsa_spmv_time": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.POINTER(_DBL)]),
     "lsa_ilu_create": (ctypes.c_int, [_P, _P, ctypes.c_int, _DBL, _PP]),
     "lsa_ilu_destroy": (None, [_P]),
@@ -109,6 +110,7 @@ SIGNATURES = {
     "lsa_nd_sym_export": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "lsa_nd_sym_export_tables": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "lsa_ndlu_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
+    "lsa_ndlu_prepare": (ctypes.c_int, [_P, _P, ctypes.c_int, _I32]),
     "lsa_ndlu_refactor": (ctypes.c_int, [_P, _P, _P]),
     "lsa_ndlu_destroy": (None, [_P]),
     "lsa_ndlu_solve": (ctypes.c_int, [_P, _P, _P, _P]),
@@ -330,6 +332,10 @@ class CsrMatrix:
         )
         return cls(ctx, h, (A.shape[0], n_global), A.nnz, dt)
 
+    def prepare_lu(self, complex_factors: bool, leaf_size: int = 0) -> None:
+        """Pattern-only phase of the nested-dissection LU for matrices with this pattern (``lsa_ndlu_prepare``)."""
+        self.ctx.check(self.ctx._lib.lsa_ndlu_prepare(self.ctx.handle, self.handle, LSA_C128 if complex_factors else LSA_F64, int(leaf_size)))
+
     def axpby(self, other: "CsrMatrix", alpha: complex, beta: complex, dtype=None) -> "CsrMatrix":
         """alpha*self + beta*other on the shared pattern (MatAXPY, Solver/eigen2.py:110-111)."""
         alpha, beta = complex(alpha), complex(beta)
@@ -355,6 +361,13 @@ class CsrMatrix:
 
     def rmatvec(self, x: DeviceVector, y: DeviceVector, conj: bool = True) -> None:
         self.ctx.check(self.ctx._lib.lsa_spmv_transpose(self.ctx.handle, self.handle, int(conj), x.handle, y.handle))
+
+    def matvec_info(self, vector_dtype=np.complex128) -> dict:
+        """Kernel ``lsa_spmv`` launches for this matrix / vector type and the bytes it moves per launch."""
+        name = ctypes.create_string_buffer(128)
+        nbytes = _I64(0)
+        self.ctx.check(self.ctx._lib.lsa_spmv_info(self.ctx.handle, self.handle, _dtype_code(vector_dtype), name, 128, ctypes.byref(nbytes)))
+        return {"kernel": name.value.decode(), "bytes_moved": nbytes.value}
 
     def time_matvec(self, x: DeviceVector, y: DeviceVector, iters: int) -> float:
         """Mean milliseconds per SpMV launch over ``iters`` back-to-back launches (HIP events on the library's stream)."""

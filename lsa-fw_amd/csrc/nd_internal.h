@@ -31,6 +31,10 @@ struct NdSymbolic {
     // forward-solve gather lists: front position j of node t sums ubuf[gidx[g]] for g in [gptr[g_off[t] + j], gptr[g_off[t] + j + 1])
     std::vector<int64_t> g_off;       // nt + 1 offsets into gptr (f_t + 1 entries per node)
     std::vector<int32_t> gptr, gidx;
+    // the same lists as one row per child (independent loads on the device): gell[ge_off[t] + c * f_t + j] = index into the
+    // update-vector buffer that child c of node t contributes to front position j, or -1
+    std::vector<int64_t> ge_off;      // nt + 1
+    std::vector<int32_t> gell;
     // assembly of the original entries: front_buffer[asm_dst[e]] = values[asm_src[e]]
     std::vector<int32_t> asm_src;
     std::vector<int64_t> asm_dst;

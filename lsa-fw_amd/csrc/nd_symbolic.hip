@@ -412,6 +412,20 @@ int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_siz
             run = gp[f];
         }
     }
+    // the gather lists again, one row per child
+    S.ge_off.assign((size_t)nt + 1, 0);
+    for (int32_t t = 0; t < nt; ++t)
+        S.ge_off[(size_t)t + 1] = S.ge_off[(size_t)t] + (int64_t)(S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t]) * S.f[(size_t)t];
+    S.gell.assign((size_t)S.ge_off[(size_t)nt], -1);
+    for (int32_t t = 0; t < nt; ++t) {
+        const int32_t f = S.f[(size_t)t];
+        for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) {
+            const int32_t c = S.child_idx[(size_t)cp];
+            int32_t* row = S.gell.data() + S.ge_off[(size_t)t] + (int64_t)(cp - S.child_ptr[(size_t)t]) * f;
+            const int32_t b = S.cmap_off[(size_t)c + 1] - S.cmap_off[(size_t)c];
+            for (int32_t k = 0; k < b; ++k) row[S.cmap[(size_t)S.cmap_off[(size_t)c] + k]] = (int32_t)(S.u_off[(size_t)c] + k);
+        }
+    }
     // assembly map of the original entries
     S.asm_src.resize((size_t)S.nnz);
     S.asm_dst.resize((size_t)S.nnz);

@@ -46,7 +46,9 @@ struct NdNodeDev {
     int32_t cmap_off;   // into cmap (b entries)
     int32_t piv_off;    // into ipiv / rowq (m entries)
     int32_t m, f, parent;
-    int32_t pad0, pad1;
+    int32_t nchild;     // rows of the node's gather table
+    int32_t pad1;
+    int64_t ge_off;     // into gell (nchild * f entries)
 };
 
 struct TileList {
@@ -58,7 +60,8 @@ struct NdLevel {
     int32_t node_begin = 0, node_count = 0, max_m = 0;
     std::vector<int32_t> sorted_m;          // own sizes of the level's nodes (descending)
     std::vector<int32_t> upd_tile_prefix;   // update tiles of the first k nodes
-    TileList upd, unperm, gemm[3], copyback, fwd, bwd;
+    TileList upd, unperm, gemm[3], copyback;
+    int32_t fwd_tiles = 0, bwd_tiles = 0;  // grid.y of the sweep kernels: tiles of the tallest node (0 = nothing to do)
     std::vector<TileList> ext;  // one per child rank
     int64_t scratch = 0;
 };
@@ -446,38 +449,75 @@ __device__ __forceinline__ VT sub16_sum(VT v) {
     return v;
 }
 
-// upward sweep, one tree level: tile = kRT rows of a node's [F11; F21] block column
+// acc0 += Fa[0:cn] . vs, acc1 += Fb[0:cn] . vs over the 16 lanes of a sub-wave; eight row loads in flight per lane (the
+// sweeps are chains of short kernels: what they wait for is memory latency, not bandwidth)
 template <typename MT, typename VT>
-__global__ __launch_bounds__(256) void nd_fwd_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
-                                                     const MT* __restrict__ front, const int32_t* __restrict__ idx,
-                                                     const int32_t* __restrict__ gptr, const int32_t* __restrict__ gidx,
+__device__ __forceinline__ void two_row_dot(const MT* __restrict__ Fa, const MT* __restrict__ Fb, const VT* vs, int32_t cn, int sl, VT& acc0,
+                                            VT& acc1) {
+    int32_t k = sl;
+    for (; k + 48 < cn; k += 64) {
+        const MT a0 = Fa[k], a1 = Fa[k + 16], a2 = Fa[k + 32], a3 = Fa[k + 48];
+        const MT b0 = Fb[k], b1 = Fb[k + 16], b2 = Fb[k + 32], b3 = Fb[k + 48];
+        fma_acc(acc0, a0, vs[k]);
+        fma_acc(acc1, b0, vs[k]);
+        fma_acc(acc0, a1, vs[k + 16]);
+        fma_acc(acc1, b1, vs[k + 16]);
+        fma_acc(acc0, a2, vs[k + 32]);
+        fma_acc(acc1, b2, vs[k + 32]);
+        fma_acc(acc0, a3, vs[k + 48]);
+        fma_acc(acc1, b3, vs[k + 48]);
+    }
+    for (; k < cn; k += 16) {
+        const MT a0 = Fa[k], b0 = Fb[k];
+        fma_acc(acc0, a0, vs[k]);
+        fma_acc(acc1, b0, vs[k]);
+    }
+}
+
+// sum of the children's update-vector entries that land on front position j (fixed order: child rank)
+template <typename VT>
+__device__ __forceinline__ VT gather_updates(const int32_t* __restrict__ ge, int32_t nchild, int32_t f, int32_t j, const VT* __restrict__ ubuf,
+                                             VT v) {
+    int32_t c = 0;
+    for (; c + 3 < nchild; c += 4) {
+        const int32_t g0 = ge[(size_t)c * f + j], g1 = ge[(size_t)(c + 1) * f + j], g2 = ge[(size_t)(c + 2) * f + j], g3 = ge[(size_t)(c + 3) * f + j];
+        const VT u0 = g0 >= 0 ? ubuf[g0] : scalar_traits<VT>::zero(), u1 = g1 >= 0 ? ubuf[g1] : scalar_traits<VT>::zero();
+        const VT u2 = g2 >= 0 ? ubuf[g2] : scalar_traits<VT>::zero(), u3 = g3 >= 0 ? ubuf[g3] : scalar_traits<VT>::zero();
+        v = s_add(s_add(s_add(s_add(v, u0), u1), u2), u3);
+    }
+    int32_t g[3] = {-1, -1, -1};
+    for (int q = 0; q < 3; ++q)
+        if (c + q < nchild) g[q] = ge[(size_t)(c + q) * f + j];
+    VT u[3];
+    for (int q = 0; q < 3; ++q) u[q] = g[q] >= 0 ? ubuf[g[q]] : scalar_traits<VT>::zero();
+    for (int q = 0; q < 3; ++q)
+        if (c + q < nchild) v = s_add(v, u[q]);
+    return v;
+}
+
+// upward sweep, one tree level: workgroup (x = node of the level, y = tile of kRT rows of its [F11; F21] block column)
+template <typename MT, typename VT>
+__global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ front,
+                                                     const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
                                                      const VT* __restrict__ rhs, VT* __restrict__ x, VT* __restrict__ ubuf) {
     __shared__ VT vs[kCH];
-    const int32_t t = tiles[2 * blockIdx.x], r0 = tiles[2 * blockIdx.x + 1];
-    const NdNodeDev nd = nodes[t];
+    const NdNodeDev nd = lnodes[blockIdx.x];
+    const int32_t r0 = (int32_t)blockIdx.y * kRT;
     const int32_t m = nd.m, f = nd.f;
+    if (r0 >= f) return;
     const int32_t* ix = idx + nd.idx_off;
-    const int32_t* gp = gptr + nd.g_off;
+    const int32_t* ge = gell + nd.ge_off;
     const MT* F = front + nd.front_off;
     const int tid = threadIdx.x, sw = tid >> 4, sl = tid & 15;
     const int32_t ra = r0 + sw, rb = r0 + sw + 16;
+    const MT* Fa = F + (size_t)min(ra, f - 1) * f;
+    const MT* Fb = F + (size_t)min(rb, f - 1) * f;
     VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
     for (int32_t c0 = 0; c0 < m; c0 += kCH) {
         const int32_t cn = min(kCH, m - c0);
-        for (int32_t j = tid; j < cn; j += 256) {
-            VT v = rhs[ix[c0 + j]];
-            for (int32_t g = gp[c0 + j]; g < gp[c0 + j + 1]; ++g) v = s_add(v, ubuf[gidx[g]]);
-            vs[j] = v;
-        }
+        for (int32_t j = tid; j < cn; j += 256) vs[j] = gather_updates(ge, nd.nchild, f, c0 + j, ubuf, rhs[ix[c0 + j]]);
         __syncthreads();
-        if (ra < f) {
-            const MT* Fa = F + (size_t)ra * f + c0;
-            for (int32_t k = sl; k < cn; k += 16) fma_acc(acc0, Fa[k], vs[k]);
-        }
-        if (rb < f) {
-            const MT* Fb = F + (size_t)rb * f + c0;
-            for (int32_t k = sl; k < cn; k += 16) fma_acc(acc1, Fb[k], vs[k]);
-        }
+        two_row_dot(Fa + c0, Fb + c0, vs, cn, sl, acc0, acc1);
         __syncthreads();
     }
     acc0 = sub16_sum(acc0);
@@ -486,49 +526,45 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const int32_t* __restrict__
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int32_t r = h ? rb : ra;
-            VT a = h ? acc1 : acc0;
+            const VT a = h ? acc1 : acc0;
             if (r >= f) continue;
             if (r < m) x[ix[r]] = a;
-            else {
-                for (int32_t g = gp[r]; g < gp[r + 1]; ++g) a = s_add(a, ubuf[gidx[g]]);
-                ubuf[nd.u_off + (r - m)] = a;
-            }
+            else ubuf[nd.u_off + (r - m)] = gather_updates(ge, nd.nchild, f, r, ubuf, a);
         }
     }
 }
 
 // downward sweep, one tree level: x[own] -= F12 x[boundary]
 template <typename MT, typename VT>
-__global__ __launch_bounds__(256) void nd_bwd_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
-                                                     const MT* __restrict__ front, const int32_t* __restrict__ idx, VT* __restrict__ x) {
+__global__ __launch_bounds__(256) void nd_bwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ front,
+                                                     const int32_t* __restrict__ idx, VT* __restrict__ x) {
     __shared__ VT vs[kCH];
-    const int32_t t = tiles[2 * blockIdx.x], r0 = tiles[2 * blockIdx.x + 1];
-    const NdNodeDev nd = nodes[t];
+    const NdNodeDev nd = lnodes[blockIdx.x];
+    const int32_t r0 = (int32_t)blockIdx.y * kRT;
     const int32_t m = nd.m, f = nd.f, b = f - m;
+    if (r0 >= m || b == 0) return;
     const int32_t* ix = idx + nd.idx_off;
     const MT* F = front + nd.front_off + m;
     const int tid = threadIdx.x, sw = tid >> 4, sl = tid & 15;
     const int32_t ra = r0 + sw, rb = r0 + sw + 16;
+    const MT* Fa = F + (size_t)min(ra, m - 1) * f;
+    const MT* Fb = F + (size_t)min(rb, m - 1) * f;
+    // the rows' own entries are needed only at the end: issue their loads before the sweep over the boundary
+    const int32_t ia = ix[min(ra, m - 1)], ib = ix[min(rb, m - 1)];
+    const VT xa = x[ia], xb = x[ib];
     VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
     for (int32_t c0 = 0; c0 < b; c0 += kCH) {
         const int32_t cn = min(kCH, b - c0);
         for (int32_t j = tid; j < cn; j += 256) vs[j] = x[ix[m + c0 + j]];
         __syncthreads();
-        if (ra < m) {
-            const MT* Fa = F + (size_t)ra * f + c0;
-            for (int32_t k = sl; k < cn; k += 16) fma_acc(acc0, Fa[k], vs[k]);
-        }
-        if (rb < m) {
-            const MT* Fb = F + (size_t)rb * f + c0;
-            for (int32_t k = sl; k < cn; k += 16) fma_acc(acc1, Fb[k], vs[k]);
-        }
+        two_row_dot(Fa + c0, Fb + c0, vs, cn, sl, acc0, acc1);
         __syncthreads();
     }
     acc0 = sub16_sum(acc0);
     acc1 = sub16_sum(acc1);
     if (sl == 0) {
-        if (ra < m) x[ix[ra]] = s_sub(x[ix[ra]], acc0);
-        if (rb < m) x[ix[rb]] = s_sub(x[ix[rb]], acc1);
+        if (ra < m) x[ia] = s_sub(xa, acc0);
+        if (rb < m) x[ib] = s_sub(xb, acc1);
     }
 }
 
@@ -539,8 +575,9 @@ struct lsa_ndlu {
     NdSymbolic S;
     int dtype = LSA_C128;
     std::vector<NdLevel> levels;
-    NdNodeDev* d_nodes = nullptr;
-    int32_t *d_idx = nullptr, *d_cmap = nullptr, *d_gptr = nullptr, *d_gidx = nullptr, *d_tiles = nullptr, *d_lvl_nodes = nullptr;
+    NdNodeDev *d_nodes = nullptr, *d_lnodes = nullptr;  // by node id / in lvl_nodes order
+    int32_t* d_gell = nullptr;
+    int32_t *d_idx = nullptr, *d_cmap = nullptr, *d_tiles = nullptr, *d_lvl_nodes = nullptr;
     int64_t* d_asm_dst = nullptr;
     int32_t *d_ipiv = nullptr, *d_rowq = nullptr, *d_flag = nullptr;
     unsigned long long* d_maxabs = nullptr;
@@ -553,7 +590,7 @@ namespace {
 
 void nd_free(lsa_ndlu* f) {
     if (!f) return;
-    for (void* p : {(void*)f->d_nodes, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_gptr, (void*)f->d_gidx, (void*)f->d_tiles,
+    for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
                     (void*)f->d_lvl_nodes, (void*)f->d_asm_dst, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_maxabs,
                     f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp})
         if (p) (void)hipFree(p);
@@ -606,7 +643,9 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
             nd.m = (int32_t)m;
             nd.f = (int32_t)ff;
             nd.parent = S.parent[(size_t)t];
-            nd.pad0 = nd.pad1 = 0;
+            nd.nchild = S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t];
+            nd.pad1 = 0;
+            nd.ge_off = S.ge_off[(size_t)t];
             scr += m * m + 2 * m * b;
             L.max_m = std::max(L.max_m, (int32_t)m);
             L.sorted_m.push_back((int32_t)m);
@@ -649,17 +688,12 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
                     for (int32_t tn = 0; tn * kGT < N; ++tn) push(L.gemm[kind], t, (tm << 16) | tn);
             }
         }
-        begin_list(L.fwd);
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            for (int32_t r0 = 0; r0 < S.f[(size_t)t]; r0 += kRT) push(L.fwd, t, r0);
+            L.fwd_tiles = std::max(L.fwd_tiles, (S.f[(size_t)t] + kRT - 1) / kRT);
+            if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.m[(size_t)t] + kRT - 1) / kRT);
         }
-        begin_list(L.bwd);
-        for (int32_t q = 0; q < L.node_count; ++q) {
-            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            if (S.f[(size_t)t] == S.m[(size_t)t]) continue;
-            for (int32_t r0 = 0; r0 < S.m[(size_t)t]; r0 += kRT) push(L.bwd, t, r0);
-        }
+        if (L.fwd_tiles > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a front of more than %d rows is not supported", 65535 * kRT);
         begin_list(L.copyback);
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
@@ -668,10 +702,14 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         if (L.max_m > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a pivot block of %d rows exceeds the 65 535 the pivot key encodes", L.max_m);
     }
     LSA_CHECK(upload(ctx, nodes, &f->d_nodes));
+    {
+        std::vector<NdNodeDev> lnodes((size_t)nt);
+        for (int32_t q = 0; q < nt; ++q) lnodes[(size_t)q] = nodes[(size_t)S.lvl_nodes[(size_t)q]];
+        LSA_CHECK(upload(ctx, lnodes, &f->d_lnodes));
+    }
+    LSA_CHECK(upload(ctx, S.gell, &f->d_gell));
     LSA_CHECK(upload(ctx, S.idx, &f->d_idx));
     LSA_CHECK(upload(ctx, S.cmap, &f->d_cmap));
-    LSA_CHECK(upload(ctx, S.gptr, &f->d_gptr));
-    LSA_CHECK(upload(ctx, S.gidx, &f->d_gidx));
     LSA_CHECK(upload(ctx, S.asm_dst, &f->d_asm_dst));
     LSA_CHECK(upload(ctx, S.lvl_nodes, &f->d_lvl_nodes));
     LSA_CHECK(upload(ctx, tiles, &f->d_tiles));
@@ -686,7 +724,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ubuf, (size_t)std::max<int64_t>(S.u_off[(size_t)nt], 1) * 16));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_tmp, nn * 16));
     f->solve_launches = 0;
-    for (const NdLevel& L : f->levels) f->solve_launches += (L.fwd.count > 0) + (L.bwd.count > 0);
+    for (const NdLevel& L : f->levels) f->solve_launches += (L.fwd_tiles > 0) + (L.bwd_tiles > 0);
     return LSA_OK;
 }
 
@@ -768,16 +806,15 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
 template <typename MT, typename VT>
 int nd_apply(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
     hipStream_t st = ctx->stream;
-    const int32_t* tl = f->d_tiles;
     const MT* front = (const MT*)f->d_front;
     for (const NdLevel& L : f->levels)
-        if (L.fwd.count > 0)
-            hipLaunchKernelGGL((nd_fwd_kernel<MT, VT>), dim3(L.fwd.count), dim3(256), 0, st, tl + 2 * L.fwd.off, f->d_nodes, front, f->d_idx, f->d_gptr,
-                               f->d_gidx, b, x, (VT*)f->d_ubuf);
+        if (L.fwd_tiles > 0)
+            hipLaunchKernelGGL((nd_fwd_kernel<MT, VT>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,
+                               f->d_gell, b, x, (VT*)f->d_ubuf);
     for (size_t l = f->levels.size(); l-- > 0;) {
         const NdLevel& L = f->levels[l];
-        if (L.bwd.count > 0)
-            hipLaunchKernelGGL((nd_bwd_kernel<MT, VT>), dim3(L.bwd.count), dim3(256), 0, st, tl + 2 * L.bwd.off, f->d_nodes, front, f->d_idx, x);
+        if (L.bwd_tiles > 0)
+            hipLaunchKernelGGL((nd_bwd_kernel<MT, VT>), dim3(L.node_count, L.bwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx, x);
     }
     LSA_HIP_CHECK(ctx, hipGetLastError());
     return LSA_OK;

@@ -4,6 +4,9 @@
   outputs, no code): tests/unit/Solver/test_eigen.py and tests/benchmark/vibrating_membrane.md.
 * ``cylinder_s2k.json``: the oracle's output on the deterministic S2k pair (the reference ships no (A, M) fixture,
   so these numbers are pinned by the oracle alone; see DESIGN.md "parity").
+* ``cylinder_s30k_k20.json``: the oracle's 20 eigenvalues nearest the Re = 50 target on S30k (BASELINE config 2).
+* ``sensitivity_re100.json``: direct eigenvalue nearest the target and the adjoint one (of (A^H, M^H) at the conjugate
+  target) at Re = 100 on S5k and S30k (BASELINE config 5; flow of Sensitivity/__init__.py:158-311).
 """
 import hashlib
 import json
@@ -45,4 +48,34 @@ cyl = {
     "row_degree_histogram": {str(k): int(v) for k, v in zip(*np.unique(np.diff(es.A.indptr), return_counts=True))},
 }
 (HERE / "cylinder_s2k.json").write_text(json.dumps(cyl, indent=1))
+
+
+def _digest(es):
+    h = hashlib.sha256()
+    for arr in (es.A.indptr, es.A.indices, np.round(es.A.data, 10), np.round(es.M.data, 10)):
+        h.update(np.ascontiguousarray(arr).tobytes())
+    return h.hexdigest()
+
+
+es = fem.cylinder_case("S30k")
+lam, V, res = shift_invert.solve(es.A, es.M, fem.SIGMA_RE50, k=20, tol=1e-13, ncv=80)
+(HERE / "cylinder_s30k_k20.json").write_text(json.dumps({
+    "case": "S30k", "re": 50.0, "n": es.n, "nnz": int(es.A.nnz), "sigma": [fem.SIGMA_RE50.real, fem.SIGMA_RE50.imag], "k": 20, "ncv": 80,
+    "matrix_sha256_rounded_1e-10": _digest(es), "eigenvalues": [[float(z.real), float(z.imag)] for z in lam], "max_residual": float(res.max()),
+}, indent=1))
+
+TARGET_RE100 = 0.1 + 0.74j  # the reference tabulates shifts up to Re = 90 (.examples/eigenvalues.py:37-49); stated here for Re = 100
+sens = {"re": 100.0, "target": [TARGET_RE100.real, TARGET_RE100.imag], "flow": "Sensitivity/__init__.py:158-311", "cases": {}}
+for case in ("S5k", "S30k"):
+    es = fem.cylinder_case(case, re=100.0)
+    lam_d, _, res_d = shift_invert.solve(es.A, es.M, TARGET_RE100, k=5, tol=1e-13, ncv=60)
+    direct = lam_d[np.argmin(np.abs(lam_d - TARGET_RE100))]
+    AH, MH = es.A.conj().T.tocsr(), es.M.conj().T.tocsr()
+    lam_a, _, res_a = shift_invert.solve(AH, MH, np.conj(TARGET_RE100), k=5, tol=1e-13, ncv=60)
+    adjoint = lam_a[np.argmin(np.abs(lam_a - np.conj(direct)))]
+    sens["cases"][case] = {"n": es.n, "matrix_sha256_rounded_1e-10": _digest(es), "direct": [float(direct.real), float(direct.imag)],
+                           "adjoint": [float(adjoint.real), float(adjoint.imag)],
+                           "direct_nearest5": [[float(z.real), float(z.imag)] for z in lam_d],
+                           "max_residual": float(max(res_d.max(), res_a.max()))}
+(HERE / "sensitivity_re100.json").write_text(json.dumps(sens, indent=1))
 print("wrote", [p.name for p in HERE.glob("*.json")])

@@ -146,8 +146,10 @@ int lsa_blu_apply_launches(const lsa_blu *f, int32_t *launches);
 typedef struct lsa_nd_sym lsa_nd_sym;  /* analysis of a pattern (host only)  */
 typedef struct lsa_ndlu lsa_ndlu;      /* factorisation resident in HBM      */
 /* Host-only analysis of a square CSR pattern (no GPU needed): ordering, elimination forest, front index lists.
- * leaf_size <= 0 picks 128 unknowns per leaf subdomain.  The handle is returned on failure too (for lsa_nd_sym_error). */
-int lsa_nd_analyse(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t leaf_size, lsa_nd_sym **out);
+ * leaf_size <= 0 picks 128 unknowns per leaf subdomain.  constraint: NULL, or n flags marking the unknowns whose diagonal
+ * is numerically zero (the pressure rows of a saddle-point matrix): they are eliminated after all their neighbours, which
+ * keeps every pivot block non-singular.  The handle is returned on failure too (for lsa_nd_sym_error). */
+int lsa_nd_analyse(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t leaf_size, const int8_t *constraint, lsa_nd_sym **out);
 const char *lsa_nd_sym_error(const lsa_nd_sym *h);
 void lsa_nd_sym_destroy(lsa_nd_sym *h);
 /* tree nodes, tree levels, largest front, total length of the front index lists, scalars one solve reads (sum of
@@ -163,14 +165,16 @@ int lsa_nd_sym_export(const lsa_nd_sym *h, int32_t *perm, int32_t *node_start, i
  * matrix entry), lvl_ptr[nlevels + 1] / lvl_nodes[ntree] (nodes by level) */
 int lsa_nd_sym_export_tables(const lsa_nd_sym *h, int32_t *cmap, int32_t *gptr, int32_t *gidx, int64_t *asm_dst, int32_t *lvl_ptr,
                              int32_t *lvl_nodes);
-/* Analysis (from C's host copy of the pattern; reused from the context when the last destroyed factorisation had the same
- * pattern) + numeric factorisation on the device.  LSA_ERR_ZERO_PIVOT when a pivot block is singular to 1e-13 max|C|,
- * LSA_ERR_OOM when the fronts do not fit. */
+/* Analysis (from C's host copy of the pattern; reused from the context when the last destroyed or prepared factorisation
+ * had the same pattern) + numeric factorisation on the device.  If a pivot block comes out singular and C has zero
+ * diagonal entries, the analysis is redone once with those unknowns as constraints.  LSA_ERR_ZERO_PIVOT when a pivot block
+ * is singular to 1e-13 max|C| after that, LSA_ERR_OOM when the fronts do not fit. */
 int lsa_ndlu_create(lsa_ctx *ctx, const lsa_mat *C, int32_t leaf_size, lsa_ndlu **out);
 /* Analysis only, parked in the context: the pattern of P (any matrix with C's pattern, e.g. A) and the scalar type the
  * factors will have.  The next lsa_ndlu_create on that pattern then runs the numeric phase alone.  Lets a caller keep
- * the pattern-only work out of a timed solve (the Python layer calls it from prepare()). */
-int lsa_ndlu_prepare(lsa_ctx *ctx, const lsa_mat *P, int dtype, int32_t leaf_size);
+ * the pattern-only work out of a timed solve (the Python layer calls it from prepare()).  constraint: as for
+ * lsa_nd_analyse (NULL: none). */
+int lsa_ndlu_prepare(lsa_ctx *ctx, const lsa_mat *P, int dtype, int32_t leaf_size, const int8_t *constraint);
 /* new values on the analysed pattern (a shift sweep: .examples/eigenvalues.py:97-108) */
 int lsa_ndlu_refactor(lsa_ctx *ctx, lsa_ndlu *f, const lsa_mat *C);
 void lsa_ndlu_destroy(lsa_ndlu *f);

@@ -12,6 +12,7 @@ struct NdSymbolic {
     int32_t n = 0;
     int64_t nnz = 0;
     uint64_t pattern_hash = 0;
+    uint64_t constraint_hash = 0;  // 0: no constraint unknowns were given; else a hash of the flagged set
     int32_t leaf_size = 0;
     int32_t nt = 0;       // tree nodes
     int32_t nlevels = 0;  // height of the forest + 1
@@ -47,5 +48,7 @@ struct NdSymbolic {
 };
 
 // Analysis of a square pattern (CSR, any order, need not be structurally symmetric).  Returns 0 or a negative lsa_status.
-int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, NdSymbolic* out, char* err, int errlen);
+// constraint: null, or n flags marking the unknowns with a numerically zero diagonal (eliminated after their neighbours)
+int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, const int8_t* constraint, NdSymbolic* out, char* err,
+               int errlen);
 uint64_t nd_pattern_hash(int32_t n, const int32_t* rp, const int32_t* ci);

@@ -223,7 +223,8 @@ uint64_t nd_pattern_hash(int32_t n, const int32_t* rp, const int32_t* ci) {
     return h;
 }
 
-int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, NdSymbolic* out, char* err, int errlen) {
+int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, const int8_t* constraint, NdSymbolic* out, char* err,
+               int errlen) {
     auto fail = [&](int code, const char* msg) {
         if (err && errlen > 0) snprintf(err, (size_t)errlen, "%s", msg);
         return code;
@@ -247,6 +248,51 @@ int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_siz
     std::vector<int32_t> par;
     if (n > 0) dissect(g, leaf_size, own, par);
     const int32_t nt = (int32_t)own.size();
+    S.constraint_hash = 0;
+    if (constraint && nt > 0) {
+        // Saddle-point matrices: an unknown with a (numerically) zero diagonal -- a constraint, the pressure of a mesh
+        // vertex -- is eliminated in the highest tree node that owns one of its neighbours.  All its neighbours then lie
+        // in that node's subtree (they are pairwise linked through the vertex's other unknowns, so they sit on one root
+        // path), every pivot block sees complete constraint rows, and the Schur complement -B F^-1 B^T it receives from
+        // the eliminated neighbours is what the row is pivoted on.  Without this a leaf can hold more constraints than its
+        // interior unknowns support and its pivot block is singular (met on the 3D Taylor-Hood pattern).
+        std::vector<int32_t> depth((size_t)nt, 0), node_of_v((size_t)n, -1);
+        for (int32_t t = 0; t < nt; ++t) depth[(size_t)t] = par[(size_t)t] >= 0 ? depth[(size_t)par[(size_t)t]] + 1 : 0;  // parents are created first
+        for (int32_t t = 0; t < nt; ++t)
+            for (int32_t v : own[(size_t)t]) node_of_v[(size_t)v] = t;
+        std::vector<int32_t> target((size_t)n, -1), left((size_t)nt, 0);
+        for (int32_t t = 0; t < nt; ++t) left[(size_t)t] = (int32_t)own[(size_t)t].size();
+        uint64_t h = 1469598103934665603ull;
+        for (int32_t v = 0; v < n; ++v) {
+            if (!constraint[v]) continue;
+            h ^= (uint64_t)(uint32_t)v;
+            h *= 1099511628211ull;
+            const int32_t t0 = node_of_v[(size_t)v];
+            int32_t best = t0;
+            for (int64_t p = g.ptr[v]; p < g.ptr[(size_t)v + 1]; ++p) {
+                const int32_t t = node_of_v[(size_t)g.adj[(size_t)p]];
+                if (depth[(size_t)t] < depth[(size_t)best]) best = t;
+            }
+            if (best == t0 || left[(size_t)t0] <= 1) continue;
+            int32_t a = t0;  // best must be an ancestor of t0
+            while (a >= 0 && depth[(size_t)a] > depth[(size_t)best]) a = par[(size_t)a];
+            if (a != best) continue;
+            target[(size_t)v] = best;
+            --left[(size_t)t0];
+        }
+        S.constraint_hash = h | 1ull;
+        std::vector<std::vector<int32_t>> moved((size_t)nt);
+        for (int32_t t = 0; t < nt; ++t) {
+            std::vector<int32_t>& L = own[(size_t)t];
+            size_t keep = 0;
+            for (int32_t v : L) {
+                if (target[(size_t)v] >= 0) moved[(size_t)target[(size_t)v]].push_back(v);
+                else L[keep++] = v;
+            }
+            L.resize(keep);
+        }
+        for (int32_t t = 0; t < nt; ++t) own[(size_t)t].insert(own[(size_t)t].end(), moved[(size_t)t].begin(), moved[(size_t)t].end());
+    }
     // post-order numbering (children before parents)
     std::vector<std::vector<int32_t>> kids((size_t)nt);
     std::vector<int32_t> roots;
@@ -463,13 +509,13 @@ struct lsa_nd_sym {
 
 extern "C" {
 
-int lsa_nd_analyse(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t leaf_size, lsa_nd_sym** out) {
+int lsa_nd_analyse(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t leaf_size, const int8_t* constraint, lsa_nd_sym** out) {
     if (!out) return LSA_ERR_ARG;
     lsa_nd_sym* h = new lsa_nd_sym();
     char buf[256] = {0};
     int rc;
     try {
-        rc = nd_analyse(n, rowptr, col, leaf_size, &h->S, buf, (int)sizeof buf);
+        rc = nd_analyse(n, rowptr, col, leaf_size, constraint, &h->S, buf, (int)sizeof buf);
     } catch (const std::bad_alloc&) {
         rc = LSA_ERR_ARG;
         snprintf(buf, sizeof buf, "nd_analyse: out of host memory");

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <functional>
 #include <new>
+#include <string>
 
 #include "lsa_internal.h"
 #include "nd_internal.h"
@@ -167,7 +168,10 @@ __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restri
         const int32_t p = 65535 - (int32_t)(key & 0xFFFFull);
         if (tid == 0) {
             piv[k0 + jj] = p;
-            if (!(__longlong_as_double((long long)(key & ~0xFFFFull)) > tiny2)) atomicCAS(&flag[1], 0, t + 1);
+            if (!(__longlong_as_double((long long)(key & ~0xFFFFull)) > tiny2) && atomicCAS(&flag[1], 0, t + 1) == 0) {
+                flag[2] = k0 + jj;
+                flag[3] = (int32_t)(key >> 32);  // high word of |pivot|^2
+            }
         }
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
@@ -244,7 +248,10 @@ __global__ __launch_bounds__(1024) void nd_gj_panel_big_kernel(const int32_t* __
         const int32_t p = 65535 - (int32_t)(key & 0xFFFFull);
         if (tid == 0) {
             piv[k0 + jj] = p;
-            if (!(__longlong_as_double((long long)(key & ~0xFFFFull)) > tiny2)) atomicCAS(&flag[1], 0, t + 1);
+            if (!(__longlong_as_double((long long)(key & ~0xFFFFull)) > tiny2) && atomicCAS(&flag[1], 0, t + 1) == 0) {
+                flag[2] = k0 + jj;
+                flag[3] = (int32_t)(key >> 32);
+            }
             __hip_atomic_store(&rq[p], k0 + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         if (tid < w) {
@@ -795,10 +802,14 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
     LSA_HIP_CHECK(ctx, hipGetLastError());
     if (hflag[1] != 0) {
         const int32_t t = hflag[1] - 1;
+        const unsigned long long hi = (unsigned long long)(uint32_t)hflag[3] << 32;
+        double mag2;
+        memcpy(&mag2, &hi, sizeof mag2);
         return lsa_set_error(ctx, LSA_ERR_ZERO_PIVOT,
-                             "lsa_ndlu: the pivot block of tree node %d (%d unknowns, level %d) is singular to 1e-13 * max|C|: the matrix is "
-                             "singular, or needs pivoting across fronts",
-                             t, S.m[(size_t)t], S.level[(size_t)t]);
+                             "lsa_ndlu: the pivot block of tree node %d (%d unknowns, front %d, level %d) is singular at its column %d: largest "
+                             "candidate pivot %.3e against max|C| = %.3e (threshold 1e-13 max|C|); the matrix is singular, or needs pivoting "
+                             "across fronts",
+                             t, S.m[(size_t)t], S.f[(size_t)t], S.level[(size_t)t], hflag[2], std::sqrt(mag2), std::sqrt(max2));
     }
     return LSA_OK;
 }
@@ -835,6 +846,34 @@ int ndlu_solve_dev(lsa_ctx* ctx, lsa_ndlu* f, int vdtype, const void* b, void* x
     return nd_apply<double, double>(ctx, f, (const double*)b, (double*)x);
 }
 
+template <typename T>
+__global__ void nd_zero_diag_kernel(int32_t n, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci, const T* __restrict__ val,
+                                    int8_t* __restrict__ flags) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        int8_t z = 1;  // structurally absent counts as zero
+        for (int32_t p = rp[i]; p < rp[i + 1]; ++p)
+            if (ci[p] == (int32_t)i) z = s_abs2(val[p]) == 0.0 ? 1 : 0;
+        flags[i] = z;
+    }
+}
+
+// flags[i] = 1 where the diagonal entry of C is exactly zero (or not stored)
+static int nd_zero_diagonal_flags(lsa_ctx* ctx, const lsa_mat* C, std::vector<int8_t>& flags) {
+    flags.assign((size_t)std::max<int32_t>(C->n, 1), 0);
+    int8_t* d = nullptr;
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&d, flags.size()));
+    const int blocks = std::max(1, std::min((C->n + 255) / 256, ctx->num_cu * 8));
+    if (C->dtype == LSA_C128) hipLaunchKernelGGL((nd_zero_diag_kernel<cplx>), dim3(blocks), dim3(256), 0, ctx->stream, C->n, C->rp, C->ci, (const cplx*)C->val, d);
+    else hipLaunchKernelGGL((nd_zero_diag_kernel<double>), dim3(blocks), dim3(256), 0, ctx->stream, C->n, C->rp, C->ci, (const double*)C->val, d);
+    const hipError_t e = hipMemcpyAsync(flags.data(), d, flags.size(), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess || e2 != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_ndlu: reading the diagonal failed");
+    flags.resize((size_t)C->n);
+    return LSA_OK;
+}
+
 // the last destroyed factorisation of a context is kept (analysis, tables, buffers): a shift sweep refactorises the
 // same pattern once per sigma (.examples/eigenvalues.py:97-108)
 extern "C" void lsa_ndlu_drop_cache(lsa_ctx* ctx) {
@@ -858,7 +897,9 @@ int lsa_ndlu_refactor(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
 
 // analysis + device tables + buffers for the pattern of P and factors of type `dtype`; taken from the context's cache
 // when the parked factorisation matches
-static int nd_symbolic_phase(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t leaf_size, lsa_ndlu** out) {
+// (strict: the parked analysis must also have been made for the same set of constraint unknowns)
+static int nd_symbolic_phase(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t leaf_size, const int8_t* constraint, bool strict,
+                             lsa_ndlu** out) {
     *out = nullptr;
     if (P->n != P->ncols || P->row0 != 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: needs a square, unsharded matrix");
     if ((int64_t)P->h_rp.size() != (int64_t)P->n + 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: the matrix has no host copy of its pattern");
@@ -867,7 +908,17 @@ static int nd_symbolic_phase(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t 
     // same pattern as the parked factorisation: only the numbers change
     if (ctx->nd_cache) {
         lsa_ndlu* c = ctx->nd_cache;
-        if (c->S.n == P->n && c->S.nnz == P->nnz && c->dtype == dtype && c->S.leaf_size == leaf_size &&
+        uint64_t want = 0;
+        if (strict && constraint) {
+            want = 1469598103934665603ull;
+            for (int32_t v = 0; v < P->n; ++v)
+                if (constraint[v]) {
+                    want ^= (uint64_t)(uint32_t)v;
+                    want *= 1099511628211ull;
+                }
+            want |= 1ull;
+        }
+        if (c->S.n == P->n && c->S.nnz == P->nnz && c->dtype == dtype && c->S.leaf_size == leaf_size && (!strict || c->S.constraint_hash == want) &&
             c->S.pattern_hash == nd_pattern_hash(P->n, P->h_rp.data(), P->h_ci.data())) {
             ctx->nd_cache = nullptr;
             c->seconds_analyse = 0.0;
@@ -882,7 +933,7 @@ static int nd_symbolic_phase(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t 
     char buf[256] = {0};
     int rc;
     try {
-        rc = nd_analyse(P->n, P->h_rp.data(), P->h_ci.data(), leaf_size, &f->S, buf, (int)sizeof buf);
+        rc = nd_analyse(P->n, P->h_rp.data(), P->h_ci.data(), leaf_size, constraint, &f->S, buf, (int)sizeof buf);
     } catch (const std::bad_alloc&) {
         rc = LSA_ERR_ARG;
         snprintf(buf, sizeof buf, "lsa_ndlu: out of host memory in the analysis");
@@ -901,10 +952,10 @@ static int nd_symbolic_phase(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t 
     return LSA_OK;
 }
 
-int lsa_ndlu_prepare(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t leaf_size) {
+int lsa_ndlu_prepare(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t leaf_size, const int8_t* constraint) {
     if (!ctx || !P || (dtype != LSA_F64 && dtype != LSA_C128)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_prepare: bad argument");
     lsa_ndlu* f = nullptr;
-    LSA_CHECK(nd_symbolic_phase(ctx, P, dtype, leaf_size, &f));
+    LSA_CHECK(nd_symbolic_phase(ctx, P, dtype, leaf_size, constraint, true, &f));
     lsa_ndlu_drop_cache(ctx);
     ctx->nd_cache = f;  // the next lsa_ndlu_create on this pattern only runs the numeric phase
     return LSA_OK;
@@ -914,8 +965,26 @@ int lsa_ndlu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t leaf_size, lsa_ndlu*
     if (!ctx || !C || !out) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create: null argument");
     *out = nullptr;
     lsa_ndlu* f = nullptr;
-    LSA_CHECK(nd_symbolic_phase(ctx, C, C->dtype, leaf_size, &f));
-    const int rc = lsa_ndlu_refactor(ctx, f, C);
+    LSA_CHECK(nd_symbolic_phase(ctx, C, C->dtype, leaf_size, nullptr, false, &f));
+    int rc = lsa_ndlu_refactor(ctx, f, C);
+    if (rc == LSA_ERR_ZERO_PIVOT && f->S.constraint_hash == 0) {
+        // A pivot block is singular although pivots are searched over its whole columns.  On saddle-point matrices that is
+        // a leaf holding more constraint (zero-diagonal) unknowns than its interior supports: analyse again with those
+        // unknowns eliminated after their neighbours, once.  The new analysis replaces the old one for this pattern.
+        std::vector<int8_t> flags;
+        const int frc = nd_zero_diagonal_flags(ctx, C, flags);
+        bool any = false;
+        for (int8_t v : flags) any |= v != 0;
+        if (frc == LSA_OK && any) {
+            const std::string first = ctx->err;
+            const int32_t leaf = f->S.leaf_size;
+            nd_free(f);
+            f = nullptr;
+            LSA_CHECK(nd_symbolic_phase(ctx, C, C->dtype, leaf, flags.data(), true, &f));
+            rc = lsa_ndlu_refactor(ctx, f, C);
+            if (rc == LSA_ERR_ZERO_PIVOT) lsa_set_error(ctx, rc, "%s (also with the zero-diagonal unknowns eliminated last; first attempt: %s)", std::string(ctx->err).c_str(), first.c_str());
+        }
+    }
     if (rc != LSA_OK) {
         nd_free(f);
         return rc;

@@ -102,7 +102,7 @@ SIGNATURES = {
     "lsa_blu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
     "lsa_blu_apply_bytes": (ctypes.c_int, [_P, ctypes.POINTER(_I64)]),
     "lsa_blu_apply_launches": (ctypes.c_int, [_P, ctypes.POINTER(_I32)]),
-    "lsa_nd_analyse": (ctypes.c_int, [_I32, _P, _P, _I32, _PP]),
+    "lsa_nd_analyse": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _PP]),
     "lsa_nd_sym_error": (ctypes.c_char_p, [_P]),
     "lsa_nd_sym_destroy": (None, [_P]),
     "lsa_nd_sym_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64),
@@ -110,7 +110,7 @@ SIGNATURES = {
     "lsa_nd_sym_export": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "lsa_nd_sym_export_tables": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "lsa_ndlu_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
-    "lsa_ndlu_prepare": (ctypes.c_int, [_P, _P, ctypes.c_int, _I32]),
+    "lsa_ndlu_prepare": (ctypes.c_int, [_P, _P, ctypes.c_int, _I32, _P]),
     "lsa_ndlu_refactor": (ctypes.c_int, [_P, _P, _P]),
     "lsa_ndlu_destroy": (None, [_P]),
     "lsa_ndlu_solve": (ctypes.c_int, [_P, _P, _P, _P]),
@@ -332,9 +332,12 @@ class CsrMatrix:
         )
         return cls(ctx, h, (A.shape[0], n_global), A.nnz, dt)
 
-    def prepare_lu(self, complex_factors: bool, leaf_size: int = 0) -> None:
-        """Pattern-only phase of the nested-dissection LU for matrices with this pattern (``lsa_ndlu_prepare``)."""
-        self.ctx.check(self.ctx._lib.lsa_ndlu_prepare(self.ctx.handle, self.handle, LSA_C128 if complex_factors else LSA_F64, int(leaf_size)))
+    def prepare_lu(self, complex_factors: bool, leaf_size: int = 0, constraint=None) -> None:
+        """Pattern-only phase of the nested-dissection LU for matrices with this pattern (``lsa_ndlu_prepare``);
+        ``constraint``: optional mask of the zero-diagonal unknowns to eliminate after their neighbours."""
+        flags = None if constraint is None else np.ascontiguousarray(constraint, dtype=np.int8)
+        self.ctx.check(self.ctx._lib.lsa_ndlu_prepare(self.ctx.handle, self.handle, LSA_C128 if complex_factors else LSA_F64, int(leaf_size),
+                                                      None if flags is None else _ptr(flags)))
 
     def axpby(self, other: "CsrMatrix", alpha: complex, beta: complex, dtype=None) -> "CsrMatrix":
         """alpha*self + beta*other on the shared pattern (MatAXPY, Solver/eigen2.py:110-111)."""
@@ -463,7 +466,9 @@ class NdAnalysis:
     """Host-only analysis of the nested-dissection multifrontal LU (``lsa_nd_analyse``): ordering, elimination forest
     and the index tables of the device kernels.  Needs no GPU; used by the tests and by sizing tools."""
 
-    def __init__(self, A, leaf_size: int = 0):
+    def __init__(self, A, leaf_size: int = 0, constraint=None):
+        """``constraint``: optional boolean mask of the unknowns with a numerically zero diagonal (eliminated after all
+        their neighbours: the pressure rows of a saddle-point matrix)."""
         import scipy.sparse as sp
 
         A = sp.csr_matrix(A)
@@ -474,7 +479,10 @@ class NdAnalysis:
         rp = np.ascontiguousarray(A.indptr, dtype=np.int32)
         ci = np.ascontiguousarray(A.indices, dtype=np.int32)
         h = ctypes.c_void_p()
-        rc = self._lib.lsa_nd_analyse(self.n, _ptr(rp), _ptr(ci), int(leaf_size), ctypes.byref(h))
+        flags = None if constraint is None else np.ascontiguousarray(constraint, dtype=np.int8)
+        if flags is not None and flags.shape != (self.n,):
+            raise ValueError("constraint mask must have one entry per row")
+        rc = self._lib.lsa_nd_analyse(self.n, _ptr(rp), _ptr(ci), int(leaf_size), None if flags is None else _ptr(flags), ctypes.byref(h))
         self.handle = h
         if rc != 0:
             msg = self._lib.lsa_nd_sym_error(h).decode(errors="replace")

@@ -328,6 +328,194 @@ def cylinder_case(name: str = "S30k", re: float = 50.0) -> EigenSystem:
 
 
 # --------------------------------------------------------------------------------------------------
+# 3D: unit-cube duct, Taylor-Hood P2/P1 on Kuhn tetrahedra (BASELINE config 4)
+# --------------------------------------------------------------------------------------------------
+# The reference's 3D case is the unit cube cut into tetrahedra (``.examples/cube.py:37``: ``Mesher(Shape.UNIT_CUBE,
+# (20, 20, 20), iCellType.TETRAHEDRON)``, Re = 10) with ``config_files/3D/unit_cube/mesh_tags.toml`` /``bcs.toml``:
+# velocity Dirichlet on the inlet x = 0 and on the four walls, pressure Dirichlet on the outlet x = 1.  Restated here
+# on n^3 cubes of six Kuhn tetrahedra each (all share the cube's main diagonal); the P2 nodes are exactly the
+# (2n + 1)^3 lattice (cube-edge, face-diagonal and body-diagonal midpoints).  Row degrees: 3 x 10 + 4 = 34 unknowns per
+# tetrahedron, mean row length ~ 95 at 5 M unknowns (SURVEY.md 8d quotes ~ 99).
+
+
+def _tet_rule(n: int = 4) -> tuple[np.ndarray, np.ndarray]:
+    """Collapsed Gauss-Legendre rule on the unit tetrahedron, exact to degree 2n - 3 (5 for n = 4: the convective and
+    shear terms with a P2 base flow).  Returns barycentric points (Q, 4) and weights summing to 1/6."""
+    g, w = np.polynomial.legendre.leggauss(n)
+    g, w = 0.5 * (g + 1.0), 0.5 * w
+    u, v, t = np.meshgrid(g, g, g, indexing="ij")
+    wu, wv, wt = np.meshgrid(w, w, w, indexing="ij")
+    x = u.ravel()
+    y = (v * (1.0 - u)).ravel()
+    z = (t * (1.0 - u) * (1.0 - v)).ravel()
+    wq = (wu * wv * wt * (1.0 - u) ** 2 * (1.0 - v)).ravel()
+    lam = np.stack([1.0 - x - y - z, x, y, z], axis=1)
+    return lam, wq
+
+
+_TET_EDGES = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
+
+
+def _p2_tet_tables(lam: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """P2 basis (Q, 10) and d(basis)/d(lambda_i) (Q, 10, 4) on a tetrahedron; order: 4 vertices, then the edges
+    01 02 03 12 13 23."""
+    Q = lam.shape[0]
+    phi = np.empty((Q, 10))
+    d = np.zeros((Q, 10, 4))
+    for i in range(4):
+        phi[:, i] = lam[:, i] * (2.0 * lam[:, i] - 1.0)
+        d[:, i, i] = 4.0 * lam[:, i] - 1.0
+    for e, (i, j) in enumerate(_TET_EDGES):
+        phi[:, 4 + e] = 4.0 * lam[:, i] * lam[:, j]
+        d[:, 4 + e, i] = 4.0 * lam[:, j]
+        d[:, 4 + e, j] = 4.0 * lam[:, i]
+    return phi, d
+
+
+@dataclass
+class CubeMesh:
+    """n^3 cubes of the unit cube, six Kuhn tetrahedra each; P2 nodes on the (2n + 1)^3 lattice, z fastest."""
+
+    n: int
+
+    @property
+    def n_nodes(self) -> int:
+        return (2 * self.n + 1) ** 3
+
+    def node(self, i, j, k):
+        L = 2 * self.n + 1
+        return (i * L + j) * L + k
+
+    def node_xyz(self) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        g = np.linspace(0.0, 1.0, 2 * self.n + 1)
+        X, Y, Z = np.meshgrid(g, g, g, indexing="ij")
+        return X.ravel(), Y.ravel(), Z.ravel()
+
+    def is_vertex(self) -> np.ndarray:
+        a = np.arange(2 * self.n + 1)
+        I, J, K = np.meshgrid(a, a, a, indexing="ij")
+        return ((I % 2 == 0) & (J % 2 == 0) & (K % 2 == 0)).ravel()
+
+    def tetrahedra(self) -> np.ndarray:
+        """(E, 10) node ids per tetrahedron in P2 order (positively oriented)."""
+        import itertools
+
+        a = np.arange(self.n)
+        ci, cj, ck = (2 * g.ravel() for g in np.meshgrid(a, a, a, indexing="ij"))
+        base = np.stack([ci, cj, ck], axis=1)  # lattice position of every cube's (0, 0, 0) corner
+        out = []
+        for perm in itertools.permutations(range(3)):
+            # Kuhn path (0,0,0) -> +e_perm[0] -> +e_perm[1] -> (1,1,1); odd permutations are mirrored: swap two vertices
+            corners = [np.zeros(3, dtype=np.int64)]
+            for ax in perm:
+                nxt = corners[-1].copy()
+                nxt[ax] += 2
+                corners.append(nxt)
+            sign = np.linalg.det(np.array([c - corners[0] for c in corners[1:]], dtype=float))
+            if sign < 0:
+                corners[2], corners[3] = corners[3], corners[2]
+            loc = corners + [(corners[i] + corners[j]) // 2 for i, j in _TET_EDGES]
+            out.append(np.stack([self.node(base[:, 0] + l[0], base[:, 1] + l[1], base[:, 2] + l[2]) for l in loc], axis=1))
+        return np.concatenate(out, axis=0)
+
+
+def duct_baseflow(X, Y, Z, *, peak: float = 1.0):
+    """Analytic fully developed-like duct profile U = (peak * 16 y (1 - y) z (1 - z), 0, 0): no slip on the four walls."""
+    return peak * 16.0 * Y * (1.0 - Y) * Z * (1.0 - Z), np.zeros_like(X), np.zeros_like(X)
+
+
+def assemble_linearized_ns_3d(mesh: CubeMesh, re: float = 10.0, *, baseflow=duct_baseflow, chunk: int = 20_000) -> EigenSystem:
+    """(A, M) of the linearised Navier-Stokes operator on the unit cube: the forms of the module docstring in 3D, mixed
+    34 x 34 coupling per tetrahedron (stored zeros in the pressure block and the cross-component mass entries)."""
+    tets = mesh.tetrahedra()
+    X, Y, Z = mesh.node_xyz()
+    P = np.stack([X, Y, Z], axis=1)
+    isv = mesh.is_vertex()
+    n_nodes = mesh.n_nodes
+    node_offset = 3 * np.arange(n_nodes) + np.concatenate([[0], np.cumsum(isv)[:-1]])
+    n = int(3 * n_nodes + isv.sum())
+    U = np.stack(baseflow(X, Y, Z), axis=1)  # (nodes, 3)
+
+    lam, wq = _tet_rule(4)
+    phi, dphi = _p2_tet_tables(lam)  # (Q,10), (Q,10,4)
+    psi = lam  # P1 basis (Q,4)
+
+    rows_l, cols_l, a_l, m_l = [], [], [], []
+    for s0 in range(0, len(tets), chunk):
+        tet = tets[s0 : s0 + chunk]
+        E = len(tet)
+        v = P[tet[:, :4]]  # (E,4,3)
+        J = np.stack([v[:, 1] - v[:, 0], v[:, 2] - v[:, 0], v[:, 3] - v[:, 0]], axis=2)  # columns = edge vectors
+        det = np.linalg.det(J)
+        if np.any(det <= 0):
+            raise ValueError("degenerate or inverted tetrahedron")
+        Jinv = np.linalg.inv(J)  # rows = gradients of lambda_1..3
+        gl = np.empty((E, 4, 3))
+        gl[:, 1:] = Jinv
+        gl[:, 0] = -Jinv.sum(axis=1)
+        w = wq[None, :] * det[:, None]  # (E,Q): sum wq = 1/6 -> volume
+        g = np.einsum("qai,eik->eqak", dphi, gl)  # physical gradients of the P2 basis (E,Q,10,3)
+        Uq = np.einsum("qa,eac->eqc", phi, U[tet])  # (E,Q,3)
+        dU = np.einsum("eqak,eac->eqck", g, U[tet])  # dU_c/dx_k (E,Q,3,3)
+        mass = np.einsum("eq,qa,qb->eab", w, phi, phi)
+        stiff = np.einsum("eq,eqak,eqbk->eab", w, g, g)
+        adv = np.einsum("eqk,eqbk->eqb", Uq, g)  # U.grad(phi_b)
+        conv = np.einsum("eq,qa,eqb->eab", w, phi, adv)
+        Ae = np.zeros((E, 34, 34))
+        Me = np.zeros((E, 34, 34))
+        for i in range(3):
+            si = slice(10 * i, 10 * i + 10)
+            for j in range(3):
+                sj = slice(10 * j, 10 * j + 10)
+                Ae[:, si, sj] -= np.einsum("eq,eq,qa,qb->eab", w, dU[:, :, i, j], phi, phi)  # (phi_b dU_i/dx_j, phi_a)
+            Ae[:, si, si] -= conv + stiff / re
+            Me[:, si, si] = mass
+            G = np.einsum("eq,qc,eqa->eac", w, psi, g[..., i])  # (psi_c, d phi_a / dx_i)
+            Ae[:, si, 30:34] += G
+            Ae[:, 30:34, si] += np.transpose(G, (0, 2, 1))
+        ldofs = np.concatenate([node_offset[tet], node_offset[tet] + 1, node_offset[tet] + 2, node_offset[tet[:, :4]] + 3], axis=1)  # (E,34)
+        rows_l.append(np.repeat(ldofs, 34, axis=1).ravel().astype(np.int32))
+        cols_l.append(np.tile(ldofs, (1, 34)).ravel().astype(np.int32))
+        a_l.append(Ae.ravel())
+        m_l.append(Me.ravel())
+
+    rows = np.concatenate(rows_l)
+    cols = np.concatenate(cols_l)
+    A = sp.coo_matrix((np.concatenate(a_l), (rows, cols)), shape=(n, n)).tocsr()
+    M = sp.coo_matrix((np.concatenate(m_l), (rows, cols)), shape=(n, n)).tocsr()
+    A.sort_indices()
+    M.sort_indices()
+    assert np.array_equal(A.indptr, M.indptr) and np.array_equal(A.indices, M.indices)
+
+    # velocity Dirichlet: inlet x = 0 (marker 1) and the walls y, z in {0, 1} (markers 3-6); pressure Dirichlet on the
+    # outlet x = 1 (marker 2): config_files/3D/unit_cube/bcs.toml, homogeneous for the perturbation
+    tol = 1e-12
+    vel_nodes = np.flatnonzero((X < tol) | (Y < tol) | (Y > 1 - tol) | (Z < tol) | (Z > 1 - tol))
+    ddofs = np.concatenate([node_offset[vel_nodes] + c for c in range(3)])
+    dofs_p = node_offset[isv] + 3
+    out_p = node_offset[np.flatnonzero(isv & (X > 1 - tol))] + 3
+    ddofs = np.sort(np.concatenate([ddofs, out_p]))
+    dflag = np.zeros(n, dtype=bool)
+    dflag[ddofs] = True
+    live = np.add.reduceat((~dflag[A.indices]) & (A.data != 0.0), A.indptr[:-1]) > 0
+    ddofs = np.union1d(ddofs, dofs_p[~live[dofs_p]])  # pressure unknowns with every velocity neighbour pinned
+    A = _apply_dirichlet(A, ddofs)
+    M = _apply_dirichlet(M, ddofs)
+    mask = np.ones(n, dtype=bool)
+    mask[dofs_p] = False
+    return EigenSystem(A, M, np.flatnonzero(mask).astype(np.int32), dofs_p.astype(np.int32), ddofs.astype(np.int32), mesh, node_offset)
+
+
+CUBE_CASES = {"C2k": 4, "C9k": 7, "C20k": 9, "C40k": 11, "C80k": 14, "C160k": 18, "C300k": 22, "C1M": 34, "C5M": 58}
+SIGMA_CUBE = -5.0  # shift of the 3D case: next to the least stable physical modes of the Re = 10 duct (-5.99, -6.00, -6.8, ...) and
+# away from the spurious lambda = 1 of the identity Dirichlet rows; real, so the factors are float64
+
+
+def cube_case(name: str = "C20k", re: float = 10.0) -> EigenSystem:
+    return assemble_linearized_ns_3d(CubeMesh(CUBE_CASES[name]), re)
+
+
+# --------------------------------------------------------------------------------------------------
 # membrane benchmark (scalar P2 Laplace)
 # --------------------------------------------------------------------------------------------------
 

@@ -5,6 +5,8 @@
 * ``cylinder_s2k.json``: the oracle's output on the deterministic S2k pair (the reference ships no (A, M) fixture,
   so these numbers are pinned by the oracle alone; see DESIGN.md "parity").
 * ``cylinder_s30k_k20.json``: the oracle's 20 eigenvalues nearest the Re = 50 target on S30k (BASELINE config 2).
+* ``cube_c20k.json``: the oracle's 10 eigenvalues nearest the 3D target on the C20k unit-cube pair (BASELINE config 4's
+  discretisation at a size the oracle factorises in seconds).
 * ``sensitivity_re100.json``: direct eigenvalue nearest the target and the adjoint one (of (A^H, M^H) at the conjugate
   target) at Re = 100 on S5k and S30k (BASELINE config 5; flow of Sensitivity/__init__.py:158-311).
 """
@@ -78,4 +80,11 @@ for case in ("S5k", "S30k"):
                            "direct_nearest5": [[float(z.real), float(z.imag)] for z in lam_d],
                            "max_residual": float(max(res_d.max(), res_a.max()))}
 (HERE / "sensitivity_re100.json").write_text(json.dumps(sens, indent=1))
+
+es = fem.cube_case("C20k")
+lam, V, res = shift_invert.solve(es.A, es.M, fem.SIGMA_CUBE, k=10, tol=1e-13, ncv=60)
+(HERE / "cube_c20k.json").write_text(json.dumps({
+    "case": "C20k", "re": 10.0, "n": es.n, "nnz": int(es.A.nnz), "sigma": [float(np.real(fem.SIGMA_CUBE)), float(np.imag(fem.SIGMA_CUBE))], "k": 10,
+    "matrix_sha256_rounded_1e-10": _digest(es), "eigenvalues": [[float(z.real), float(z.imag)] for z in lam], "max_residual": float(res.max()),
+}, indent=1))
 print("wrote", [p.name for p in HERE.glob("*.json")])

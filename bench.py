@@ -14,11 +14,15 @@ reported under config.other_pc so both numbers are always on the line.
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1 (this round): the embarrassingly parallel "replicas" layout of SURVEY.md section 8e -- every rank runs the N = 1
-workload (same pair, the Re = 50 shift), so the per-GPU work is fixed as N grows ("weak") and there is no data-path
-collective.  `--sweep` gives each rank its own shift of the reference's Re-sweep table (.examples/eigenvalues.py:37-49)
-instead; the shifts need 116-259 operator applies each, so that variant measures load imbalance, not the GPUs.  The
-row-sharded single-problem layout is described in DESIGN.md.
+N > 1, default `--layout sharded` (the layout BASELINE.json's north_star names): ONE problem, its rows cut into N blocks,
+one rank per GPU.  Each rank holds its rows of A, M, C = A - sigma M and the exact LU of its diagonal block; the Krylov
+bases are replicated; every SpMV and every preconditioner apply ends with one in-place all-gather (RCCL over xGMI);
+the inner solve is GMRES preconditioned by the block-Jacobi LU.  Total work is fixed as N grows ("strong"); `value`
+counts the pairs of that one problem.  The line carries the inner iterations per apply and the all-gather traffic.
+`--layout replicas` (reported as config.replicas in the sharded line too): every rank solves the N = 1 workload on its
+own, no data-path collective ("weak"); `--sweep` gives each rank its own shift of the reference's Re-sweep table
+(.examples/eigenvalues.py:37-49) instead.  Rehearsal on one GPU: LSA_BENCH_DEVICE=0 LSA_BENCH_BACKEND=gloo (all ranks on
+device 0, host-staged all-gather through gloo).
 
 Rank 0 prints ONE JSON line.  `roofline` is measured on the SpMV kernel (the kernel the metric names) on SROOF, a
 ~1.5e8-nnz CSR with the cylinder-flow row pattern that does not fit the 256 MB Infinity Cache; `cpu_baseline` is the
@@ -65,13 +69,13 @@ def log(msg: str) -> None:
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
-def build_solver(es, sigma, args, device, pc):
+def build_solver(es, sigma, args, device, pc, layout="single"):
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
     cfg = EigensolverConfig(num_eig=args.k, atol=args.atol, ncv=args.ncv, max_it=500)
     kw = {"ilu_levels": args.ilu_levels} if pc == "ilu" else {}
-    solver = EigenSolver(es.A, es.M, cfg, check_hermitian=False, restart=args.restart, device=device, **kw)
+    solver = EigenSolver(es.A, es.M, cfg, check_hermitian=False, restart=args.restart, device=device, layout=layout, **kw)
     solver.solver.set_st_type(iSTType.SINVERT)
     solver.solver.set_target(sigma)
     solver.solver.set_st_pc_type(PreconditionerType.ILU if pc == "ilu" else PreconditionerType.LU)
@@ -236,7 +240,9 @@ def main() -> None:
     ap.add_argument("--ncv", type=int, default=80)
     ap.add_argument("--atol", type=float, default=1e-10)
     ap.add_argument("--pc", choices=("lu", "ilu"), default="lu")
-    ap.add_argument("--sweep", action="store_true", help="N > 1: one shift of the Re-sweep table per rank instead of N replicas of the Re = 50 solve")
+    ap.add_argument("--layout", choices=("sharded", "replicas"), default=None,
+                    help="N > 1: 'sharded' (default) = one problem row-sharded over the ranks; 'replicas' = one independent solve per rank")
+    ap.add_argument("--sweep", action="store_true", help="replicas layout: one shift of the Re-sweep table per rank instead of N copies of the Re = 50 solve")
     ap.add_argument("--no-other-pc", action="store_true", help="skip the single timed solve of the other inner-solver variant")
     ap.add_argument("--ilu-levels", type=int, default=6, help="fill level of the ILU variant: 2/3/4/6/8/12 -> 14.5/12.2/9.7/8.1/8.2/10.1 s per S30k solve")
     ap.add_argument("--restart", type=int, default=1000)
@@ -273,11 +279,15 @@ def main() -> None:
 
     from synthetic import fem
 
+    layout = "single" if world == 1 else (args.layout or "sharded")
+    if args.sweep:
+        layout = "replicas"
+    sharded = layout == "sharded"
     es = fem.cylinder_case(args.case)
     sigma = SWEEP_SIGMAS[(2 + rank) % len(SWEEP_SIGMAS)] if args.sweep else SWEEP_SIGMAS[2]
-    log(f"rank {rank}/{world}: {args.case} n={es.n} nnz={es.A.nnz} sigma={sigma}")
-    solver = build_solver(es, sigma, args, device, args.pc)
-    solver.solver.prepare()  # ordering + upload: (A, M) now resident in HBM
+    log(f"rank {rank}/{world}: {args.case} n={es.n} nnz={es.A.nnz} sigma={sigma} layout={layout}")
+    solver = build_solver(es, sigma, args, device, args.pc, "sharded" if sharded else "single")
+    solver.solver.prepare()  # ordering + upload: (A, M) -- this rank's rows when sharded -- now resident in HBM
 
     def barrier():
         if dist is not None:
@@ -305,13 +315,35 @@ def main() -> None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        p = torch.tensor([total_pairs], dtype=torch.float64, device=reduce_device)
-        dist.all_reduce(p, op=dist.ReduceOp.SUM)
-        total_pairs = float(p.item())
+        if not sharded:  # replicas: every rank solved a problem of its own; sharded: the ranks solved ONE problem together
+            p = torch.tensor([total_pairs], dtype=torch.float64, device=reduce_device)
+            dist.all_reduce(p, op=dist.ReduceOp.SUM)
+            total_pairs = float(p.item())
     lam_gpu = np.array([solver.solver.get_eigenvalue(i) for i in range(min(args.k, solver.solver.get_num_converged()))])
     solver.solver.release()
+    replicas = None
+    if sharded and not args.no_other_pc:
+        # secondary figure: the same N GPUs as N independent solves of the N = 1 workload (no data-path collective)
+        try:
+            so = build_solver(es, sigma, args, device, args.pc)
+            so.solver.prepare()
+            so.solve()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                so.solve()
+            barrier()
+            dt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=reduce_device)
+            dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            nrep = torch.tensor([2.0 * int(np.sum(so.solver.residuals()[: args.k] <= RESIDUAL_TOL))], dtype=torch.float64, device=reduce_device)
+            dist.all_reduce(nrep, op=dist.ReduceOp.SUM)
+            replicas = {"eigenpairs_per_s": float(nrep.item()) / float(dt.item()), "ms_per_step": 1e3 * float(dt.item()) / 2, "scaling": "weak",
+                        "note": "secondary: one independent solve of the N = 1 workload per rank"}
+            so.solver.release()
+        except Exception as exc:  # noqa: BLE001  (every rank takes the same path: the collectives above stay matched)
+            replicas = {"error": f"{type(exc).__name__}: {exc}"}
     other = None
-    if rank == 0 and not args.no_other_pc:
+    if rank == 0 and not args.no_other_pc and world == 1:
         opc = "ilu" if args.pc == "lu" else "lu"
         try:  # the other inner-solver variant is informative only: it must never cost the bench line
             so = build_solver(es, sigma, args, device, opc)
@@ -338,7 +370,7 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
             "dtype": "c128",
             "data": "synthetic",
@@ -349,7 +381,14 @@ def main() -> None:
                                else f"inner solves: ILU({args.ilu_levels})-GMRES({args.restart}), blocked SpTRSV"),
                 "pc": args.pc,
                 "other_pc": other,
-                "layout": ("one shift of the Re sweep per rank" if args.sweep else "replicas of the N = 1 workload") if world > 1 else "single GPU",
+                "layout": "single GPU" if world == 1 else "sharded" if sharded else "replicas: one shift of the Re sweep per rank" if args.sweep
+                          else "replicas of the N = 1 workload",
+                "parallelism": None if world == 1 else (f"rows of one problem over {world} ranks, replicated Krylov bases, block-Jacobi LU + GMRES, "
+                                                        "all-gather after every SpMV and preconditioner apply" if sharded else f"{world} independent solves"),
+                "gmres_iters_per_apply": (stats.get("gmres_iters", 0) / max(stats.get("op_applies", 1), 1)) if sharded else None,
+                "allgather_calls_per_solve": stats.get("allgather_calls") if sharded else None,
+                "allgather_bytes_received_per_rank_per_solve": stats.get("allgather_bytes_received") if sharded else None,
+                "replicas": replicas,
                 "converged_per_solve": nconv,
                 "max_residual": float(res[: args.k].max()) if len(res) else None,
                 "op_applies_per_solve": stats.get("op_applies"),

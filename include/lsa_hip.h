@@ -261,6 +261,14 @@ void lsa_mm_close(lsa_mm *h);
  * torch.distributed), every rank then calls lsa_comm_init. */
 int lsa_comm_unique_id(void *id128);
 int lsa_comm_init(lsa_ctx *ctx, int nranks, int rank, const void *id128);
+/* The same layout with a host-staged exchange instead of RCCL: the library copies this rank's block to a host buffer of
+ * nranks * bytes_per_rank bytes (block r at r * bytes_per_rank), calls fn, which must fill the other ranks' blocks
+ * (returning 0), and copies the buffer back to the device.  For tests and rehearsals with several ranks on ONE GPU (RCCL
+ * refuses two ranks on a device) and for launchers whose only transport is a host one (torch.distributed over gloo). */
+typedef int (*lsa_host_allgather_fn)(void *host_buf, int64_t bytes_per_rank, void *user);
+int lsa_comm_init_host(lsa_ctx *ctx, int nranks, int rank, lsa_host_allgather_fn fn, void *user);
+/* all-gathers issued on this context and the bytes this rank received through them */
+int lsa_comm_stats(const lsa_ctx *ctx, int64_t *calls, int64_t *bytes_received);
 /* Row-block shard of a global CSR: this rank owns rows [row0, row1); x and y of lsa_spmv stay global-length
  * and replicated, each rank computes its rows and the blocks are exchanged with ncclAllGather.
  * Padded block layout: the global index space is nranks equal blocks of B_pad = n_global / nranks slots, rank r owns

@@ -455,7 +455,7 @@ class iEpsSolver:
             dAd = lsa_hip.CsrMatrix.from_scipy(ctx, sharding.diagonal_block(Ap, part, rank))
             dMd = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, sharding.diagonal_block(Mp, part, rank))
             if world > 1:
-                ctx.comm_init(world, rank, _dist_broadcast_bytes(ctx.unique_id() if rank == 0 else None))
+                _dist_comm_init(ctx, world, rank)
         else:
             dA = lsa_hip.CsrMatrix.from_scipy(ctx, Ap)
             dM = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, Mp)
@@ -479,6 +479,7 @@ class iEpsSolver:
         """Free the device copies made by :meth:`prepare`."""
         prep = getattr(self, "_prepared", None)
         self._prepared = None
+        self._comm_seen = {"allgather_calls": 0, "allgather_bytes_received": 0}  # counters live in the context
         if prep is not None:
             ctx = prep.pop("ctx")
             prep.clear()
@@ -552,6 +553,12 @@ class iEpsSolver:
             X[perm, :] = vecs
             self._stats = op.stats()
             self._stats["krylov_restarts"] = res.restarts
+            if part is not None:
+                now = ctx.comm_stats()
+                last = getattr(self, "_comm_seen", {"allgather_calls": 0, "allgather_bytes_received": 0})
+                self._stats.update({k: now[k] - last[k] for k in now})  # of this solve
+                self._comm_seen = now
+                self._stats["ranks"] = part.nranks
             if self._stats.get("pc_fallback"):
                 logger.warning("The exact LU did not fit the device memory: the inner solves ran ILU(%d)-preconditioned GMRES instead.",
                                prep["levels"])
@@ -641,6 +648,36 @@ def _dist_rank_world() -> tuple[int, int]:
     except ImportError:
         pass
     return 0, 1
+
+
+_host_group = None
+
+
+def _dist_comm_init(ctx, world: int, rank: int) -> None:
+    """Bootstrap the all-gather of the sharded layout from the torch.distributed job: RCCL over xGMI when the job runs
+    the nccl backend (one GPU per rank), the host-staged transport over gloo otherwise (CPU-only process groups, several
+    ranks sharing one GPU in tests and rehearsals; ``LSA_COMM_TRANSPORT=host`` forces it)."""
+    import os
+
+    import torch.distributed as dist
+
+    if dist.get_backend() == "nccl" and os.environ.get("LSA_COMM_TRANSPORT", "rccl") != "host":
+        ctx.comm_init(world, rank, _dist_broadcast_bytes(ctx.unique_id() if rank == 0 else None))
+        return
+    import torch
+
+    global _host_group
+    group = None
+    if dist.get_backend() != "gloo":
+        if _host_group is None:
+            _host_group = dist.new_group(backend="gloo")
+        group = _host_group
+
+    def exchange(blocks: np.ndarray) -> None:  # (world, bytes) uint8 view of the library's staging buffer
+        t = torch.from_numpy(blocks)
+        dist.all_gather([t[r] for r in range(world)], t[rank].clone(), group=group)
+
+    ctx.comm_init_host(world, rank, exchange)
 
 
 def _dist_broadcast_bytes(payload: bytes | None) -> bytes:

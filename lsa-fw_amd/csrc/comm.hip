@@ -61,6 +61,30 @@ constexpr int kNcclChar = 0;  // ncclInt8 / ncclChar
 // r * bytes_per_rank) is this rank's contribution when r == ctx->rank
 int k_allgather_inplace(lsa_ctx* ctx, void* vec, size_t bytes_per_rank) {
     if (ctx->nranks <= 1) return LSA_OK;
+    ++ctx->comm_calls;
+    ctx->comm_bytes += (int64_t)bytes_per_rank * (ctx->nranks - 1);  // received per rank
+    if (ctx->host_gather) {
+        // host-staged transport (lsa_comm_init_host): own block to pinned memory, the caller's exchange (e.g.
+        // torch.distributed over gloo), everything back.  Same layout and call sites as the RCCL path.
+        const size_t total = bytes_per_rank * (size_t)ctx->nranks;
+        if (total > ctx->comm_stage_bytes) {
+            LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->comm_stage) (void)hipHostFree(ctx->comm_stage);
+            ctx->comm_stage = nullptr;
+            ctx->comm_stage_bytes = 0;
+            LSA_HIP_CHECK(ctx, hipHostMalloc(&ctx->comm_stage, total * 2, hipHostMallocDefault));
+            ctx->comm_stage_bytes = total * 2;
+        }
+        char* stage = (char*)ctx->comm_stage;
+        const size_t off = (size_t)ctx->rank * bytes_per_rank;
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(stage + off, (const char*)vec + off, bytes_per_rank, hipMemcpyDeviceToHost, ctx->stream));
+        LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+        const int hrc = ctx->host_gather(stage, (int64_t)bytes_per_rank, ctx->host_gather_user);
+        if (hrc != 0) return lsa_set_error(ctx, LSA_ERR_COMM, "host all-gather callback failed (%d)", hrc);
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(vec, stage, total, hipMemcpyHostToDevice, ctx->stream));
+        LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));  // the staging buffer is reused by the next exchange
+        return LSA_OK;
+    }
     Rccl& r = rccl();
     if (!r.handle || !ctx->comm) return lsa_set_error(ctx, LSA_ERR_COMM, "all-gather requested without an initialised communicator");
     const char* send = (const char*)vec + (size_t)ctx->rank * bytes_per_rank;
@@ -75,6 +99,12 @@ void comm_release(lsa_ctx* ctx) {
         if (r.handle) r.comm_destroy((nccl_comm)ctx->comm);
         ctx->comm = nullptr;
     }
+    if (ctx->comm_stage) (void)hipHostFree(ctx->comm_stage);
+    ctx->comm_stage = nullptr;
+    ctx->comm_stage_bytes = 0;
+    ctx->host_gather = nullptr;
+    ctx->nranks = 1;
+    ctx->rank = 0;
 }
 
 extern "C" {
@@ -96,6 +126,7 @@ int lsa_comm_init(lsa_ctx* ctx, int nranks, int rank, const void* id128) {
         ctx->rank = 0;
         return LSA_OK;
     }
+    comm_release(ctx);  // a second initialisation replaces the first
     Rccl& r = rccl();
     if (!r.handle) return lsa_set_error(ctx, LSA_ERR_COMM, "RCCL unavailable: %s", r.why.c_str());
     LSA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -107,6 +138,25 @@ int lsa_comm_init(lsa_ctx* ctx, int nranks, int rank, const void* id128) {
     ctx->comm = comm;
     ctx->nranks = nranks;
     ctx->rank = rank;
+    return LSA_OK;
+}
+
+int lsa_comm_init_host(lsa_ctx* ctx, int nranks, int rank, lsa_host_allgather_fn fn, void* user) {
+    if (!ctx || nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !fn)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_comm_init_host: bad argument");
+    comm_release(ctx);
+    ctx->nranks = nranks;
+    ctx->rank = rank;
+    if (nranks > 1) {
+        ctx->host_gather = fn;
+        ctx->host_gather_user = user;
+    }
+    return LSA_OK;
+}
+
+int lsa_comm_stats(const lsa_ctx* ctx, int64_t* calls, int64_t* bytes_received) {
+    if (!ctx) return LSA_ERR_ARG;
+    if (calls) *calls = ctx->comm_calls;
+    if (bytes_received) *bytes_received = ctx->comm_bytes;
     return LSA_OK;
 }
 

@@ -96,6 +96,12 @@ struct lsa_ctx {
     // RCCL (multi-GPU); null when single-process
     void* comm = nullptr;
     int nranks = 1, rank = 0;
+    // host-staged transport (tests and rehearsals on one GPU; RCCL refuses two ranks on one device)
+    lsa_host_allgather_fn host_gather = nullptr;
+    void* host_gather_user = nullptr;
+    void* comm_stage = nullptr;
+    size_t comm_stage_bytes = 0;
+    int64_t comm_calls = 0, comm_bytes = 0;  // all-gathers issued, bytes received by this rank
     // the last destroyed block LU (symbolic data + buffers), reused when the next one has the same pattern and shape:
     // a shift sweep refactorises the same pattern once per sigma (.examples/eigenvalues.py:97-108)
     struct lsa_blu* blu_cache = nullptr;
@@ -131,6 +137,7 @@ struct lsa_mat {
 };
 
 int lsa_set_error(lsa_ctx* ctx, int code, const char* fmt, ...);
+void comm_release(lsa_ctx* ctx);  // comm.hip
 int lsa_ensure_scratch(lsa_ctx* ctx, size_t dbytes, size_t hbytes);
 
 #define LSA_HIP_CHECK(ctx, expr)                                                                         \

@@ -138,9 +138,12 @@ SIGNATURES = {
     "lsa_mm_close": (None, [_P]),
     "lsa_comm_unique_id": (ctypes.c_int, [_P]),
     "lsa_comm_init": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P]),
+    "lsa_comm_init_host": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, _P]),
+    "lsa_comm_stats": (ctypes.c_int, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "lsa_csr_upload_shard": (ctypes.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, ctypes.c_int, _PP]),
 }
 
+_HOST_GATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p)
 _lib = None
 
 
@@ -250,6 +253,29 @@ class Context:
     def comm_init(self, nranks: int, rank: int, uid: bytes) -> None:
         buf = ctypes.create_string_buffer(uid, 128)
         self.check(self._lib.lsa_comm_init(self.handle, nranks, rank, buf))
+
+    def comm_init_host(self, nranks: int, rank: int, exchange) -> None:
+        """Host-staged all-gather: ``exchange(buffer)`` receives a writable uint8 numpy view of ``nranks`` equal blocks with
+        this rank's block filled in and must fill the others (``lsa_comm_init_host``)."""
+
+        def _cb(host_buf, bytes_per_rank, _user):
+            try:
+                view = np.ctypeslib.as_array((ctypes.c_uint8 * (int(bytes_per_rank) * nranks)).from_address(host_buf))
+                exchange(view.reshape(nranks, int(bytes_per_rank)))
+                return 0
+            except Exception:  # noqa: BLE001  (must not propagate through the C frame)
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._host_cb = _HOST_GATHER_FN(_cb)  # keep the trampoline alive as long as the context
+        self.check(self._lib.lsa_comm_init_host(self.handle, nranks, rank, ctypes.cast(self._host_cb, ctypes.c_void_p), None))
+
+    def comm_stats(self) -> dict:
+        calls, nbytes = _I64(0), _I64(0)
+        self._lib.lsa_comm_stats(self.handle, ctypes.byref(calls), ctypes.byref(nbytes))
+        return {"allgather_calls": calls.value, "allgather_bytes_received": nbytes.value}
 
 
 class DeviceVector:

@@ -1,7 +1,7 @@
 """GPU tests of the row-sharded layout that one GPU can run: the degenerate one-rank job (padded block layout,
 shard upload, sharded operator builder, masked start vectors, block-local ordering) must reproduce the single-GPU
 answer, and shards of a two-rank partition must reproduce their rows of the global SpMV.  The RCCL exchange itself
-needs >= 2 GPUs and is covered on CPU by the gloo emulation in tests/test_sharding_cpu.py.
+needs >= 2 GPUs; with several ranks on this one GPU the same device path runs over the host-staged transport (gloo).
 """
 
 import numpy as np
@@ -54,3 +54,66 @@ def test_two_rank_shards_reproduce_global_spmv(hip_ctx):
     ref = es.A @ x
     assert np.linalg.norm(part.unpad_vector(yp) - ref) <= 1e-13 * np.linalg.norm(ref)
     assert np.all(yp[part.pad_vector(np.ones(es.n)) == 0] == 0)  # padding untouched
+
+
+def _rank_main(rank: int, world: int, port: int, out_dir: str, case: str, pc: str) -> None:
+    """One rank of a sharded solve; all ranks share GPU 0 and exchange through the host-staged transport (gloo)."""
+    import os
+    import sys
+    from pathlib import Path
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = Path(__file__).resolve().parents[1]
+    sys.path[:0] = [str(root), str(root / "lsa-fw_amd"), str(root / "tests")]
+    import torch.distributed as dist
+
+    from oracle import fem
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    es = fem.cylinder_case(case)
+    kw = {"ilu_levels": 2} if pc == "ilu" else {}
+    solver = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=5, atol=1e-10, ncv=40), check_hermitian=False, layout="sharded", **kw)
+    solver.solver.set_st_type(iSTType.SINVERT)
+    solver.solver.set_target(fem.SIGMA_RE50)
+    solver.solver.set_st_pc_type(PreconditionerType.ILU if pc == "ilu" else PreconditionerType.LU)
+    pairs = solver.solve()
+    lam = np.array([p[0] for p in pairs[:5]])
+    V = np.column_stack([p[1].as_array() for p in pairs[:5]])
+    st = solver.solver.stats
+    np.savez(Path(out_dir) / f"rank{rank}.npz", lam=lam, V=V, res=solver.solver.residuals()[:5], gmres=st["gmres_iters"], applies=st["op_applies"],
+             gathers=st["allgather_calls"], nbytes=st["allgather_bytes_received"], ranks=st["ranks"])
+    solver.solver.release()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pc", [(2, "lu"), (3, "lu"), (2, "ilu")])
+def test_sharded_solve_with_several_ranks_on_one_gpu(tmp_path, world, pc):
+    """The whole device path of the sharded layout with more than one rank: shard upload in the padded block layout,
+    block-Jacobi factors (exact nested-dissection LU of each rank's diagonal block, or ILU(2)), GMRES over the replicated
+    basis, one all-gather after every SpMV and every preconditioner apply.  The ranks share this box's single GPU, so
+    the exchange runs through the host-staged transport (gloo) instead of RCCL: same call sites, same layout."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from oracle import fem, shift_invert
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    case = "S2k"
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), case, pc), nprocs=world, join=True)
+    out = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for o in out[1:]:  # replicated bases, fixed-order reductions: bit-identical on every rank, no all-reduce anywhere
+        assert np.array_equal(o["lam"], out[0]["lam"]) and np.array_equal(o["V"], out[0]["V"])
+    es = fem.cylinder_case(case)
+    ref, _, _ = shift_invert.solve(es.A, es.M, fem.SIGMA_RE50, k=5, tol=1e-13)
+    for r in ref:
+        assert np.min(np.abs(out[0]["lam"] - r)) <= 1e-8 * abs(r)
+    assert out[0]["res"].max() <= 1e-8
+    assert shift_invert.compute_residuals(es.A, es.M, out[0]["lam"], out[0]["V"]).max() <= 1e-8
+    assert int(out[0]["ranks"]) == world and int(out[0]["gathers"]) > 2 * int(out[0]["applies"])
+    assert int(out[0]["gmres"]) > int(out[0]["applies"])  # block-Jacobi over > 1 rank: the inner solves iterate

@@ -150,6 +150,13 @@ typedef struct lsa_ndlu lsa_ndlu;      /* factorisation resident in HBM      */
  * is numerically zero (the pressure rows of a saddle-point matrix): they are eliminated after all their neighbours, which
  * keeps every pivot block non-singular.  The handle is returned on failure too (for lsa_nd_sym_error). */
 int lsa_nd_analyse(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t leaf_size, const int8_t *constraint, lsa_nd_sym **out);
+/* The same analysis for a tree the caller provides, optionally localised for one rank of a subtree-parallel
+ * factorisation.  Node t owns the matrix indices [first[t], first[t] + size[t]) (nodes in any order in which parent[] can be
+ * looked up; -1 = root); owner[t] (NULL on one rank) = the rank whose subtree the node belongs to, -1 = the replicated top
+ * of the tree.  Rows that belong to no node must be empty (padding of the sharded block layout).  The tables then hold
+ * this rank's own nodes, the top, and the other ranks' subtree roots as childless "ghost" nodes. */
+int lsa_nd_analyse_tree(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t ntree, const int32_t *first, const int32_t *size,
+                        const int32_t *parent, const int32_t *owner, int32_t rank, int32_t nranks, lsa_nd_sym **out);
 const char *lsa_nd_sym_error(const lsa_nd_sym *h);
 void lsa_nd_sym_destroy(lsa_nd_sym *h);
 /* tree nodes, tree levels, largest front, total length of the front index lists, scalars one solve reads (sum of
@@ -165,6 +172,12 @@ int lsa_nd_sym_export(const lsa_nd_sym *h, int32_t *perm, int32_t *node_start, i
  * matrix entry), lvl_ptr[nlevels + 1] / lvl_nodes[ntree] (nodes by level) */
 int lsa_nd_sym_export_tables(const lsa_nd_sym *h, int32_t *cmap, int32_t *gptr, int32_t *gidx, int64_t *asm_dst, int32_t *lvl_ptr,
                              int32_t *lvl_nodes);
+/* per kept node: kind[ntree] (1 = factored on this rank, 2 = replicated top, 3 = another rank's subtree root), front_off /
+ * u_off[ntree + 1] (offsets into the front / update-vector buffers; the subtree roots lie in per-rank slots at the start),
+ * asm_src[scalars[3]] (matrix entry of every assembly slot), children_ptr[ntree + 1] / children_idx; scalars[6] = front
+ * slot, update-vector slot, first replicated work level, assembly entries, ranks, rank */
+int lsa_nd_sym_export_dist(const lsa_nd_sym *h, int32_t *kind, int64_t *front_off, int64_t *u_off, int32_t *asm_src, int32_t *children_ptr,
+                           int32_t *children_idx, int64_t *scalars);
 /* Analysis (from C's host copy of the pattern; reused from the context when the last destroyed or prepared factorisation
  * had the same pattern) + numeric factorisation on the device.  If a pivot block comes out singular and C has zero
  * diagonal entries, the analysis is redone once with those unknowns as constraints.  LSA_ERR_ZERO_PIVOT when a pivot block
@@ -175,6 +188,14 @@ int lsa_ndlu_create(lsa_ctx *ctx, const lsa_mat *C, int32_t leaf_size, lsa_ndlu 
  * the pattern-only work out of a timed solve (the Python layer calls it from prepare()).  constraint: as for
  * lsa_nd_analyse (NULL: none). */
 int lsa_ndlu_prepare(lsa_ctx *ctx, const lsa_mat *P, int dtype, int32_t leaf_size, const int8_t *constraint);
+/* Subtree-parallel form (one process per GPU, after lsa_comm_init*): every rank holds the whole matrix C and calls this with
+ * the same forest (arguments as for lsa_nd_analyse_tree; the context's rank selects the localisation).  A rank factors
+ * the subtrees it owns; the subtree roots' fronts are exchanged by one in-place all-gather; the top of the forest
+ * (owner -1) is then factored redundantly by every rank.  A solve exchanges the subtree roots' update vectors (a few KB)
+ * between the upward sweep over the own subtrees and the replicated top; it returns the entries of x that belong to this
+ * rank's subtrees and to the top (the caller's all-gather of x completes it).  Failures are agreed on collectively. */
+int lsa_ndlu_create_tree(lsa_ctx *ctx, const lsa_mat *C, int32_t ntree, const int32_t *first, const int32_t *size, const int32_t *parent,
+                         const int32_t *owner, lsa_ndlu **out);
 /* new values on the analysed pattern (a shift sweep: .examples/eigenvalues.py:97-108) */
 int lsa_ndlu_refactor(lsa_ctx *ctx, lsa_ndlu *f, const lsa_mat *C);
 void lsa_ndlu_destroy(lsa_ndlu *f);
@@ -283,6 +304,14 @@ int lsa_csr_upload_shard(lsa_ctx *ctx, int32_t n_global, int32_t row0, int32_t r
  * collective and the Hessenberg matrices are bit-identical on every rank. */
 int lsa_op_create_sharded(lsa_ctx *ctx, const lsa_mat *A_rows, const lsa_mat *M_rows, const lsa_mat *A_diag,
                           const lsa_mat *M_diag, const double sigma[2], int mode, const lsa_op_options *opts, lsa_op **out);
+
+/* Shift-invert operator of the subtree-parallel layout: every rank holds the WHOLE matrices A, M in the padded block layout
+ * (n_pad x n_pad, empty padding rows) and the forest of lsa_ndlu_create_tree; it multiplies with its rows [row0, row1) (then
+ * all-gather) and solves with the subtree-parallel exact LU (own subtrees, one small all-gather, replicated top, all-gather
+ * of the solution): three collectives per operator apply and no inner iteration.  mode 0 or 2, opts->pc_type 2. */
+int lsa_op_create_dist(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, int32_t row0, int32_t row1, int32_t ntree, const int32_t *first,
+                       const int32_t *size, const int32_t *parent, const int32_t *owner, const double sigma[2], int mode,
+                       const lsa_op_options *opts, lsa_op **out);
 
 #ifdef __cplusplus
 }

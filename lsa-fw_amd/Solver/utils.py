@@ -437,8 +437,25 @@ class iEpsSolver:
         Ap = _permute(A, perm)
         Mp = None if M is None else _permute(M, perm)
         ctx = lsa_hip.Context(self._device)
-        part = dAd = dMd = None
-        if self._layout == "sharded":
+        part = dAd = dMd = forest = None
+        world = _dist_rank_world()[1] if self._layout == "sharded" else 1
+        if self._layout == "sharded" and world > 1 and pc_code == 2 and sinvert:
+            # Subtree-parallel exact LU (the LU-class setting of the reference, sharded): the nested-dissection forest is cut
+            # over the ranks, a rank's unknowns are one row block of the padded layout, every rank holds the whole (A, M)
+            # -- it multiplies with its rows and factors its subtrees plus the replicated top of the forest.
+            from lsa_hip import sharding
+
+            rank = _dist_rank_world()[0]
+            Kc = sp.csr_matrix(K)
+            zd = Kc.diagonal() == 0
+            an = lsa_hip.NdAnalysis(Kc, 0, constraint=zd if zd.any() else None)  # (constraints last: no retry across ranks)
+            ex = an.export()
+            forest = sharding.partition_forest(ex["perm"], ex["node_start"], ex["parent"], ex["front_size"], world)
+            perm, part = forest.order, forest.rows
+            dA = lsa_hip.CsrMatrix.from_scipy(ctx, sharding.pad_square(_permute(A, perm), part))
+            dM = None if M is None else lsa_hip.CsrMatrix.from_scipy(ctx, sharding.pad_square(_permute(M, perm), part))
+            _dist_comm_init(ctx, world, rank)
+        elif self._layout == "sharded":
             # one process per GPU: rows of the permuted pair go to the ranks of torch.distributed (RCCL bootstrap through it)
             from lsa_hip import sharding
 
@@ -459,7 +476,7 @@ class iEpsSolver:
         else:
             dA = lsa_hip.CsrMatrix.from_scipy(ctx, Ap)
             dM = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, Mp)
-        if pc_code == 2 and K is not None:
+        if pc_code == 2 and K is not None and forest is None:
             # pattern-only phase of the nested-dissection LU (ordering, elimination forest, index tables, buffers)
             cplx_factors = bool(np.iscomplexobj(K)) or (sinvert and complex(sigma).imag != 0.0)
             fac = dAd if dAd is not None else dA
@@ -472,6 +489,7 @@ class iEpsSolver:
                 zero_diag = zd if zd.any() else None
             fac.prepare_lu(cplx_factors, constraint=zero_diag)
         self._prepared = {"sig": self._signature(), "ctx": ctx, "dA": dA, "dM": dM, "dAd": dAd, "dMd": dMd, "part": part, "perm": perm,
+                          "forest": forest,
                           "n": n, "sinvert": sinvert, "cayley": self._st_type is iSTType.CAYLEY, "sigma": sigma, "pc_code": pc_code,
                           "levels": levels}
 
@@ -523,7 +541,9 @@ class iEpsSolver:
                 ctx, prep["dA"], prep["dM"], sigma, mode=2 if cayley else 0 if sinvert else 1, antishift=nu, ilu_levels=prep["levels"],
                 ilu_shift=self._ilu_shift,
                 ksp_rtol=ksp_rtol, ksp_restart=_restart_length(self._restart_len, n), ksp_maxit=self._ksp_max_it, pc_type=prep["pc_code"],
-                A_diag=prep["dAd"], M_diag=prep["dMd"],
+                A_diag=prep["dAd"], M_diag=prep["dMd"], forest=prep["forest"],
+                rows=None if prep["forest"] is None else (_dist_rank_world()[0] * prep["part"].b_pad,
+                                                          _dist_rank_world()[0] * prep["part"].b_pad + int(np.diff(prep["part"].starts)[_dist_rank_world()[0]])),
             )
             part = prep["part"]
             keep = None

@@ -33,6 +33,23 @@ int lsa_ensure_scratch(lsa_ctx* ctx, size_t dbytes, size_t hbytes) {
     return LSA_OK;
 }
 
+lsa_mat* mat_row_view(const lsa_mat* full, int32_t r0, int32_t r1) {
+    lsa_mat* v = new lsa_mat();
+    v->ctx = full->ctx;
+    v->n = r1 - r0;
+    v->ncols = full->ncols;
+    v->row0 = r0;
+    v->nnz = (int64_t)full->h_rp[(size_t)r1] - full->h_rp[(size_t)r0];
+    v->dtype = full->dtype;
+    v->rp = full->rp + r0;  // row pointers keep their global offsets: ci / val are the viewed matrix's arrays
+    v->ci = full->ci;
+    v->val = full->val;
+    v->owns_index = false;
+    v->owns_values = false;
+    v->ci16_state = -1;  // no compressed-index form for views
+    return v;
+}
+
 extern "C" {
 
 int lsa_ctx_create(int device, lsa_ctx** out) {
@@ -200,7 +217,7 @@ void lsa_mat_destroy(lsa_mat* m) {
         if (m->rp) (void)hipFree(m->rp);
         if (m->ci) (void)hipFree(m->ci);
     }
-    if (m->val) (void)hipFree(m->val);
+    if (m->val && m->owns_values) (void)hipFree(m->val);
     if (m->ci16) (void)hipFree(m->ci16);
     if (m->cbase) (void)hipFree(m->cbase);
     delete m;

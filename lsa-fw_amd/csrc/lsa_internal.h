@@ -128,6 +128,7 @@ struct lsa_mat {
     int32_t* ci;      // device, nnz
     void* val;        // device, nnz
     bool owns_index;  // false when the index arrays are shared with another matrix
+    bool owns_values = true;  // false for a row view (mat_row_view): every device array belongs to the viewed matrix
     std::vector<int32_t> h_rp, h_ci;  // host copy of the pattern (analysis phases)
     // compressed column indices for the SpMV (built on first use): col = cbase[row] + ci16[p] when every row spans
     // fewer than 65 536 columns (banded FEM matrices do); ci16_state: 0 = not tried, 1 = available, -1 = does not fit
@@ -137,6 +138,8 @@ struct lsa_mat {
 };
 
 int lsa_set_error(lsa_ctx* ctx, int code, const char* fmt, ...);
+// rows [r0, r1) of a square matrix as a shard (n = r1 - r0, row0 = r0): borrows every array, must not outlive `full`
+lsa_mat* mat_row_view(const lsa_mat* full, int32_t r0, int32_t r1);
 void comm_release(lsa_ctx* ctx);  // comm.hip
 int lsa_ensure_scratch(lsa_ctx* ctx, size_t dbytes, size_t hbytes);
 

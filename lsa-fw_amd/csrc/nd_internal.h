@@ -14,10 +14,17 @@ struct NdSymbolic {
     uint64_t pattern_hash = 0;
     uint64_t constraint_hash = 0;  // 0: no constraint unknowns were given; else a hash of the flagged set
     int32_t leaf_size = 0;
-    int32_t nt = 0;       // tree nodes
-    int32_t nlevels = 0;  // height of the forest + 1
+    uint64_t tree_hash = 0;        // 0: the tree came from the library's own dissection; else a hash of the caller's tree
+    int32_t nt = 0;       // tree nodes this rank keeps (all of them on one rank)
+    int32_t nlevels = 0;  // work levels (entries of lvl_ptr - 1)
+    int32_t nranks = 1, rank = 0;  // subtree-parallel factorisation: the ranks the forest is split over
+    int32_t phase_b_level = 0;     // work levels [0, phase_b_level) are this rank's own subtrees, the rest the replicated top
+    int64_t xfront_slot = 0;       // scalars per rank in the exchange region at the start of the front buffer
+    int64_t xu_slot = 0;           // entries per rank in the exchange region at the start of the update-vector buffer
+    std::vector<int32_t> kind;     // per kept node: 1 = factored here (own subtree), 2 = replicated top, 3 = another rank's subtree root
+    std::vector<int32_t> piv_off;  // per kept node: first elimination position (offset into the pivot arrays of length n)
     std::vector<int32_t> perm;        // elimination order: perm[k] = original index of the k-th eliminated unknown
-    std::vector<int32_t> node_start;  // nt + 1: node t owns perm[node_start[t] .. node_start[t + 1])
+    std::vector<int32_t> node_start;  // nt + 1: node t owns perm[node_start[t] .. node_start[t + 1]) (one rank; else running sums of m)
     std::vector<int32_t> parent;      // nt, -1 for roots
     std::vector<int32_t> level;       // nt: 0 for leaves, 1 + max(children) otherwise
     std::vector<int32_t> m, f;        // nt: own size, front size (boundary b = f - m)
@@ -36,7 +43,7 @@ struct NdSymbolic {
     // update-vector buffer that child c of node t contributes to front position j, or -1
     std::vector<int64_t> ge_off;      // nt + 1
     std::vector<int32_t> gell;
-    // assembly of the original entries: front_buffer[asm_dst[e]] = values[asm_src[e]]
+    // assembly of the matrix entries this rank's fronts need: front_buffer[asm_dst[e]] = values[asm_src[e]]
     std::vector<int32_t> asm_src;
     std::vector<int64_t> asm_dst;
     // nodes sorted by (level, own size descending): lvl_nodes[lvl_ptr[l] .. lvl_ptr[l + 1])
@@ -48,6 +55,8 @@ struct NdSymbolic {
 };
 
 // Analysis of a square pattern (CSR, any order, need not be structurally symmetric).  Returns 0 or a negative lsa_status.
+int nd_analyse_tree(int32_t n, const int32_t* rp, const int32_t* ci, int32_t nt, const int32_t* first, const int32_t* size, const int32_t* parent,
+                    const int32_t* owner, int rank, int nranks, NdSymbolic* out, char* err, int errlen);
 // constraint: null, or n flags marking the unknowns with a numerically zero diagonal (eliminated after their neighbours)
 int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, const int8_t* constraint, NdSymbolic* out, char* err,
                int errlen);

@@ -223,24 +223,358 @@ uint64_t nd_pattern_hash(int32_t n, const int32_t* rp, const int32_t* ci) {
     return h;
 }
 
-int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, const int8_t* constraint, NdSymbolic* out, char* err,
-               int errlen) {
-    auto fail = [&](int code, const char* msg) {
+namespace {
+
+struct Fail {
+    char* err;
+    int errlen;
+    int operator()(int code, const char* msg) const {
         if (err && errlen > 0) snprintf(err, (size_t)errlen, "%s", msg);
         return code;
+    }
+};
+
+// Everything after the tree is known.  `own` / `par`: unknowns and parent of every tree node (any numbering in which a
+// parent can be looked up); `owner`: null, or per tree node the rank whose subtree it belongs to (-1 = the replicated top
+// of the tree).  With an owner map the tables are localised for `rank`: nodes of other ranks' subtrees are dropped, except
+// their roots, which stay as "ghost" leaves whose fronts and update vectors arrive by all-gather.
+int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Graph& g, std::vector<std::vector<int32_t>>& own,
+              std::vector<int32_t>& par, const int32_t* owner, int rank, int nranks, const Fail& fail) {
+    const int32_t nt = (int32_t)own.size();
+    // post-order numbering (children before parents)
+    std::vector<std::vector<int32_t>> kids((size_t)nt);
+    std::vector<int32_t> roots;
+    for (int32_t t = 0; t < nt; ++t) (par[t] >= 0 ? kids[(size_t)par[t]] : roots).push_back(t);
+    std::vector<int32_t> newid((size_t)nt, -1), seq;
+    seq.reserve((size_t)nt);
+    {
+        std::vector<std::pair<int32_t, size_t>> st;
+        for (int32_t r : roots) {
+            st.emplace_back(r, 0);
+            while (!st.empty()) {
+                auto& top = st.back();
+                if (top.second < kids[(size_t)top.first].size()) {
+                    const int32_t c = kids[(size_t)top.first][top.second++];
+                    st.emplace_back(c, 0);
+                } else {
+                    newid[(size_t)top.first] = (int32_t)seq.size();
+                    seq.push_back(top.first);
+                    st.pop_back();
+                }
+            }
+        }
+    }
+    if ((int32_t)seq.size() != nt) return fail(LSA_ERR_ARG, "nd_analyse: the parent array does not describe a forest");
+    // ---- the global forest ----
+    std::vector<int32_t> gstart((size_t)nt + 1, 0), gparent((size_t)nt, -1), gm((size_t)nt, 0), gowner((size_t)nt, 0);
+    S.perm.clear();
+    S.perm.reserve((size_t)n);
+    for (int32_t k = 0; k < nt; ++k) {
+        const int32_t t = seq[(size_t)k];
+        S.perm.insert(S.perm.end(), own[(size_t)t].begin(), own[(size_t)t].end());
+        gstart[(size_t)k + 1] = (int32_t)S.perm.size();
+        gm[(size_t)k] = (int32_t)own[(size_t)t].size();
+        gparent[(size_t)k] = par[t] >= 0 ? newid[(size_t)par[t]] : -1;
+        gowner[(size_t)k] = owner ? owner[t] : 0;
+    }
+    own.clear();
+    const int32_t nreal = (int32_t)S.perm.size();  // unknowns that belong to a tree node (all of them unless the matrix is padded)
+    std::vector<int32_t> pos((size_t)n, -1), node_of((size_t)std::max(nreal, 1));
+    for (int32_t k = 0; k < nreal; ++k) {
+        const int32_t v = S.perm[(size_t)k];
+        if (v < 0 || v >= n || pos[(size_t)v] >= 0) return fail(LSA_ERR_ARG, "nd_analyse: the tree's unknowns are not distinct indices of the matrix");
+        pos[(size_t)v] = k;
+    }
+    for (int32_t i = 0; i < n; ++i) {
+        const bool real = pos[(size_t)i] >= 0;
+        for (int32_t p = rp[i]; p < rp[i + 1]; ++p)
+            if (!real || pos[(size_t)ci[p]] < 0) return fail(LSA_ERR_ARG, "nd_analyse: a matrix entry lies in a row or column that belongs to no tree node");
+    }
+    for (int32_t t = 0; t < nt; ++t)
+        for (int32_t k = gstart[(size_t)t]; k < gstart[(size_t)t + 1]; ++k) node_of[(size_t)k] = t;
+    std::vector<int32_t> gchild_ptr((size_t)nt + 1, 0), gchild_idx, glevel((size_t)nt, 0);
+    for (int32_t t = 0; t < nt; ++t)
+        if (gparent[(size_t)t] >= 0) ++gchild_ptr[(size_t)gparent[(size_t)t] + 1];
+    for (int32_t t = 0; t < nt; ++t) gchild_ptr[(size_t)t + 1] += gchild_ptr[(size_t)t];
+    gchild_idx.assign((size_t)gchild_ptr[(size_t)nt], 0);
+    {
+        std::vector<int32_t> fillc(gchild_ptr.begin(), gchild_ptr.end() - 1);
+        for (int32_t t = 0; t < nt; ++t)
+            if (gparent[(size_t)t] >= 0) gchild_idx[(size_t)fillc[(size_t)gparent[(size_t)t]]++] = t;
+    }
+    for (int32_t t = 0; t < nt; ++t)
+        if (gparent[(size_t)t] >= 0) glevel[(size_t)gparent[(size_t)t]] = std::max(glevel[(size_t)gparent[(size_t)t]], glevel[(size_t)t] + 1);
+    // boundary (struct) of every node in elimination positions
+    std::vector<std::vector<int32_t>> bnd((size_t)nt);
+    {
+        std::vector<int32_t> stamp((size_t)std::max(nreal, 1), -1);
+        for (int32_t t = 0; t < nt; ++t) {
+            const int32_t a = gstart[(size_t)t], b = gstart[(size_t)t + 1];
+            std::vector<int32_t>& L = bnd[(size_t)t];
+            for (int32_t k = a; k < b; ++k) {
+                const int32_t v = S.perm[(size_t)k];
+                for (int64_t p = g.ptr[v]; p < g.ptr[(size_t)v + 1]; ++p) {
+                    const int32_t q = pos[(size_t)g.adj[(size_t)p]];
+                    if (q >= b && stamp[(size_t)q] != t) {
+                        stamp[(size_t)q] = t;
+                        L.push_back(q);
+                    }
+                }
+            }
+            for (int32_t cp = gchild_ptr[(size_t)t]; cp < gchild_ptr[(size_t)t + 1]; ++cp)
+                for (int32_t q : bnd[(size_t)gchild_idx[(size_t)cp]])
+                    if (q >= b && stamp[(size_t)q] != t) {
+                        stamp[(size_t)q] = t;
+                        L.push_back(q);
+                    }
+            std::sort(L.begin(), L.end());
+            if (!L.empty() && gparent[(size_t)t] < 0) return fail(LSA_ERR_ARG, "nd_analyse: internal error (root with a boundary)");
+        }
+    }
+    g.adj.clear();
+    g.adj.shrink_to_fit();
+    // ---- the nodes this rank keeps ----
+    const bool dist = owner != nullptr && nranks > 1;
+    S.nranks = dist ? nranks : 1;
+    S.rank = dist ? rank : 0;
+    std::vector<int32_t> kind((size_t)nt, 1), loc((size_t)nt, -1), keep;  // 1 own, 2 top (replicated), 3 ghost root, 0 dropped
+    if (dist) {
+        for (int32_t t = 0; t < nt; ++t) {
+            const int32_t o = gowner[(size_t)t], p = gparent[(size_t)t];
+            if (o >= nranks) return fail(LSA_ERR_ARG, "nd_analyse: owner rank out of range");
+            if (o < 0) {
+                kind[(size_t)t] = 2;
+                if (p >= 0 && gowner[(size_t)p] >= 0) return fail(LSA_ERR_ARG, "nd_analyse: a replicated node lies below a rank's subtree");
+            } else {
+                if (p >= 0 && gowner[(size_t)p] >= 0 && gowner[(size_t)p] != o) return fail(LSA_ERR_ARG, "nd_analyse: a subtree is split between ranks");
+                const bool root = p < 0 || gowner[(size_t)p] < 0;
+                kind[(size_t)t] = o == rank ? 1 : (root && p >= 0 ? 3 : 0);
+            }
+        }
+    }
+    for (int32_t t = 0; t < nt; ++t)
+        if (kind[(size_t)t] != 0) {
+            loc[(size_t)t] = (int32_t)keep.size();
+            keep.push_back(t);
+        }
+    const int32_t nl = (int32_t)keep.size();
+    S.nt = nl;
+    S.m.assign((size_t)nl, 0);
+    S.f.assign((size_t)nl, 0);
+    S.parent.assign((size_t)nl, -1);
+    S.level.assign((size_t)nl, 0);
+    S.kind.assign((size_t)nl, 1);
+    S.piv_off.assign((size_t)nl, 0);
+    S.node_start.assign((size_t)nl + 1, 0);
+    for (int32_t q = 0; q < nl; ++q) {
+        const int32_t t = keep[(size_t)q];
+        S.m[(size_t)q] = gm[(size_t)t];
+        S.f[(size_t)q] = gm[(size_t)t] + (int32_t)bnd[(size_t)t].size();
+        S.parent[(size_t)q] = gparent[(size_t)t] >= 0 ? loc[(size_t)gparent[(size_t)t]] : -1;
+        if (gparent[(size_t)t] >= 0 && S.parent[(size_t)q] < 0) return fail(LSA_ERR_ARG, "nd_analyse: internal error (kept node with a dropped parent)");
+        S.level[(size_t)q] = glevel[(size_t)t];
+        S.kind[(size_t)q] = kind[(size_t)t];
+        S.piv_off[(size_t)q] = gstart[(size_t)t];
+        S.node_start[(size_t)q + 1] = S.node_start[(size_t)q] + gm[(size_t)t];
+    }
+    if (!dist) S.node_start.assign(gstart.begin(), gstart.end());
+    // children among the kept nodes (ghost roots keep none)
+    S.child_ptr.assign((size_t)nl + 1, 0);
+    for (int32_t q = 0; q < nl; ++q)
+        if (S.parent[(size_t)q] >= 0) ++S.child_ptr[(size_t)S.parent[(size_t)q] + 1];
+    for (int32_t q = 0; q < nl; ++q) S.child_ptr[(size_t)q + 1] += S.child_ptr[(size_t)q];
+    S.child_idx.assign((size_t)S.child_ptr[(size_t)nl], 0);
+    {
+        std::vector<int32_t> fillc(S.child_ptr.begin(), S.child_ptr.end() - 1);
+        for (int32_t q = 0; q < nl; ++q)
+            if (S.parent[(size_t)q] >= 0) S.child_idx[(size_t)fillc[(size_t)S.parent[(size_t)q]]++] = q;
+    }
+    S.max_children = 0;
+    S.nlevels = 0;
+    for (int32_t q = 0; q < nl; ++q) {
+        S.max_children = std::max(S.max_children, S.child_ptr[(size_t)q + 1] - S.child_ptr[(size_t)q]);
+        S.nlevels = std::max(S.nlevels, S.level[(size_t)q] + 1);
+    }
+    // ---- offsets: the fronts and update vectors of the subtree roots lie in one slot per rank at the start of their
+    // buffers (the exchange regions of the in-place all-gathers), everything else behind them ----
+    auto is_xroot = [&](int32_t q) { return dist && S.kind[(size_t)q] != 2 && S.parent[(size_t)q] >= 0 && S.kind[(size_t)S.parent[(size_t)q]] == 2; };
+    S.idx_off.assign((size_t)nl + 1, 0);
+    S.front_off.assign((size_t)nl + 1, 0);
+    S.u_off.assign((size_t)nl + 1, 0);
+    S.cmap_off.assign((size_t)nl + 1, 0);
+    S.g_off.assign((size_t)nl + 1, 0);
+    S.ge_off.assign((size_t)nl + 1, 0);
+    S.xfront_slot = S.xu_slot = 0;
+    {
+        std::vector<int64_t> fuse((size_t)S.nranks, 0), uuse((size_t)S.nranks, 0);
+        if (dist) {
+            for (int32_t t = 0; t < nt; ++t) {  // slot sizes from the GLOBAL forest: every rank must agree on them
+                const int32_t o = gowner[(size_t)t], p = gparent[(size_t)t];
+                if (o >= 0 && p >= 0 && gowner[(size_t)p] < 0) {
+                    const int64_t f = gm[(size_t)t] + (int64_t)bnd[(size_t)t].size(), b = (int64_t)bnd[(size_t)t].size();
+                    fuse[(size_t)o] += f * f;
+                    uuse[(size_t)o] += b;
+                }
+            }
+            for (int r = 0; r < S.nranks; ++r) {
+                S.xfront_slot = std::max(S.xfront_slot, fuse[(size_t)r]);
+                S.xu_slot = std::max(S.xu_slot, uuse[(size_t)r]);
+            }
+            std::fill(fuse.begin(), fuse.end(), 0);
+            std::fill(uuse.begin(), uuse.end(), 0);
+        }
+        int64_t frun = S.xfront_slot * S.nranks, urun = S.xu_slot * S.nranks;
+        for (int32_t q = 0; q < nl; ++q) {
+            const int64_t m = S.m[(size_t)q], f = S.f[(size_t)q], b = f - m;
+            const int32_t nchild = S.child_ptr[(size_t)q + 1] - S.child_ptr[(size_t)q];
+            S.idx_off[(size_t)q + 1] = S.idx_off[(size_t)q] + f;
+            S.cmap_off[(size_t)q + 1] = S.cmap_off[(size_t)q] + (int32_t)b;
+            S.g_off[(size_t)q + 1] = S.g_off[(size_t)q] + f + 1;
+            S.ge_off[(size_t)q + 1] = S.ge_off[(size_t)q] + (int64_t)nchild * f;
+            if (is_xroot(q)) {
+                const int32_t o = gowner[(size_t)keep[(size_t)q]];
+                S.front_off[(size_t)q] = S.xfront_slot * o + fuse[(size_t)o];
+                S.u_off[(size_t)q] = S.xu_slot * o + uuse[(size_t)o];
+                fuse[(size_t)o] += f * f;
+                uuse[(size_t)o] += b;
+            } else {
+                S.front_off[(size_t)q] = frun;
+                S.u_off[(size_t)q] = urun;
+                frun += f * f;
+                urun += b;
+            }
+            if (S.kind[(size_t)q] != 3) {
+                S.factor_entries += m * m + 2 * m * b;
+                S.flops += (double)m * m * m + 2.0 * m * m * b + (double)m * b * b;
+            }
+        }
+        S.front_off[(size_t)nl] = frun;  // total scalars of the front buffer
+        S.u_off[(size_t)nl] = urun;      // total entries of the update-vector buffer
+    }
+    S.front_entries = S.front_off[(size_t)nl];
+    if (S.idx_off[(size_t)nl] > 0x7fffffff || S.u_off[(size_t)nl] > 0x7fffffff)
+        return fail(LSA_ERR_ARG, "nd_analyse: front index lists exceed 2^31 entries");
+    // front index lists in the matrix's numbering: own unknowns in elimination order, then the boundary
+    S.idx.resize((size_t)S.idx_off[(size_t)nl]);
+    for (int32_t q = 0; q < nl; ++q) {
+        const int32_t t = keep[(size_t)q];
+        int32_t* dst = S.idx.data() + S.idx_off[(size_t)q];
+        for (int32_t k = gstart[(size_t)t]; k < gstart[(size_t)t + 1]; ++k) *dst++ = S.perm[(size_t)k];
+        for (int32_t e : bnd[(size_t)t]) *dst++ = S.perm[(size_t)e];
+    }
+    // local front position of elimination position e in (global) node t
+    auto local = [&](int32_t t, int32_t e) -> int32_t {
+        const int32_t a = gstart[(size_t)t], b = gstart[(size_t)t + 1];
+        if (e >= a && e < b) return e - a;
+        const std::vector<int32_t>& L = bnd[(size_t)t];
+        auto itp = std::lower_bound(L.begin(), L.end(), e);
+        if (itp == L.end() || *itp != e) return -1;
+        return (b - a) + (int32_t)(itp - L.begin());
     };
-    if (n < 0 || !rp || (!ci && n > 0 && rp[n] > 0) || !out) return fail(LSA_ERR_ARG, "nd_analyse: bad argument");
+    // position of every boundary unknown in the parent's front
+    S.cmap.resize((size_t)S.cmap_off[(size_t)nl]);
+    for (int32_t q = 0; q < nl; ++q) {
+        const int32_t t = keep[(size_t)q];
+        int32_t* dst = S.cmap.data() + S.cmap_off[(size_t)q];
+        for (int32_t e : bnd[(size_t)t]) {
+            const int32_t l = local(gparent[(size_t)t], e);
+            if (l < 0) return fail(LSA_ERR_ARG, "nd_analyse: internal error (boundary not contained in the parent's front)");
+            *dst++ = l;
+        }
+    }
+    // gather lists of the upward sweep: CSR form (tests) and one row per child (device)
+    S.gptr.assign((size_t)S.g_off[(size_t)nl], 0);
+    S.gidx.resize((size_t)S.cmap_off[(size_t)nl]);
+    S.gell.assign((size_t)S.ge_off[(size_t)nl], -1);
+    {
+        int64_t run = 0;
+        std::vector<int32_t> count;
+        for (int32_t q = 0; q < nl; ++q) {
+            const int32_t f = S.f[(size_t)q];
+            count.assign((size_t)f + 1, 0);
+            for (int32_t cp = S.child_ptr[(size_t)q]; cp < S.child_ptr[(size_t)q + 1]; ++cp) {
+                const int32_t c = S.child_idx[(size_t)cp];
+                for (int32_t k = S.cmap_off[(size_t)c]; k < S.cmap_off[(size_t)c + 1]; ++k) ++count[(size_t)S.cmap[(size_t)k] + 1];
+            }
+            int32_t* gp = S.gptr.data() + S.g_off[(size_t)q];
+            gp[0] = (int32_t)run;
+            for (int32_t j = 0; j < f; ++j) gp[j + 1] = gp[j] + count[(size_t)j + 1];
+            std::vector<int32_t> cur(gp, gp + f);
+            for (int32_t cp = S.child_ptr[(size_t)q]; cp < S.child_ptr[(size_t)q + 1]; ++cp) {
+                const int32_t c = S.child_idx[(size_t)cp];
+                int32_t* row = S.gell.data() + S.ge_off[(size_t)q] + (int64_t)(cp - S.child_ptr[(size_t)q]) * f;
+                const int32_t b = S.cmap_off[(size_t)c + 1] - S.cmap_off[(size_t)c];
+                for (int32_t k = 0; k < b; ++k) {
+                    const int32_t j = S.cmap[(size_t)S.cmap_off[(size_t)c] + k];
+                    S.gidx[(size_t)cur[(size_t)j]++] = (int32_t)(S.u_off[(size_t)c] + k);
+                    row[j] = (int32_t)(S.u_off[(size_t)c] + k);
+                }
+            }
+            run = gp[f];
+        }
+    }
+    // assembly map: every matrix entry goes to the front of the node that eliminates its first unknown, if this rank
+    // factors that node
+    S.asm_src.clear();
+    S.asm_dst.clear();
+    S.asm_src.reserve((size_t)S.nnz / (size_t)std::max(1, S.nranks) + 16);
+    S.asm_dst.reserve((size_t)S.nnz / (size_t)std::max(1, S.nranks) + 16);
+    for (int32_t i = 0; i < n; ++i) {
+        const int32_t pi = pos[(size_t)i];
+        for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
+            const int32_t pj = pos[(size_t)ci[p]];
+            const int32_t t = node_of[(size_t)std::min(pi, pj)];
+            if (kind[(size_t)t] != 1 && kind[(size_t)t] != 2) continue;
+            const int32_t li = local(t, pi), lj = local(t, pj);
+            if (li < 0 || lj < 0) return fail(LSA_ERR_ARG, "nd_analyse: internal error (entry outside its front)");
+            const int32_t q = loc[(size_t)t];
+            S.asm_src.push_back(p);
+            S.asm_dst.push_back(S.front_off[(size_t)q] + (int64_t)li * S.f[(size_t)q] + lj);
+        }
+    }
+    // work lists: this rank's own nodes level by level (larger pivot blocks first), then -- after the exchange of the
+    // subtree roots -- the replicated nodes level by level
+    S.lvl_ptr.assign(1, 0);
+    S.lvl_nodes.clear();
+    for (int phase = 1; phase <= 2; ++phase) {
+        if (phase == 2) S.phase_b_level = (int32_t)S.lvl_ptr.size() - 1;
+        for (int32_t l = 0; l < S.nlevels; ++l) {
+            const size_t before = S.lvl_nodes.size();
+            for (int32_t q = 0; q < nl; ++q)
+                if (S.kind[(size_t)q] == phase && S.level[(size_t)q] == l) S.lvl_nodes.push_back(q);
+            if (S.lvl_nodes.size() == before) continue;
+            std::stable_sort(S.lvl_nodes.begin() + (int64_t)before, S.lvl_nodes.end(), [&](int32_t x, int32_t y) { return S.m[(size_t)x] > S.m[(size_t)y]; });
+            S.lvl_ptr.push_back((int32_t)S.lvl_nodes.size());
+        }
+    }
+    S.nlevels = (int32_t)S.lvl_ptr.size() - 1;  // work levels from here on
+    if (!dist) S.phase_b_level = S.nlevels;
+    return LSA_OK;
+}
+
+int check_pattern(int32_t n, const int32_t* rp, const int32_t* ci, const Fail& fail) {
+    if (n < 0 || !rp || (!ci && n > 0 && rp[n] > 0)) return fail(LSA_ERR_ARG, "nd_analyse: bad argument");
+    for (int32_t i = 0; i < n; ++i) {
+        if (rp[i + 1] < rp[i]) return fail(LSA_ERR_ARG, "nd_analyse: row pointers decrease");
+        for (int32_t p = rp[i]; p < rp[i + 1]; ++p)
+            if (ci[p] < 0 || ci[p] >= n) return fail(LSA_ERR_ARG, "nd_analyse: column index out of range");
+    }
+    return LSA_OK;
+}
+
+}  // namespace
+
+int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, const int8_t* constraint, NdSymbolic* out, char* err,
+               int errlen) {
+    const Fail fail{err, errlen};
+    if (!out) return fail(LSA_ERR_ARG, "nd_analyse: bad argument");
+    if (int rc = check_pattern(n, rp, ci, fail)) return rc;
     if (leaf_size <= 0) leaf_size = 128;
     NdSymbolic& S = *out;
     S = NdSymbolic();
     S.n = n;
     S.nnz = n > 0 ? rp[n] : 0;
     S.leaf_size = leaf_size;
-    for (int32_t i = 0; i < n; ++i) {
-        if (rp[i + 1] < rp[i]) return fail(LSA_ERR_ARG, "nd_analyse: row pointers decrease");
-        for (int32_t p = rp[i]; p < rp[i + 1]; ++p)
-            if (ci[p] < 0 || ci[p] >= n) return fail(LSA_ERR_ARG, "nd_analyse: column index out of range");
-    }
     S.pattern_hash = nd_pattern_hash(n, rp, ci);
     Graph g;
     build_graph(n, rp, ci, g);
@@ -284,221 +618,55 @@ int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_siz
         std::vector<std::vector<int32_t>> moved((size_t)nt);
         for (int32_t t = 0; t < nt; ++t) {
             std::vector<int32_t>& L = own[(size_t)t];
-            size_t keep = 0;
+            size_t keepn = 0;
             for (int32_t v : L) {
                 if (target[(size_t)v] >= 0) moved[(size_t)target[(size_t)v]].push_back(v);
-                else L[keep++] = v;
+                else L[keepn++] = v;
             }
-            L.resize(keep);
+            L.resize(keepn);
         }
         for (int32_t t = 0; t < nt; ++t) own[(size_t)t].insert(own[(size_t)t].end(), moved[(size_t)t].begin(), moved[(size_t)t].end());
     }
-    // post-order numbering (children before parents)
-    std::vector<std::vector<int32_t>> kids((size_t)nt);
-    std::vector<int32_t> roots;
-    for (int32_t t = 0; t < nt; ++t) (par[t] >= 0 ? kids[(size_t)par[t]] : roots).push_back(t);
-    std::vector<int32_t> newid((size_t)nt, -1), seq;
-    seq.reserve((size_t)nt);
-    {
-        std::vector<std::pair<int32_t, size_t>> st;
-        for (int32_t r : roots) {
-            st.emplace_back(r, 0);
-            while (!st.empty()) {
-                auto& top = st.back();
-                if (top.second < kids[(size_t)top.first].size()) {
-                    const int32_t c = kids[(size_t)top.first][top.second++];
-                    st.emplace_back(c, 0);
-                } else {
-                    newid[(size_t)top.first] = (int32_t)seq.size();
-                    seq.push_back(top.first);
-                    st.pop_back();
-                }
-            }
-        }
-    }
-    S.nt = nt;
-    S.perm.reserve((size_t)n);
-    S.node_start.assign((size_t)nt + 1, 0);
-    S.parent.assign((size_t)nt, -1);
-    S.m.assign((size_t)nt, 0);
-    for (int32_t k = 0; k < nt; ++k) {
-        const int32_t t = seq[(size_t)k];
-        S.perm.insert(S.perm.end(), own[(size_t)t].begin(), own[(size_t)t].end());
-        S.node_start[(size_t)k + 1] = (int32_t)S.perm.size();
-        S.m[(size_t)k] = (int32_t)own[(size_t)t].size();
-        S.parent[(size_t)k] = par[t] >= 0 ? newid[(size_t)par[t]] : -1;
-    }
-    if ((int32_t)S.perm.size() != n) return fail(LSA_ERR_ARG, "nd_analyse: internal error (ordering is not a permutation)");
-    own.clear();
-    // children lists, levels
-    S.child_ptr.assign((size_t)nt + 1, 0);
-    for (int32_t t = 0; t < nt; ++t)
-        if (S.parent[(size_t)t] >= 0) ++S.child_ptr[(size_t)S.parent[(size_t)t] + 1];
-    for (int32_t t = 0; t < nt; ++t) S.child_ptr[(size_t)t + 1] += S.child_ptr[(size_t)t];
-    S.child_idx.assign((size_t)S.child_ptr[(size_t)nt], 0);
-    {
-        std::vector<int32_t> fillc(S.child_ptr.begin(), S.child_ptr.end() - 1);
-        for (int32_t t = 0; t < nt; ++t)
-            if (S.parent[(size_t)t] >= 0) S.child_idx[(size_t)fillc[(size_t)S.parent[(size_t)t]]++] = t;
-    }
-    S.level.assign((size_t)nt, 0);
-    for (int32_t t = 0; t < nt; ++t) {
-        const int32_t p = S.parent[(size_t)t];
-        if (p >= 0) S.level[(size_t)p] = std::max(S.level[(size_t)p], S.level[(size_t)t] + 1);
-        S.max_children = std::max(S.max_children, S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t]);
-    }
-    S.nlevels = 0;
-    for (int32_t t = 0; t < nt; ++t) S.nlevels = std::max(S.nlevels, S.level[(size_t)t] + 1);
-    // elimination position of every unknown, node of every position
-    std::vector<int32_t> pos((size_t)n), node_of((size_t)n);
-    for (int32_t k = 0; k < n; ++k) pos[(size_t)S.perm[(size_t)k]] = k;
-    for (int32_t t = 0; t < nt; ++t)
-        for (int32_t k = S.node_start[(size_t)t]; k < S.node_start[(size_t)t + 1]; ++k) node_of[(size_t)k] = t;
-    // boundary (struct) of every node in elimination positions
-    std::vector<std::vector<int32_t>> bnd((size_t)nt);
-    {
-        std::vector<int32_t> stamp((size_t)n, -1);
-        for (int32_t t = 0; t < nt; ++t) {
-            const int32_t a = S.node_start[(size_t)t], b = S.node_start[(size_t)t + 1];
-            std::vector<int32_t>& L = bnd[(size_t)t];
-            for (int32_t k = a; k < b; ++k) {
-                const int32_t v = S.perm[(size_t)k];
-                for (int64_t p = g.ptr[v]; p < g.ptr[(size_t)v + 1]; ++p) {
-                    const int32_t q = pos[(size_t)g.adj[(size_t)p]];
-                    if (q >= b && stamp[(size_t)q] != t) {
-                        stamp[(size_t)q] = t;
-                        L.push_back(q);
-                    }
-                }
-            }
-            for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp)
-                for (int32_t q : bnd[(size_t)S.child_idx[(size_t)cp]])
-                    if (q >= b && stamp[(size_t)q] != t) {
-                        stamp[(size_t)q] = t;
-                        L.push_back(q);
-                    }
-            std::sort(L.begin(), L.end());
-            // every boundary unknown must belong to an ancestor
-            if (!L.empty() && S.parent[(size_t)t] < 0) return fail(LSA_ERR_ARG, "nd_analyse: internal error (root with a boundary)");
-        }
-    }
-    g.adj.clear();
-    g.adj.shrink_to_fit();
-    S.f.assign((size_t)nt, 0);
-    S.idx_off.assign((size_t)nt + 1, 0);
-    S.front_off.assign((size_t)nt + 1, 0);
-    S.u_off.assign((size_t)nt + 1, 0);
-    S.cmap_off.assign((size_t)nt + 1, 0);
-    S.g_off.assign((size_t)nt + 1, 0);
-    for (int32_t t = 0; t < nt; ++t) {
-        const int64_t m = S.m[(size_t)t], b = (int64_t)bnd[(size_t)t].size(), f = m + b;
-        S.f[(size_t)t] = (int32_t)f;
-        S.idx_off[(size_t)t + 1] = S.idx_off[(size_t)t] + f;
-        S.front_off[(size_t)t + 1] = S.front_off[(size_t)t] + f * f;
-        S.u_off[(size_t)t + 1] = S.u_off[(size_t)t] + b;
-        S.cmap_off[(size_t)t + 1] = S.cmap_off[(size_t)t] + (int32_t)b;
-        S.g_off[(size_t)t + 1] = S.g_off[(size_t)t] + f + 1;
-        S.factor_entries += m * m + 2 * m * b;
-        S.flops += (double)m * m * m + 2.0 * m * m * b + (double)m * b * b;
-    }
-    S.front_entries = S.front_off[(size_t)nt];
-    if (S.idx_off[(size_t)nt] > 0x7fffffff || S.u_off[(size_t)nt] > 0x7fffffff)
-        return fail(LSA_ERR_ARG, "nd_analyse: front index lists exceed 2^31 entries");
-    S.idx.resize((size_t)S.idx_off[(size_t)nt]);
-    for (int32_t t = 0; t < nt; ++t) {
-        int32_t* dst = S.idx.data() + S.idx_off[(size_t)t];
-        for (int32_t k = S.node_start[(size_t)t]; k < S.node_start[(size_t)t + 1]; ++k) *dst++ = S.perm[(size_t)k];
-        for (int32_t q : bnd[(size_t)t]) *dst++ = S.perm[(size_t)q];
-    }
-    // local front position of elimination position q in node t
-    auto local = [&](int32_t t, int32_t q) -> int32_t {
-        const int32_t a = S.node_start[(size_t)t], b = S.node_start[(size_t)t + 1];
-        if (q >= a && q < b) return q - a;
-        const std::vector<int32_t>& L = bnd[(size_t)t];
-        auto itp = std::lower_bound(L.begin(), L.end(), q);
-        if (itp == L.end() || *itp != q) return -1;
-        return (b - a) + (int32_t)(itp - L.begin());
+    return nd_finish(S, n, rp, ci, g, own, par, nullptr, 0, 1, fail);
+}
+
+// The same tables for a tree the caller provides (nodes in any parent-consistent order; node t owns the matrix indices
+// [first[t], first[t] + size[t])), optionally split over ranks: owner[t] = rank of the subtree the node belongs to, -1 for
+// the replicated top.  Matrix rows that belong to no node must be empty (the padding of the sharded block layout).
+int nd_analyse_tree(int32_t n, const int32_t* rp, const int32_t* ci, int32_t nt, const int32_t* first, const int32_t* size, const int32_t* parent,
+                    const int32_t* owner, int rank, int nranks, NdSymbolic* out, char* err, int errlen) {
+    const Fail fail{err, errlen};
+    if (!out || nt < 0 || (nt > 0 && (!first || !size || !parent))) return fail(LSA_ERR_ARG, "nd_analyse_tree: bad argument");
+    if (int rc = check_pattern(n, rp, ci, fail)) return rc;
+    NdSymbolic& S = *out;
+    S = NdSymbolic();
+    S.n = n;
+    S.nnz = n > 0 ? rp[n] : 0;
+    S.leaf_size = 0;
+    S.pattern_hash = nd_pattern_hash(n, rp, ci);
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](int32_t v) {
+        h ^= (uint64_t)(uint32_t)v;
+        h *= 1099511628211ull;
     };
-    // position of every boundary unknown in the parent's front
-    S.cmap.resize((size_t)S.cmap_off[(size_t)nt]);
+    std::vector<std::vector<int32_t>> own((size_t)nt);
+    std::vector<int32_t> par(parent, parent + nt);
     for (int32_t t = 0; t < nt; ++t) {
-        const int32_t p = S.parent[(size_t)t];
-        int32_t* dst = S.cmap.data() + S.cmap_off[(size_t)t];
-        for (int32_t q : bnd[(size_t)t]) {
-            const int32_t l = local(p, q);
-            if (l < 0) return fail(LSA_ERR_ARG, "nd_analyse: internal error (boundary not contained in the parent's front)");
-            *dst++ = l;
-        }
+        if (first[t] < 0 || size[t] < 1 || (int64_t)first[t] + size[t] > n || parent[t] >= nt || parent[t] == t)
+            return fail(LSA_ERR_ARG, "nd_analyse_tree: node range or parent out of bounds");
+        own[(size_t)t].resize((size_t)size[t]);
+        std::iota(own[(size_t)t].begin(), own[(size_t)t].end(), first[t]);
+        mix(first[t]);
+        mix(size[t]);
+        mix(parent[t]);
+        mix(owner ? owner[t] : 0);
     }
-    // gather lists of the forward solve
-    S.gptr.assign((size_t)S.g_off[(size_t)nt], 0);
-    S.gidx.resize((size_t)S.u_off[(size_t)nt]);
-    {
-        int64_t run = 0;
-        std::vector<int32_t> count;
-        for (int32_t t = 0; t < nt; ++t) {
-            const int32_t f = S.f[(size_t)t];
-            count.assign((size_t)f + 1, 0);
-            for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) {
-                const int32_t c = S.child_idx[(size_t)cp];
-                for (int32_t k = S.cmap_off[(size_t)c]; k < S.cmap_off[(size_t)c + 1]; ++k) ++count[(size_t)S.cmap[(size_t)k] + 1];
-            }
-            int32_t* gp = S.gptr.data() + S.g_off[(size_t)t];
-            gp[0] = (int32_t)run;
-            for (int32_t j = 0; j < f; ++j) gp[j + 1] = gp[j] + count[(size_t)j + 1];
-            std::vector<int32_t> cur(gp, gp + f);
-            for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) {
-                const int32_t c = S.child_idx[(size_t)cp];
-                const int32_t b = S.cmap_off[(size_t)c + 1] - S.cmap_off[(size_t)c];
-                for (int32_t k = 0; k < b; ++k) {
-                    const int32_t j = S.cmap[(size_t)S.cmap_off[(size_t)c] + k];
-                    S.gidx[(size_t)cur[(size_t)j]++] = (int32_t)(S.u_off[(size_t)c] + k);
-                }
-            }
-            run = gp[f];
-        }
-    }
-    // the gather lists again, one row per child
-    S.ge_off.assign((size_t)nt + 1, 0);
-    for (int32_t t = 0; t < nt; ++t)
-        S.ge_off[(size_t)t + 1] = S.ge_off[(size_t)t] + (int64_t)(S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t]) * S.f[(size_t)t];
-    S.gell.assign((size_t)S.ge_off[(size_t)nt], -1);
-    for (int32_t t = 0; t < nt; ++t) {
-        const int32_t f = S.f[(size_t)t];
-        for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) {
-            const int32_t c = S.child_idx[(size_t)cp];
-            int32_t* row = S.gell.data() + S.ge_off[(size_t)t] + (int64_t)(cp - S.child_ptr[(size_t)t]) * f;
-            const int32_t b = S.cmap_off[(size_t)c + 1] - S.cmap_off[(size_t)c];
-            for (int32_t k = 0; k < b; ++k) row[S.cmap[(size_t)S.cmap_off[(size_t)c] + k]] = (int32_t)(S.u_off[(size_t)c] + k);
-        }
-    }
-    // assembly map of the original entries
-    S.asm_src.resize((size_t)S.nnz);
-    S.asm_dst.resize((size_t)S.nnz);
-    for (int32_t i = 0; i < n; ++i) {
-        const int32_t pi = pos[(size_t)i];
-        for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
-            const int32_t pj = pos[(size_t)ci[p]];
-            const int32_t t = node_of[(size_t)std::min(pi, pj)];
-            const int32_t li = local(t, pi), lj = local(t, pj);
-            if (li < 0 || lj < 0) return fail(LSA_ERR_ARG, "nd_analyse: internal error (entry outside its front)");
-            S.asm_src[(size_t)p] = p;
-            S.asm_dst[(size_t)p] = S.front_off[(size_t)t] + (int64_t)li * S.f[(size_t)t] + lj;
-        }
-    }
-    // nodes by level, larger pivot blocks first
-    S.lvl_ptr.assign((size_t)S.nlevels + 1, 0);
-    for (int32_t t = 0; t < nt; ++t) ++S.lvl_ptr[(size_t)S.level[(size_t)t] + 1];
-    for (int32_t l = 0; l < S.nlevels; ++l) S.lvl_ptr[(size_t)l + 1] += S.lvl_ptr[(size_t)l];
-    S.lvl_nodes.resize((size_t)nt);
-    {
-        std::vector<int32_t> fillp(S.lvl_ptr.begin(), S.lvl_ptr.end() - 1);
-        for (int32_t t = 0; t < nt; ++t) S.lvl_nodes[(size_t)fillp[(size_t)S.level[(size_t)t]]++] = t;
-        for (int32_t l = 0; l < S.nlevels; ++l)
-            std::stable_sort(S.lvl_nodes.begin() + S.lvl_ptr[(size_t)l], S.lvl_nodes.begin() + S.lvl_ptr[(size_t)l + 1],
-                             [&](int32_t x, int32_t y) { return S.m[(size_t)x] > S.m[(size_t)y]; });
-    }
-    return LSA_OK;
+    mix(rank);
+    mix(nranks);
+    S.tree_hash = h | 1ull;
+    Graph g;
+    build_graph(n, rp, ci, g);
+    return nd_finish(S, n, rp, ci, g, own, par, owner, rank, nranks, fail);
 }
 
 // ---- C-ABI: analysis only (host) -----------------------------------------------------------------------------------------
@@ -522,6 +690,23 @@ int lsa_nd_analyse(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t
     }
     h->err = buf;
     *out = h;  // returned on failure too, so that the message can be read; release with lsa_nd_sym_destroy
+    return rc;
+}
+
+int lsa_nd_analyse_tree(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t ntree, const int32_t* first, const int32_t* size,
+                        const int32_t* parent, const int32_t* owner, int32_t rank, int32_t nranks, lsa_nd_sym** out) {
+    if (!out) return LSA_ERR_ARG;
+    lsa_nd_sym* h = new lsa_nd_sym();
+    char buf[256] = {0};
+    int rc;
+    try {
+        rc = nd_analyse_tree(n, rowptr, col, ntree, first, size, parent, owner, rank, nranks, &h->S, buf, (int)sizeof buf);
+    } catch (const std::bad_alloc&) {
+        rc = LSA_ERR_ARG;
+        snprintf(buf, sizeof buf, "nd_analyse_tree: out of host memory");
+    }
+    h->err = buf;
+    *out = h;
     return rc;
 }
 
@@ -557,6 +742,27 @@ int lsa_nd_sym_export(const lsa_nd_sym* h, int32_t* perm, int32_t* node_start, i
     if (level) std::copy(S.level.begin(), S.level.end(), level);
     if (front_size) std::copy(S.f.begin(), S.f.end(), front_size);
     if (idx) std::copy(S.idx.begin(), S.idx.end(), idx);
+    return LSA_OK;
+}
+
+int lsa_nd_sym_export_dist(const lsa_nd_sym* h, int32_t* kind, int64_t* front_off, int64_t* u_off, int32_t* asm_src, int32_t* children_ptr,
+                           int32_t* children_idx, int64_t* scalars) {
+    if (!h) return LSA_ERR_ARG;
+    const NdSymbolic& S = h->S;
+    if (kind) std::copy(S.kind.begin(), S.kind.end(), kind);
+    if (front_off) std::copy(S.front_off.begin(), S.front_off.end(), front_off);
+    if (u_off) std::copy(S.u_off.begin(), S.u_off.end(), u_off);
+    if (asm_src) std::copy(S.asm_src.begin(), S.asm_src.end(), asm_src);
+    if (children_ptr) std::copy(S.child_ptr.begin(), S.child_ptr.end(), children_ptr);
+    if (children_idx) std::copy(S.child_idx.begin(), S.child_idx.end(), children_idx);
+    if (scalars) {
+        scalars[0] = S.xfront_slot;
+        scalars[1] = S.xu_slot;
+        scalars[2] = S.phase_b_level;
+        scalars[3] = (int64_t)S.asm_src.size();
+        scalars[4] = S.nranks;
+        scalars[5] = S.rank;
+    }
     return LSA_OK;
 }
 

@@ -27,6 +27,8 @@
 #include "lsa_internal.h"
 #include "nd_internal.h"
 
+int k_allgather_inplace(lsa_ctx* ctx, void* vec, size_t bytes_per_rank);  // comm.hip
+
 namespace {
 
 constexpr int kW = 8;        // pivot columns per panel
@@ -80,9 +82,10 @@ __global__ void nd_maxabs2_kernel(int64_t nnz, const T* __restrict__ v, unsigned
 }
 
 template <typename T>
-__global__ void nd_assemble_kernel(int64_t nnz, const T* __restrict__ val, const int64_t* __restrict__ dst, T* __restrict__ front) {
+__global__ void nd_assemble_kernel(int64_t count, const T* __restrict__ val, const int32_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                   T* __restrict__ front) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < nnz; e += stride) front[dst[e]] = val[e];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) front[dst[e]] = val[src[e]];
 }
 
 // parent front += child's update matrix (tile = 16 rows of the child's boundary block)
@@ -586,7 +589,8 @@ struct lsa_ndlu {
     int32_t* d_gell = nullptr;
     int32_t *d_idx = nullptr, *d_cmap = nullptr, *d_tiles = nullptr, *d_lvl_nodes = nullptr;
     int64_t* d_asm_dst = nullptr;
-    int32_t *d_ipiv = nullptr, *d_rowq = nullptr, *d_flag = nullptr;
+    int32_t* d_asm_src = nullptr;
+    int32_t *d_ipiv = nullptr, *d_rowq = nullptr, *d_flag = nullptr, *d_xflag = nullptr;
     unsigned long long* d_maxabs = nullptr;
     void *d_front = nullptr, *d_scratch = nullptr, *d_ubuf = nullptr, *d_tmp = nullptr;
     double seconds_analyse = 0.0, seconds_numeric = 0.0;
@@ -598,7 +602,7 @@ namespace {
 void nd_free(lsa_ndlu* f) {
     if (!f) return;
     for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
-                    (void*)f->d_lvl_nodes, (void*)f->d_asm_dst, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_maxabs,
+                    (void*)f->d_lvl_nodes, (void*)f->d_asm_dst, (void*)f->d_asm_src, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_xflag, (void*)f->d_maxabs,
                     f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp})
         if (p) (void)hipFree(p);
     delete f;
@@ -629,6 +633,22 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     std::vector<int32_t> rank((size_t)nt, 0);
     for (int32_t t = 0; t < nt; ++t)
         for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) rank[(size_t)S.child_idx[(size_t)cp]] = cp - S.child_ptr[(size_t)t];
+    for (int32_t t = 0; t < nt; ++t) {  // every kept node, the other ranks' subtree roots included (they are children here)
+        NdNodeDev& nd = nodes[(size_t)t];
+        nd.front_off = S.front_off[(size_t)t];
+        nd.scr_off = 0;
+        nd.u_off = S.u_off[(size_t)t];
+        nd.g_off = S.g_off[(size_t)t];
+        nd.idx_off = (int32_t)S.idx_off[(size_t)t];
+        nd.cmap_off = S.cmap_off[(size_t)t];
+        nd.piv_off = S.piv_off[(size_t)t];
+        nd.m = S.m[(size_t)t];
+        nd.f = S.f[(size_t)t];
+        nd.parent = S.parent[(size_t)t];
+        nd.nchild = S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t];
+        nd.pad1 = 0;
+        nd.ge_off = S.ge_off[(size_t)t];
+    }
     int64_t max_scratch = 1;
     for (int32_t l = 0; l < S.nlevels; ++l) {
         NdLevel& L = f->levels[(size_t)l];
@@ -639,20 +659,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
             const int64_t m = S.m[(size_t)t], ff = S.f[(size_t)t], b = ff - m;
-            NdNodeDev& nd = nodes[(size_t)t];
-            nd.front_off = S.front_off[(size_t)t];
-            nd.scr_off = scr;
-            nd.u_off = S.u_off[(size_t)t];
-            nd.g_off = S.g_off[(size_t)t];
-            nd.idx_off = (int32_t)S.idx_off[(size_t)t];
-            nd.cmap_off = S.cmap_off[(size_t)t];
-            nd.piv_off = S.node_start[(size_t)t];
-            nd.m = (int32_t)m;
-            nd.f = (int32_t)ff;
-            nd.parent = S.parent[(size_t)t];
-            nd.nchild = S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t];
-            nd.pad1 = 0;
-            nd.ge_off = S.ge_off[(size_t)t];
+            nodes[(size_t)t].scr_off = scr;
             scr += m * m + 2 * m * b;
             L.max_m = std::max(L.max_m, (int32_t)m);
             L.sorted_m.push_back((int32_t)m);
@@ -710,14 +717,15 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     }
     LSA_CHECK(upload(ctx, nodes, &f->d_nodes));
     {
-        std::vector<NdNodeDev> lnodes((size_t)nt);
-        for (int32_t q = 0; q < nt; ++q) lnodes[(size_t)q] = nodes[(size_t)S.lvl_nodes[(size_t)q]];
+        std::vector<NdNodeDev> lnodes(S.lvl_nodes.size());
+        for (size_t q = 0; q < S.lvl_nodes.size(); ++q) lnodes[q] = nodes[(size_t)S.lvl_nodes[q]];
         LSA_CHECK(upload(ctx, lnodes, &f->d_lnodes));
     }
     LSA_CHECK(upload(ctx, S.gell, &f->d_gell));
     LSA_CHECK(upload(ctx, S.idx, &f->d_idx));
     LSA_CHECK(upload(ctx, S.cmap, &f->d_cmap));
     LSA_CHECK(upload(ctx, S.asm_dst, &f->d_asm_dst));
+    LSA_CHECK(upload(ctx, S.asm_src, &f->d_asm_src));
     LSA_CHECK(upload(ctx, S.lvl_nodes, &f->d_lvl_nodes));
     LSA_CHECK(upload(ctx, tiles, &f->d_tiles));
     const size_t es = esize(f->dtype);
@@ -725,6 +733,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_ipiv, nn * sizeof(int32_t)));
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_rowq, nn * sizeof(int32_t)));
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_flag, 4 * sizeof(int32_t)));
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_xflag, 4 * sizeof(int32_t) * (size_t)std::max(1, S.nranks)));
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_maxabs, sizeof(unsigned long long)));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_front, (size_t)std::max<int64_t>(S.front_entries, 1) * es));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_scratch, (size_t)max_scratch * es));
@@ -754,7 +763,9 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
     if (S.nnz > 0) {
         const int blocks = (int)std::min<int64_t>((S.nnz + 255) / 256, (int64_t)ctx->num_cu * 16);
         hipLaunchKernelGGL((nd_maxabs2_kernel<T>), dim3(blocks), dim3(256), 0, st, S.nnz, (const T*)C->val, f->d_maxabs);
-        hipLaunchKernelGGL((nd_assemble_kernel<T>), dim3(blocks), dim3(256), 0, st, S.nnz, (const T*)C->val, f->d_asm_dst, front);
+        if (!S.asm_src.empty())
+            hipLaunchKernelGGL((nd_assemble_kernel<T>), dim3(blocks), dim3(256), 0, st, (int64_t)S.asm_src.size(), (const T*)C->val, f->d_asm_src,
+                               f->d_asm_dst, front);
     }
     unsigned long long mbits = 0;
     LSA_HIP_CHECK(ctx, hipMemcpyAsync(&mbits, f->d_maxabs, sizeof mbits, hipMemcpyDeviceToHost, st));
@@ -764,7 +775,11 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
     if (!std::isfinite(max2)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "lsa_ndlu: the matrix holds non-finite values");
     const double tiny2 = 1e-26 * max2;  // (1e-13 * max|C|)^2
     const int32_t* tl = f->d_tiles;
-    for (const NdLevel& L : f->levels) {
+    for (size_t li = 0; li < f->levels.size(); ++li) {
+        const NdLevel& L = f->levels[li];
+        // subtree-parallel: the ranks' subtree roots are done; every rank receives all of their fronts (update matrices)
+        if ((int32_t)li == S.phase_b_level && S.nranks > 1 && S.xfront_slot > 0)
+            LSA_CHECK(k_allgather_inplace(ctx, f->d_front, (size_t)S.xfront_slot * sizeof(T)));
         for (const TileList& e : L.ext)
             if (e.count > 0) hipLaunchKernelGGL((nd_extend_add_kernel<T>), dim3(e.count), dim3(256), 0, st, tl + 2 * e.off, f->d_nodes, f->d_cmap, front);
         for (int32_t k0 = 0; k0 < L.max_m; k0 += kW) {
@@ -796,10 +811,31 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
         if (L.copyback.count > 0)
             hipLaunchKernelGGL((nd_copyback_kernel<T>), dim3(L.copyback.count), dim3(256), 0, st, tl + 2 * L.copyback.off, f->d_nodes, front, scratch);
     }
+    if ((int32_t)f->levels.size() == S.phase_b_level && S.nranks > 1 && S.xfront_slot > 0)  // (no replicated level: still a collective)
+        LSA_CHECK(k_allgather_inplace(ctx, f->d_front, (size_t)S.xfront_slot * sizeof(T)));
     int32_t hflag[4] = {0, 0, 0, 0};
-    LSA_HIP_CHECK(ctx, hipMemcpyAsync(hflag, f->d_flag, sizeof hflag, hipMemcpyDeviceToHost, st));
-    LSA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (S.nranks > 1) {
+        // every rank must take the same decision (a rank that returned early would leave the others in a collective):
+        // the failure flags are exchanged, the first failing rank's record wins
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(f->d_xflag + 4 * S.rank, f->d_flag, 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        LSA_CHECK(k_allgather_inplace(ctx, f->d_xflag, 4 * sizeof(int32_t)));
+        std::vector<int32_t> all((size_t)4 * S.nranks, 0);
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(all.data(), f->d_xflag, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        LSA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        for (int r = 0; r < S.nranks; ++r)
+            if (all[(size_t)4 * r + 1] != 0) {
+                memcpy(hflag, &all[(size_t)4 * r], sizeof hflag);
+                if (r != S.rank) hflag[1] = -(r + 1);  // another rank's node: no local record of it
+                break;
+            }
+    } else {
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(hflag, f->d_flag, sizeof hflag, hipMemcpyDeviceToHost, st));
+        LSA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    }
     LSA_HIP_CHECK(ctx, hipGetLastError());
+    if (hflag[1] < 0)
+        return lsa_set_error(ctx, LSA_ERR_ZERO_PIVOT, "lsa_ndlu: a pivot block on rank %d is singular to 1e-13 * max|C| (column %d of its node)", -hflag[1] - 1,
+                             hflag[2]);
     if (hflag[1] != 0) {
         const int32_t t = hflag[1] - 1;
         const unsigned long long hi = (unsigned long long)(uint32_t)hflag[3] << 32;
@@ -818,10 +854,16 @@ template <typename MT, typename VT>
 int nd_apply(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
     hipStream_t st = ctx->stream;
     const MT* front = (const MT*)f->d_front;
-    for (const NdLevel& L : f->levels)
+    const NdSymbolic& S = f->S;
+    for (size_t li = 0; li <= f->levels.size(); ++li) {
+        // subtree-parallel: the update vectors of all ranks' subtree roots, before the replicated top of the tree
+        if ((int32_t)li == S.phase_b_level && S.nranks > 1 && S.xu_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, f->d_ubuf, (size_t)S.xu_slot * sizeof(VT)));
+        if (li == f->levels.size()) break;
+        const NdLevel& L = f->levels[li];
         if (L.fwd_tiles > 0)
             hipLaunchKernelGGL((nd_fwd_kernel<MT, VT>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,
                                f->d_gell, b, x, (VT*)f->d_ubuf);
+    }
     for (size_t l = f->levels.size(); l-- > 0;) {
         const NdLevel& L = f->levels[l];
         if (L.bwd_tiles > 0)
@@ -985,6 +1027,68 @@ int lsa_ndlu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t leaf_size, lsa_ndlu*
             if (rc == LSA_ERR_ZERO_PIVOT) lsa_set_error(ctx, rc, "%s (also with the zero-diagonal unknowns eliminated last; first attempt: %s)", std::string(ctx->err).c_str(), first.c_str());
         }
     }
+    if (rc != LSA_OK) {
+        nd_free(f);
+        return rc;
+    }
+    *out = f;
+    return LSA_OK;
+}
+
+int lsa_ndlu_create_tree(lsa_ctx* ctx, const lsa_mat* C, int32_t ntree, const int32_t* first, const int32_t* size, const int32_t* parent,
+                         const int32_t* owner, lsa_ndlu** out) {
+    if (!ctx || !C || !out || ntree < 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create_tree: bad argument");
+    *out = nullptr;
+    if (C->n != C->ncols || C->row0 != 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create_tree: needs the whole square matrix (every rank holds it)");
+    if ((int64_t)C->h_rp.size() != (int64_t)C->n + 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create_tree: the matrix has no host copy of its pattern");
+    const double t0 = now_s();
+    lsa_ndlu* f = nullptr;
+    // the parked factorisation, if it was made for this pattern, this tree and this rank
+    if (ctx->nd_cache) {
+        lsa_ndlu* c = ctx->nd_cache;
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](int32_t v) {
+            h ^= (uint64_t)(uint32_t)v;
+            h *= 1099511628211ull;
+        };
+        for (int32_t t = 0; t < ntree; ++t) {
+            mix(first[t]);
+            mix(size[t]);
+            mix(parent[t]);
+            mix(owner ? owner[t] : 0);
+        }
+        mix(ctx->rank);
+        mix(ctx->nranks);
+        if (c->S.tree_hash == (h | 1ull) && c->S.n == C->n && c->S.nnz == C->nnz && c->dtype == C->dtype &&
+            c->S.pattern_hash == nd_pattern_hash(C->n, C->h_rp.data(), C->h_ci.data())) {
+            f = c;
+            ctx->nd_cache = nullptr;
+            f->seconds_analyse = 0.0;
+        } else {
+            lsa_ndlu_drop_cache(ctx);
+        }
+    }
+    if (!f) {
+        f = new lsa_ndlu();
+        f->ctx = ctx;
+        f->dtype = C->dtype;
+        char buf[256] = {0};
+        int rc;
+        try {
+            rc = nd_analyse_tree(C->n, C->h_rp.data(), C->h_ci.data(), ntree, first, size, parent, owner, ctx->rank, ctx->nranks, &f->S, buf, (int)sizeof buf);
+        } catch (const std::bad_alloc&) {
+            rc = LSA_ERR_ARG;
+            snprintf(buf, sizeof buf, "lsa_ndlu_create_tree: out of host memory in the analysis");
+        }
+        if (rc == LSA_OK) rc = nd_setup(ctx, f);
+        else lsa_set_error(ctx, rc, "%s", buf);
+        if (rc != LSA_OK) {
+            nd_free(f);
+            return rc;
+        }
+        f->seconds_analyse = now_s() - t0;
+    }
+    const int rc = lsa_ndlu_refactor(ctx, f, C);
     if (rc != LSA_OK) {
         nd_free(f);
         return rc;

@@ -105,6 +105,7 @@ struct PcRef {
     lsa_ilu* ilu = nullptr;  // ILU(k) + triangular solves
     lsa_blu* blu = nullptr;  // exact block-tridiagonal LU (banded order)
     lsa_ndlu* nd = nullptr;  // exact nested-dissection multifrontal LU
+    bool nd_dist = false;    // the subtree-parallel form: reads and writes whole replicated vectors
     explicit operator bool() const { return ilu || blu || nd; }
     bool exact() const { return blu || nd; }
 };
@@ -113,7 +114,8 @@ int pc_global(lsa_ctx* ctx, PcRef pc, int32_t row0, int64_t nglobal, int dtype, 
     const size_t es = esize(dtype);
     const char* bl = (const char*)b + (size_t)row0 * es;
     char* xl = (char*)x + (size_t)row0 * es;
-    if (pc.nd) LSA_CHECK(ndlu_solve_dev(ctx, pc.nd, dtype, bl, xl));
+    if (pc.nd && pc.nd_dist) LSA_CHECK(ndlu_solve_dev(ctx, pc.nd, dtype, b, x));  // own subtrees + replicated top; x completed below
+    else if (pc.nd) LSA_CHECK(ndlu_solve_dev(ctx, pc.nd, dtype, bl, xl));
     else if (pc.blu) LSA_CHECK(blu_solve_dev(ctx, pc.blu, dtype, bl, xl));
     else LSA_CHECK(ilu_solve_dev(ctx, pc.ilu, 2, dtype, bl, xl));
     if (ctx->nranks > 1) LSA_CHECK(k_allgather_inplace(ctx, x, (size_t)(nglobal / ctx->nranks) * es));
@@ -342,6 +344,13 @@ __global__ void shift_diag_kernel(int32_t n, int32_t row0, const int32_t* __rest
 // ---- objects ------------------------------------------------------------------------------------------------------
 static_assert(sizeof(lsa_op_options) == 56, "lsa_op_options layout is part of the C-ABI (tests/test_abi.py)");
 
+// the caller's elimination forest for the subtree-parallel factorisation (lsa_op_create_dist)
+struct TreeArg {
+    int32_t nt;
+    const int32_t *first, *size, *parent, *owner;
+    int32_t row0, row1;  // this rank's rows of the padded layout
+};
+
 struct lsa_op {
     lsa_ctx* ctx;
     int64_t n;
@@ -353,6 +362,8 @@ struct lsa_op {
     lsa_ilu* pc;
     lsa_blu* blu;         // exact block-tridiagonal LU (opts.pc_type == 3)
     lsa_ndlu* nd = nullptr;  // exact nested-dissection LU (opts.pc_type == 2)
+    bool nd_dist = false;    // ... subtree-parallel over the ranks: works on whole replicated vectors
+    lsa_mat *view_fac = nullptr, *view_mul = nullptr;  // this rank's rows of the whole matrices (subtree-parallel layout)
     lsa_op_options opts;
     GmresWork gw;
     bool gw_ready;
@@ -422,9 +433,16 @@ static int build_shifted(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const
 
 // shared builder: (A, M) are the full matrices or this rank's row shards; (Ad, Md) are null or the rank's diagonal blocks
 static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_mat* Ad, const lsa_mat* Md, const double sigma[2],
-                    int mode, const lsa_op_options* opts, lsa_op** out) {
+                    int mode, const lsa_op_options* opts, lsa_op** out, const TreeArg* tree = nullptr) {
     if (!ctx || !A || !sigma || !opts || !out) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: null argument");
     const bool sharded = Ad != nullptr;
+    if (tree) {
+        const int nr = std::max(1, ctx->nranks);
+        if (sharded || A->n != A->ncols || A->row0 != 0 || (mode != 0 && mode != 2) || opts->pc_type != 2)
+            return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create_dist: needs the whole square matrices, a factorising mode (0 or 2) and pc_type 2");
+        if (A->ncols % nr != 0 || tree->row0 != (int64_t)ctx->rank * (A->ncols / nr) || tree->row1 < tree->row0 || tree->row1 > tree->row0 + A->ncols / nr)
+            return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create_dist: this rank's rows do not sit on its block of the padded layout");
+    }
     if (!sharded && A->n != A->ncols) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: A must be square (got %d x %d)", A->n, A->ncols);
     if (M && (M->n != A->n || M->ncols != A->ncols || M->row0 != A->row0)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: M does not match A's shape");
     if (mode < 0 || mode > 2) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: mode must be 0 (sinvert), 1 (shift) or 2 (Cayley)");
@@ -463,6 +481,14 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
     if (mode == 0 || mode == 2) {
         op->Kfac = C;
         op->Kmul = M;
+        if (tree) {  // SpMV on this rank's rows of the whole matrices
+            op->view_fac = mat_row_view(C, tree->row0, tree->row1);
+            op->Kfac = op->view_fac;
+            if (M) {
+                op->view_mul = mat_row_view(M, tree->row0, tree->row1);
+                op->Kmul = op->view_mul;
+            }
+        }
         if (mode == 2) {  // Cayley: multiply by A + nu M = A - (-nu) M
             const double mnu[2] = {-opts->antishift[0], -opts->antishift[1]};
             const bool cmul = cdt || opts->antishift[1] != 0.0;
@@ -471,7 +497,11 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
                 lsa_op_destroy(op);
                 return rc;
             }
-            op->Kmul = op->owned_mul;
+            if (tree) {
+                if (op->view_mul) lsa_mat_destroy(op->view_mul);
+                op->view_mul = mat_row_view(op->owned_mul, tree->row0, tree->row1);
+                op->Kmul = op->view_mul;
+            } else op->Kmul = op->owned_mul;
         }
         if (sharded) {
             rc = build_shifted(ctx, Ad, Md, sigma, cdt, &op->owned_diag);
@@ -490,7 +520,15 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
     if (op->Kfac && fac_src && (opts->pc_type == 2 || opts->pc_type == 3)) {
         // exact LU.  Only running out of device memory is answered by the leaner ILU(k) + GMRES (and said so on stderr
         // and in the statistics); a singular pivot block or any other failure is an error, as with PETSc's PC LU.
-        rc = opts->pc_type == 2 ? lsa_ndlu_create(ctx, fac_src, 0, &op->nd) : lsa_blu_create(ctx, fac_src, 0, &op->blu);
+        if (tree) {
+            rc = lsa_ndlu_create_tree(ctx, fac_src, tree->nt, tree->first, tree->size, tree->parent, tree->owner, &op->nd);
+            op->nd_dist = rc == LSA_OK;
+            if (rc == LSA_ERR_OOM) {  // no leaner collective method to agree on: an error on every rank that hits it
+                lsa_op_destroy(op);
+                return rc;
+            }
+        } else
+            rc = opts->pc_type == 2 ? lsa_ndlu_create(ctx, fac_src, 0, &op->nd) : lsa_blu_create(ctx, fac_src, 0, &op->blu);
         if (rc == LSA_ERR_OOM) {
             fprintf(stderr, "[lsa_hip] exact LU does not fit the device memory (%s): falling back to ILU(%d) + GMRES\n", ctx->err.c_str(),
                     opts->ilu_levels);
@@ -529,12 +567,22 @@ int lsa_op_create_sharded(lsa_ctx* ctx, const lsa_mat* A_rows, const lsa_mat* M_
     return op_build(ctx, A_rows, M_rows, A_diag, M_diag, sigma, mode, opts, out);
 }
 
+int lsa_op_create_dist(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, int32_t row0, int32_t row1, int32_t ntree, const int32_t* first,
+                       const int32_t* size, const int32_t* parent, const int32_t* owner, const double sigma[2], int mode, const lsa_op_options* opts,
+                       lsa_op** out) {
+    if (!first || !size || !parent || !owner || ntree < 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create_dist: the forest is required");
+    const TreeArg tree{ntree, first, size, parent, owner, row0, row1};
+    return op_build(ctx, A, M, nullptr, nullptr, sigma, mode, opts, out, &tree);
+}
+
 void lsa_op_destroy(lsa_op* op) {
     if (!op) return;
     if (op->ctx && op->ctx->stream) (void)hipStreamSynchronize(op->ctx->stream);
     if (op->pc) lsa_ilu_destroy(op->pc);
     if (op->blu) lsa_blu_destroy(op->blu);
     if (op->nd) lsa_ndlu_destroy(op->nd);
+    if (op->view_fac) lsa_mat_destroy(op->view_fac);
+    if (op->view_mul) lsa_mat_destroy(op->view_mul);
     if (op->owned) lsa_mat_destroy(op->owned);
     if (op->owned_mul) lsa_mat_destroy(op->owned_mul);
     if (op->owned_diag) lsa_mat_destroy(op->owned_diag);
@@ -563,7 +611,7 @@ static int op_apply_dev(lsa_ctx* ctx, lsa_op* op, const void* x, void* y) {
     if (!op->gw_ready) {
         int restart = std::max(1, std::min(op->opts.ksp_restart, op->opts.ksp_maxit));
         // with an exact factorisation on one GPU GMRES only polishes (0-2 iterations): keep its basis small
-        if ((op->blu || op->nd) && ctx->nranks == 1) restart = std::min(restart, 40);
+        if ((op->blu || op->nd) && (ctx->nranks == 1 || op->nd_dist)) restart = std::min(restart, 40);
         LSA_CHECK(op->gw.alloc(ctx, op->n, restart, dtype));
         op->gw_ready = true;
     }
@@ -571,6 +619,7 @@ static int op_apply_dev(lsa_ctx* ctx, lsa_op* op, const void* x, void* y) {
     pcr.ilu = op->pc;
     pcr.blu = op->blu;
     pcr.nd = op->nd;
+    pcr.nd_dist = op->nd_dist;
     LSA_CHECK(gmres_run(ctx, op->Kfac, pcr, dtype, rhs, y, false, op->opts.ksp_rtol, op->opts.ksp_maxit, op->gw, nullptr, nullptr, &op->st));
     if (op->keep) LSA_CHECK(k_mask(ctx, dtype, op->n, op->keep, y));
     return LSA_OK;

@@ -103,6 +103,8 @@ SIGNATURES = {
     "lsa_blu_apply_bytes": (ctypes.c_int, [_P, ctypes.POINTER(_I64)]),
     "lsa_blu_apply_launches": (ctypes.c_int, [_P, ctypes.POINTER(_I32)]),
     "lsa_nd_analyse": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _PP]),
+    "lsa_nd_analyse_tree": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _PP]),
+    "lsa_nd_sym_export_dist": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "lsa_nd_sym_error": (ctypes.c_char_p, [_P]),
     "lsa_nd_sym_destroy": (None, [_P]),
     "lsa_nd_sym_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64),
@@ -111,6 +113,7 @@ SIGNATURES = {
     "lsa_nd_sym_export_tables": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "lsa_ndlu_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
     "lsa_ndlu_prepare": (ctypes.c_int, [_P, _P, ctypes.c_int, _I32, _P]),
+    "lsa_ndlu_create_tree": (ctypes.c_int, [_P, _P, _I32, _P, _P, _P, _P, _PP]),
     "lsa_ndlu_refactor": (ctypes.c_int, [_P, _P, _P]),
     "lsa_ndlu_destroy": (None, [_P]),
     "lsa_ndlu_solve": (ctypes.c_int, [_P, _P, _P, _P]),
@@ -120,6 +123,7 @@ SIGNATURES = {
     "lsa_gmres": (ctypes.c_int, [_P, _P, _P, _P, _P, ctypes.c_int, _DBL, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
     "lsa_op_create": (ctypes.c_int, [_P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
     "lsa_op_create_sharded": (ctypes.c_int, [_P, _P, _P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
+    "lsa_op_create_dist": (ctypes.c_int, [_P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _DBL * 2, ctypes.c_int, ctypes.POINTER(lsa_op_options), _PP]),
     "lsa_op_destroy": (None, [_P]),
     "lsa_op_apply": (ctypes.c_int, [_P, _P, _P, _P]),
     "lsa_op_stats": (ctypes.c_int, [_P, ctypes.POINTER(lsa_stats)]),
@@ -492,9 +496,10 @@ class NdAnalysis:
     """Host-only analysis of the nested-dissection multifrontal LU (``lsa_nd_analyse``): ordering, elimination forest
     and the index tables of the device kernels.  Needs no GPU; used by the tests and by sizing tools."""
 
-    def __init__(self, A, leaf_size: int = 0, constraint=None):
+    def __init__(self, A, leaf_size: int = 0, constraint=None, tree=None, rank: int = 0, nranks: int = 1):
         """``constraint``: optional boolean mask of the unknowns with a numerically zero diagonal (eliminated after all
-        their neighbours: the pressure rows of a saddle-point matrix)."""
+        their neighbours: the pressure rows of a saddle-point matrix).  ``tree``: instead of dissecting, take the forest
+        ``{"first", "size", "parent"[, "owner"]}`` (``lsa_nd_analyse_tree``), localised for ``rank`` of ``nranks``."""
         import scipy.sparse as sp
 
         A = sp.csr_matrix(A)
@@ -508,7 +513,13 @@ class NdAnalysis:
         flags = None if constraint is None else np.ascontiguousarray(constraint, dtype=np.int8)
         if flags is not None and flags.shape != (self.n,):
             raise ValueError("constraint mask must have one entry per row")
-        rc = self._lib.lsa_nd_analyse(self.n, _ptr(rp), _ptr(ci), int(leaf_size), None if flags is None else _ptr(flags), ctypes.byref(h))
+        if tree is None:
+            rc = self._lib.lsa_nd_analyse(self.n, _ptr(rp), _ptr(ci), int(leaf_size), None if flags is None else _ptr(flags), ctypes.byref(h))
+        else:
+            first, size, parent = (np.ascontiguousarray(tree[k], dtype=np.int32) for k in ("first", "size", "parent"))
+            owner = None if tree.get("owner") is None else np.ascontiguousarray(tree["owner"], dtype=np.int32)
+            rc = self._lib.lsa_nd_analyse_tree(self.n, _ptr(rp), _ptr(ci), len(parent), _ptr(first), _ptr(size), _ptr(parent),
+                                               None if owner is None else _ptr(owner), int(rank), int(nranks), ctypes.byref(h))
         self.handle = h
         if rc != 0:
             msg = self._lib.lsa_nd_sym_error(h).decode(errors="replace")
@@ -532,11 +543,21 @@ class NdAnalysis:
         ex = self.export()
         m = np.diff(ex["node_start"])
         b = ex["front_size"] - m
+        scal = np.zeros(6, np.int64)
+        self._lib.lsa_nd_sym_export_dist(self.handle, None, None, None, None, None, None, _ptr(scal))
+        nlist = int(np.count_nonzero(np.ones(self.ntree)))  # lvl_nodes holds the nodes this rank works on (ghosts excluded)
         out = {"cmap": np.empty(int(b.sum()), np.int32), "gptr": np.empty(int((ex["front_size"] + 1).sum()), np.int32),
-               "gidx": np.empty(int(b.sum()), np.int32), "asm_dst": np.empty(self.nnz, np.int64), "lvl_ptr": np.empty(self.nlevels + 1, np.int32),
-               "lvl_nodes": np.empty(self.ntree, np.int32)}
+               "gidx": np.empty(int(b.sum()), np.int32), "asm_dst": np.empty(int(scal[3]), np.int64), "lvl_ptr": np.empty(self.nlevels + 1, np.int32),
+               "lvl_nodes": np.full(nlist, -1, np.int32), "kind": np.empty(self.ntree, np.int32), "front_off": np.empty(self.ntree + 1, np.int64),
+               "u_off": np.empty(self.ntree + 1, np.int64), "asm_src": np.empty(int(scal[3]), np.int32), "child_ptr": np.empty(self.ntree + 1, np.int32)}
         self._lib.lsa_nd_sym_export_tables(self.handle, *[_ptr(out[k]) for k in ("cmap", "gptr", "gidx", "asm_dst", "lvl_ptr", "lvl_nodes")])
+        out["lvl_nodes"] = out["lvl_nodes"][: int(out["lvl_ptr"][-1])]
+        self._lib.lsa_nd_sym_export_dist(self.handle, _ptr(out["kind"]), _ptr(out["front_off"]), _ptr(out["u_off"]), _ptr(out["asm_src"]),
+                                         _ptr(out["child_ptr"]), None, None)
+        out["child_idx"] = np.empty(int(out["child_ptr"][-1]), np.int32)
+        self._lib.lsa_nd_sym_export_dist(self.handle, None, None, None, None, None, _ptr(out["child_idx"]), None)
         out.update(ex)
+        out.update({"front_slot": int(scal[0]), "u_slot": int(scal[1]), "phase_b_level": int(scal[2]), "nranks": int(scal[4]), "rank": int(scal[5])})
         return out
 
     def __del__(self):
@@ -548,10 +569,18 @@ class NdAnalysis:
 class NdLu:
     """Nested-dissection multifrontal LU of a CSR matrix, resident on the device (``lsa_ndlu_*``)."""
 
-    def __init__(self, ctx: Context, C: CsrMatrix, leaf_size: int = 0):
+    def __init__(self, ctx: Context, C: CsrMatrix, leaf_size: int = 0, tree: dict | None = None):
+        """``tree``: ``{"first", "size", "parent"[, "owner"]}`` selects ``lsa_ndlu_create_tree`` (subtree-parallel when
+        the context has more than one rank and ``owner`` is given)."""
         self.ctx, self._C = ctx, C
         h = ctypes.c_void_p()
-        ctx.check(ctx._lib.lsa_ndlu_create(ctx.handle, C.handle, int(leaf_size), ctypes.byref(h)))
+        if tree is None:
+            ctx.check(ctx._lib.lsa_ndlu_create(ctx.handle, C.handle, int(leaf_size), ctypes.byref(h)))
+        else:
+            first, size, parent = (np.ascontiguousarray(tree[k], dtype=np.int32) for k in ("first", "size", "parent"))
+            owner = None if tree.get("owner") is None else np.ascontiguousarray(tree["owner"], dtype=np.int32)
+            ctx.check(ctx._lib.lsa_ndlu_create_tree(ctx.handle, C.handle, len(parent), _ptr(first), _ptr(size), _ptr(parent),
+                                                    None if owner is None else _ptr(owner), ctypes.byref(h)))
         self.handle = h
         self.n = C.shape[0]
 
@@ -599,9 +628,11 @@ class ShiftInvertOperator:
     def __init__(self, ctx: Context, A: CsrMatrix, M: CsrMatrix | None, sigma: complex, *, mode: int = 0, antishift: complex = 0.0,
                  ilu_levels: int = 0,
                  ilu_shift: float = 0.0, ksp_rtol: float = 1e-11, ksp_restart: int = 200, ksp_maxit: int = 2000, pc_type: int = 1,
-                 A_diag: CsrMatrix | None = None, M_diag: CsrMatrix | None = None):
+                 A_diag: CsrMatrix | None = None, M_diag: CsrMatrix | None = None, forest=None, rows: tuple[int, int] | None = None):
         """With ``A_diag`` (and ``M_diag``) given, ``A`` / ``M`` are this rank's row shards in the padded block layout
-        (:mod:`lsa_hip.sharding`) and the preconditioner is block-Jacobi ILU(k) over ranks."""
+        (:mod:`lsa_hip.sharding`) and the preconditioner is block-Jacobi over ranks.  With ``forest`` (a
+        :class:`lsa_hip.sharding.ForestPartition`) and ``rows`` (this rank's padded row range), ``A`` / ``M`` are the WHOLE
+        padded matrices and the inner solve is the subtree-parallel exact LU (``lsa_op_create_dist``)."""
         self.ctx, self._A, self._M, self._Ad, self._Md = ctx, A, M, A_diag, M_diag
         sigma = complex(sigma)
         antishift = complex(antishift)
@@ -609,7 +640,12 @@ class ShiftInvertOperator:
                               (_DBL * 2)(antishift.real, antishift.imag))
         h = ctypes.c_void_p()
         sig = (_DBL * 2)(sigma.real, sigma.imag)
-        if A_diag is None:
+        if forest is not None:
+            self._forest = tuple(np.ascontiguousarray(getattr(forest, k), dtype=np.int32) for k in ("first", "size", "parent", "owner"))
+            f0, f1, f2, f3 = self._forest
+            ctx.check(ctx._lib.lsa_op_create_dist(ctx.handle, A.handle, M.handle if M is not None else None, int(rows[0]), int(rows[1]), len(f2),
+                                                  _ptr(f0), _ptr(f1), _ptr(f2), _ptr(f3), sig, int(mode), ctypes.byref(opts), ctypes.byref(h)))
+        elif A_diag is None:
             ctx.check(ctx._lib.lsa_op_create(ctx.handle, A.handle, M.handle if M is not None else None, sig, int(mode), ctypes.byref(opts), ctypes.byref(h)))
         else:
             ctx.check(

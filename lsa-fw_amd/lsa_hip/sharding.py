@@ -90,3 +90,101 @@ def diagonal_block(A: sp.csr_matrix, part: RowPartition, rank: int) -> sp.csr_ma
     blk = sp.csr_matrix(A[r0:r1][:, r0:r1])
     blk.sort_indices()
     return blk
+
+
+# ---- subtree-parallel exact LU: the elimination forest cut over the ranks ------------------------------------------------
+
+
+@dataclass(frozen=True)
+class ForestPartition:
+    """The nested-dissection forest of ``lsa_hip.NdAnalysis`` cut over ``P`` ranks.
+
+    Every rank factors whole subtrees; the top of the forest (``owner == -1``) is replicated.  ``order`` lists the
+    unknowns (original numbering) rank by rank -- each rank's subtrees in elimination order, the top last, at the end of
+    the last rank's block -- so that a rank's unknowns are one contiguous row block and the order is still a post-order
+    of the same forest.  ``first`` / ``size`` / ``parent`` / ``owner`` describe the forest in the padded block layout of
+    ``rows`` (what ``lsa_op_create_dist`` takes)."""
+
+    order: np.ndarray
+    rows: RowPartition
+    first: np.ndarray
+    size: np.ndarray
+    parent: np.ndarray
+    owner: np.ndarray
+    subtree_work: np.ndarray  # per rank: factor scalars of its subtrees
+    top_work: int  # factor scalars of the replicated top
+
+
+def partition_forest(perm: np.ndarray, node_start: np.ndarray, parent: np.ndarray, front_size: np.ndarray, nranks: int, align: int = 64,
+                     imbalance: float = 1.25) -> ForestPartition:
+    """Cut the forest (arrays of ``NdAnalysis.export()``: nodes in post-order) over ``nranks`` ranks.
+
+    The frontier starts at the roots; its heaviest subtree is split (its root joins the replicated top, its children the
+    frontier) until there are at least ``nranks`` subtrees and the heaviest one is within ``imbalance`` of the mean load,
+    or nothing is left to split.  Subtrees go to ranks heaviest first, each to the least loaded rank."""
+    nt = len(parent)
+    m = np.diff(node_start).astype(np.int64)
+    b = front_size.astype(np.int64) - m
+    work = m * m + 2 * m * b
+    nodes_in = np.ones(nt, dtype=np.int64)
+    sub = work.copy()
+    children = [[] for _ in range(nt)]
+    for t in range(nt):  # post-order: children come first
+        p = int(parent[t])
+        if p >= 0:
+            sub[p] += sub[t]
+            nodes_in[p] += nodes_in[t]
+            children[p].append(t)
+    frontier = [t for t in range(nt) if parent[t] < 0]
+    top: list[int] = []
+    while True:
+        splittable = [t for t in frontier if children[t]]
+        if not splittable:
+            break
+        heavy = max(frontier, key=lambda t: sub[t])
+        mean = sum(sub[t] for t in frontier) / nranks
+        if len(frontier) >= nranks and (sub[heavy] <= imbalance * mean or len(frontier) >= 8 * nranks):
+            break
+        t = heavy if children[heavy] else max(splittable, key=lambda t: sub[t])
+        frontier.remove(t)
+        top.append(t)
+        frontier.extend(children[t])
+    load = np.zeros(nranks, dtype=np.int64)
+    rank_of_root = {}
+    for t in sorted(frontier, key=lambda t: (-sub[t], t)):
+        r = int(np.argmin(load))
+        rank_of_root[t] = r
+        load[r] += sub[t]
+    owner = np.full(nt, -1, dtype=np.int32)
+    for t, r in rank_of_root.items():
+        owner[t - nodes_in[t] + 1 : t + 1] = r  # a subtree is a contiguous run of post-order ids ending at its root
+    # new node order: rank by rank, then the top
+    new_nodes = np.concatenate([np.flatnonzero(owner == r) for r in range(nranks)] + [np.flatnonzero(owner < 0)])
+    new_id = np.empty(nt, dtype=np.int64)
+    new_id[new_nodes] = np.arange(nt)
+    order = np.concatenate([perm[node_start[t] : node_start[t + 1]] for t in new_nodes]) if nt else np.zeros(0, dtype=np.int64)
+    sizes = m[new_nodes]
+    first_unpadded = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    rows_per_rank = np.array([m[owner == r].sum() for r in range(nranks)], dtype=np.int64)
+    rows_per_rank[-1] += m[owner < 0].sum()
+    if np.any(rows_per_rank == 0):
+        raise ValueError(f"the elimination forest is too small to be cut over {nranks} ranks")
+    starts = np.concatenate([[0], np.cumsum(rows_per_rank)])
+    b_pad = ((int(rows_per_rank.max()) + align - 1) // align) * align
+    rows = RowPartition(starts, b_pad)
+    par_new = np.where(parent[new_nodes] >= 0, new_id[np.maximum(parent[new_nodes], 0)], -1).astype(np.int32)
+    return ForestPartition(order=np.asarray(order, dtype=np.int64), rows=rows, first=rows.to_padded(first_unpadded).astype(np.int32),
+                           size=sizes.astype(np.int32), parent=par_new, owner=owner[new_nodes].astype(np.int32),
+                           subtree_work=load, top_work=int(work[owner < 0].sum()))
+
+
+def pad_square(A: sp.csr_matrix, part: RowPartition) -> sp.csr_matrix:
+    """The whole (already permuted) matrix embedded in the padded block layout: n_pad x n_pad with empty padding rows."""
+    A = sp.csr_matrix(A)
+    n = A.shape[0]
+    slots = part.to_padded(np.arange(n))
+    counts = np.zeros(part.n_pad, dtype=np.int64)
+    counts[slots] = np.diff(A.indptr)
+    indptr = np.concatenate([[0], np.cumsum(counts)])
+    out = sp.csr_matrix((A.data, part.to_padded(A.indices).astype(np.int32), indptr), shape=(part.n_pad, part.n_pad))
+    return out

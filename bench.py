@@ -235,7 +235,8 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--case", default="S30k")
+    ap.add_argument("--case", default=None, help="synthetic cylinder case; default S30k on one GPU (BASELINE config 2), S500k for the sharded layout "
+                                                 "(BASELINE config 3: the refined mesh row-sharded over the GPUs)")
     ap.add_argument("--k", type=int, default=20)
     ap.add_argument("--ncv", type=int, default=80)
     ap.add_argument("--atol", type=float, default=1e-10)
@@ -283,6 +284,8 @@ def main() -> None:
     if args.sweep:
         layout = "replicas"
     sharded = layout == "sharded"
+    if args.case is None:
+        args.case = "S500k" if sharded else "S30k"
     es = fem.cylinder_case(args.case)
     sigma = SWEEP_SIGMAS[(2 + rank) % len(SWEEP_SIGMAS)] if args.sweep else SWEEP_SIGMAS[2]
     log(f"rank {rank}/{world}: {args.case} n={es.n} nnz={es.A.nnz} sigma={sigma} layout={layout}")
@@ -383,8 +386,11 @@ def main() -> None:
                 "other_pc": other,
                 "layout": "single GPU" if world == 1 else "sharded" if sharded else "replicas: one shift of the Re sweep per rank" if args.sweep
                           else "replicas of the N = 1 workload",
-                "parallelism": None if world == 1 else (f"rows of one problem over {world} ranks, replicated Krylov bases, block-Jacobi LU + GMRES, "
-                                                        "all-gather after every SpMV and preconditioner apply" if sharded else f"{world} independent solves"),
+                "parallelism": None if world == 1 else (
+                    (f"one problem over {world} ranks: rows of A, M, C sharded (SpMV + all-gather), Krylov bases replicated, "
+                     + ("subtree-parallel exact LU (own subtrees of the nested-dissection forest, all-gather of the subtree roots' update "
+                        "vectors, replicated top, all-gather of the solution)" if args.pc == "lu"
+                        else "block-Jacobi ILU(k) + GMRES, all-gather after every SpMV and preconditioner apply")) if sharded else f"{world} independent solves"),
                 "gmres_iters_per_apply": (stats.get("gmres_iters", 0) / max(stats.get("op_applies", 1), 1)) if sharded else None,
                 "allgather_calls_per_solve": stats.get("allgather_calls") if sharded else None,
                 "allgather_bytes_received_per_rank_per_solve": stats.get("allgather_bytes_received") if sharded else None,

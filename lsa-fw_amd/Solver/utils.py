@@ -681,10 +681,31 @@ def _dist_comm_init(ctx, world: int, rank: int) -> None:
 
     import torch.distributed as dist
 
-    if dist.get_backend() == "nccl" and os.environ.get("LSA_COMM_TRANSPORT", "rccl") != "host":
-        ctx.comm_init(world, rank, _dist_broadcast_bytes(ctx.unique_id() if rank == 0 else None))
-        return
     import torch
+
+    if dist.get_backend() == "nccl" and os.environ.get("LSA_COMM_TRANSPORT", "rccl") != "host":
+        # RCCL is opened by the library itself (dlopen); if that fails on ANY rank, every rank falls back to the host
+        # transport together (a collective decision: ranks on different transports would dead-lock)
+        ok = 1
+        try:
+            uid = ctx.unique_id() if rank == 0 else None
+        except Exception as exc:  # noqa: BLE001
+            logger.warning("RCCL unavailable on rank 0 (%s)", exc)
+            uid, ok = None, 0
+        uid = _dist_broadcast_bytes(uid)
+        if uid is not None and ok:
+            try:
+                ctx.comm_init(world, rank, uid)
+            except Exception as exc:  # noqa: BLE001
+                logger.warning("RCCL communicator initialisation failed on rank %d (%s)", rank, exc)
+                ok = 0
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return
+        logger.warning("Falling back to the host-staged all-gather (gloo) on every rank.")
 
     global _host_group
     group = None

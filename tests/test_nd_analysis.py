@@ -1,0 +1,123 @@
+"""CPU suite, part 5: the host-side analysis of the nested-dissection multifrontal LU (``lsa_nd_analyse`` /
+``lsa_nd_analyse_tree``: no GPU needed) and the cut of its forest over ranks (``lsa_hip.sharding.partition_forest``).
+
+The index tables the device kernels walk are checked by walking them in numpy in the kernels' order and data flow
+(tests/nd_emulation.py), pivot blocks by LAPACK: the result must be a direct solve of the matrix.  The device kernels
+themselves are compared with SuperLU and with this walk in tests/test_gpu_ndlu.py."""
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import helpers  # noqa: F401  (sys.path)
+import lsa_hip
+from lsa_hip import sharding
+from nd_emulation import Emulated, EmulatedRanks
+from oracle import fem
+
+
+def _shifted(es, sigma):
+    return sp.csr_matrix((es.A.data - sigma * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+
+
+@pytest.fixture(scope="module")
+def s5k():
+    es = fem.cylinder_case("S5k")
+    return es, _shifted(es, fem.SIGMA_RE50)
+
+
+def test_forest_is_a_valid_nested_dissection(s5k):
+    es, C = s5k
+    an = lsa_hip.NdAnalysis(C, 128)
+    ex = an.export()
+    perm, start, parent, level, fsize = ex["perm"], ex["node_start"], ex["parent"], ex["level"], ex["front_size"]
+    assert sorted(perm) == list(range(es.n)) and start[0] == 0 and start[-1] == es.n and np.all(np.diff(start) > 0)
+    assert np.all(parent[parent >= 0] > np.flatnonzero(parent >= 0))  # post-order: parents after children
+    assert np.all(level[parent[parent >= 0]] > level[parent >= 0]) and an.nlevels == level.max() + 1
+    assert np.diff(start)[level == 0].max() <= 128  # leaves respect the leaf size
+    # separator property: an entry couples two unknowns only if one's node is an ancestor of (or equal to) the other's
+    pos = np.empty(es.n, dtype=np.int64)
+    pos[perm] = np.arange(es.n)
+    node_of = np.searchsorted(start, pos, side="right") - 1
+    anc = [set() for _ in parent]
+    for t in range(len(parent) - 1, -1, -1):
+        anc[t] = {t} | (anc[parent[t]] if parent[t] >= 0 else set())
+    coo = C.tocoo()
+    lo = np.minimum(node_of[coo.row], node_of[coo.col])
+    hi = np.maximum(node_of[coo.row], node_of[coo.col])
+    assert all(h in anc[l] for l, h in set(zip(lo.tolist(), hi.tolist())))
+    # the fronts' boundaries lie in ancestors and are sorted by elimination position
+    off = np.concatenate([[0], np.cumsum(fsize)])
+    for t in range(len(parent)):
+        own = ex["idx"][off[t]:off[t] + start[t + 1] - start[t]]
+        bnd = ex["idx"][off[t] + start[t + 1] - start[t]:off[t + 1]]
+        assert np.array_equal(own, perm[start[t]:start[t + 1]])
+        assert np.all(np.diff(pos[bnd]) > 0) and all(node_of[b] in anc[t] and node_of[b] != t for b in bnd)
+    assert an.factor_entries == int(np.sum(np.diff(start).astype(np.int64) * (2 * fsize.astype(np.int64) - np.diff(start))))
+
+
+@pytest.mark.parametrize("case,sigma,constraints", [("S2k", fem.SIGMA_RE50, False), ("S5k", fem.SIGMA_RE50, False), ("S5k", 0.05, True),
+                                                     ("C2k", fem.SIGMA_CUBE, False), ("C2k", fem.SIGMA_CUBE, True)])
+def test_walking_the_tables_is_a_direct_solve(case, sigma, constraints):
+    es = fem.cube_case(case) if case.startswith("C") else fem.cylinder_case(case)
+    C = _shifted(es, sigma)
+    flags = (C.diagonal() == 0) if constraints else None
+    an = lsa_hip.NdAnalysis(C, 64, constraint=flags)
+    em = Emulated(an.export_tables(), C.data)
+    rng = np.random.default_rng(1)
+    b = rng.standard_normal(es.n).astype(C.dtype)
+    x = em.solve(b)
+    assert np.linalg.norm(C @ x - b) <= 1e-12 * np.linalg.norm(b)
+    if constraints:  # every zero-diagonal unknown is eliminated after all its neighbours
+        ex = an.export()
+        pos = np.empty(es.n, dtype=np.int64)
+        pos[ex["perm"]] = np.arange(es.n)
+        node_of = np.searchsorted(ex["node_start"], pos, side="right") - 1
+        S = sp.csr_matrix(C + C.T)
+        for v in np.flatnonzero(flags)[::7]:
+            nb = S.indices[S.indptr[v]:S.indptr[v + 1]]
+            assert node_of[v] >= node_of[nb].max() or np.diff(ex["node_start"])[node_of[v]] == 1
+
+
+def test_general_patterns_and_bad_input():
+    rng = np.random.default_rng(3)
+    A = sp.csr_matrix(sp.random(300, 300, density=0.02, random_state=rng) + sp.diags(1.0 + rng.random(300), 0))
+    em = Emulated(lsa_hip.NdAnalysis(A, 16).export_tables(), A.data)  # structurally unsymmetric, several components
+    b = rng.standard_normal(300)
+    assert np.linalg.norm(A @ em.solve(b) - b) <= 1e-9 * np.linalg.norm(b)
+    one = lsa_hip.NdAnalysis(sp.csr_matrix(np.array([[2.0]])), 0)
+    assert one.ntree == 1 and one.max_front == 1
+    with pytest.raises(ValueError):
+        lsa_hip.NdAnalysis(sp.csr_matrix(np.ones((3, 4))))
+    with pytest.raises(ValueError):  # a tree that does not cover the rows holding entries
+        lsa_hip.NdAnalysis(A, tree={"first": [0], "size": [10], "parent": [-1]})
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 4, 8])
+def test_forest_cut_over_ranks_is_still_a_direct_solve(s5k, nranks):
+    """partition_forest + per-rank localised tables, walked rank by rank with the two exchanges of the device path."""
+    es, C = s5k
+    ex = lsa_hip.NdAnalysis(C, 128).export()
+    fp = sharding.partition_forest(ex["perm"], ex["node_start"], ex["parent"], ex["front_size"], nranks)
+    assert sorted(fp.order) == list(range(es.n)) and fp.rows.nranks == nranks and fp.rows.n == es.n
+    top = fp.owner < 0
+    assert np.all(fp.owner[fp.parent[~top & (fp.parent >= 0)]] <= fp.owner[~top & (fp.parent >= 0)])  # parent: same rank or the top (-1)
+    assert fp.subtree_work.max() <= 2.0 * fp.subtree_work.mean()  # balanced cut
+    assert fp.top_work < 0.5 * fp.subtree_work.sum()  # the replicated part is the small top of the forest
+    Cp = C[fp.order][:, fp.order].tocsr()
+    Cp.sort_indices()
+    Cpad = sharding.pad_square(Cp, fp.rows)
+    assert Cpad.shape == (fp.rows.n_pad, fp.rows.n_pad) and Cpad.nnz == C.nnz
+    tree = {"first": fp.first, "size": fp.size, "parent": fp.parent, "owner": fp.owner}
+    tabs = [lsa_hip.NdAnalysis(Cpad, tree=tree, rank=r, nranks=nranks).export_tables() for r in range(nranks)]
+    assert all(t["front_slot"] == tabs[0]["front_slot"] and t["u_slot"] == tabs[0]["u_slot"] for t in tabs)  # all-gather counts agree
+    for r, t in enumerate(tabs):
+        assert np.all(t["kind"] >= 1) and np.count_nonzero(t["kind"] == 2) == np.count_nonzero(top)
+        assert t["nranks"] == nranks and t["rank"] == r
+    em = EmulatedRanks(tabs, Cpad.data)
+    rng = np.random.default_rng(4)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    xp = em.solve(fp.rows.pad_vector(b))
+    x = fp.rows.unpad_vector(xp)
+    assert np.linalg.norm(Cp @ x - b) <= 1e-12 * np.linalg.norm(b)
+    assert np.isnan(xp[fp.rows.pad_vector(np.ones(es.n)) == 0]).all()  # padding slots are never written

@@ -46,7 +46,7 @@ sys.path[:0] = [str(ROOT), str(ROOT / "lsa-fw_amd")]
 # is enough); on the 16-core share of a one-GPU box that starves the HIP runtime's helper thread and the next
 # factorisation's 3 900 dependent launches take 88-144 ms instead of 66.  It also is the honest setting for the CPU
 # baseline: single-threaded SuperLU/ARPACK ran 5x FASTER with one BLAS thread than with 64 (6 s vs 30 s per solve).
-for _var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+for _var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS", "LSA_HOST_BLAS_THREADS"):
     os.environ.setdefault(_var, "1")
 # one solve drives up to four streams; the secondary "two solves in flight" figure needs a second set of hardware queues
 # (the runtime's default is four per process; read when the first HIP context is created)

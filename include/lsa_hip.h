@@ -81,7 +81,8 @@ void lsa_mat_destroy(lsa_mat *m);
 int lsa_mat_download_values(lsa_ctx *ctx, const lsa_mat *m, void *host_val);
 /* C = alpha*A + beta*B on one shared sparsity pattern: MatDuplicate + MatAXPY of ST sinvert
  * (explicit in Solver/eigen2.py:110-111).  alpha/beta are (re, im); out_dtype LSA_F64 needs real inputs
- * and zero imaginary parts.  The result shares A's index arrays. */
+ * and zero imaginary parts.  LIFETIME: the result BORROWS A's device index arrays (row pointers, columns) and only owns
+ * its values: A must outlive it (destroy the result first).  The Python binding keeps A alive for that reason. */
 int lsa_csr_axpby(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *B, const double alpha[2], const double beta[2],
                   int out_dtype, lsa_mat **out);
 /* y = A x: MatMult (Solver/eigen2.py:174).  Real matrix with complex vectors is supported. */

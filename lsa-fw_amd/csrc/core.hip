@@ -189,12 +189,14 @@ static int csr_upload_impl(lsa_ctx* ctx, int32_t n_local, int32_t ncols, int32_t
         lsa_mat_destroy(m);
         return lsa_set_error(ctx, LSA_ERR_HIP, "hipMalloc(CSR n=%d nnz=%lld) failed", n_local, (long long)nnz);
     }
-    LSA_HIP_CHECK(ctx, hipMemcpyAsync(m->rp, rowptr, sizeof(int32_t) * (size_t)(n_local + 1), hipMemcpyHostToDevice, ctx->stream));
-    if (nnz > 0) {
-        LSA_HIP_CHECK(ctx, hipMemcpyAsync(m->ci, col, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
-        LSA_HIP_CHECK(ctx, hipMemcpyAsync(m->val, val, (size_t)nnz * dtype_size(dtype), hipMemcpyHostToDevice, ctx->stream));
+    hipError_t e = hipMemcpyAsync(m->rp, rowptr, sizeof(int32_t) * (size_t)(n_local + 1), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(m->ci, col, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nnz > 0) e = hipMemcpyAsync(m->val, val, (size_t)nnz * dtype_size(dtype), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {  // the half-built matrix and its device buffers go with the error
+        lsa_mat_destroy(m);
+        return lsa_set_error(ctx, LSA_ERR_HIP, "CSR upload failed: %s", hipGetErrorString(e));
     }
-    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     *out = m;
     return LSA_OK;
 }

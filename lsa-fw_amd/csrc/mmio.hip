@@ -125,6 +125,12 @@ int lsa_mm_open(const char* path, lsa_mm** out, int32_t* nrows, int32_t* ncols, 
         int32_t r, c;
         double re, im;
     };
+    // an entry takes at least four bytes of text ("1 1\n"): a size line that promises more than the file can hold is
+    // rejected before anything is reserved for it (no bad_alloc across the C boundary)
+    if ((uint64_t)nz > (uint64_t)(e - p) / 4 + 1) {
+        h->err = "the size line announces more entries than the file holds";
+        return LSA_ERR_ARG;
+    }
     std::vector<Entry> ent;
     ent.reserve((size_t)nz * (general ? 1 : 2));
     for (long k = 0; k < nz; ++k) {

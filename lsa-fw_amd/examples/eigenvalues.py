@@ -104,11 +104,13 @@ def main(argv: list[str] | None = None) -> None:
     if args.synthesize:
         synthesize(args.save_dir, args.synthesize)
     cases = list(zip(_REYNOLDS, _TARGETS))
+    import os
+
+    os.environ.setdefault("LSA_HOST_BLAS_THREADS", "1")  # this script owns its process: keep spinning BLAS workers off the launch path
     if args.jobs <= 1:
         for re, target in cases:
             solve_case(args.save_dir, re, target)
     else:
-        import os
         from concurrent.futures import ThreadPoolExecutor
 
         # every solve drives up to four streams; the runtime's default of four hardware queues per process would

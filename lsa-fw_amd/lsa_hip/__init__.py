@@ -191,15 +191,15 @@ _host_blas_limit = None
 
 
 def _calm_host_blas() -> None:
-    """Pin the host BLAS pools to one thread for the life of the process (once, when the first GPU context is made).
+    """Opt-in (``LSA_HOST_BLAS_THREADS=<n>``): pin the host BLAS pools to ``n`` threads for the life of the process.
 
-    The GPU path is launch-bound (thousands of dependent launches per factorisation) and leans on the HIP runtime's
-    helper thread.  numpy's OpenBLAS workers spin for ~0.1 s after any threaded call; on a 16-core share of a GPU node
-    64 of them starve that thread and the next factorisation is 1.3-2x slower (``tools/micro/after_solve.py``).  The
-    host arithmetic of this path is tiny (80 x 80 Schur forms, n-vectors), so nothing is lost.  ``LSA_HOST_BLAS_THREADS``
-    overrides: an integer, or ``keep`` to leave the pools alone."""
+    The GPU path is a chain of dependent launches and leans on the HIP runtime's helper thread.  numpy's OpenBLAS workers
+    spin for ~0.1 s after any threaded call; on a 16-core share of a GPU node 64 of them starve that thread and the next
+    factorisation is 1.3-2x slower (``tools/micro/after_solve.py``).  A library must not change its caller's thread pools
+    behind its back, so nothing happens unless the variable is set (``bench.py`` and the examples set it to 1); the dense
+    80 x 80 algebra of the Krylov-Schur driver limits the pools only for the duration of its own LAPACK calls."""
     global _host_blas_limit
-    want = os.environ.get("LSA_HOST_BLAS_THREADS", "1")
+    want = os.environ.get("LSA_HOST_BLAS_THREADS", "keep")
     if _host_blas_limit is not None or want == "keep":
         return
     try:

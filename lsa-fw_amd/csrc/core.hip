@@ -220,6 +220,8 @@ void lsa_mat_destroy(lsa_mat* m) {
         if (m->ci) (void)hipFree(m->ci);
     }
     if (m->val && m->owns_values) (void)hipFree(m->val);
+    if (!m->owns_extras) m->ci16 = nullptr, m->cbase = nullptr, m->grp_start = nullptr;
+    if (m->grp_start) (void)hipFree(m->grp_start);
     if (m->ci16) (void)hipFree(m->ci16);
     if (m->cbase) (void)hipFree(m->cbase);
     delete m;

@@ -135,6 +135,13 @@ struct lsa_mat {
     mutable uint16_t* ci16 = nullptr;
     mutable int32_t* cbase = nullptr;
     mutable int ci16_state = 0;
+    // row groups for the SpMV (built on first use): consecutive rows with one and the same column pattern (the unknowns of
+    // a mesh node) share their column indices and their gathers of x; grp_start[g] .. grp_start[g + 1] are the rows of
+    // group g (at most 4).  grp_state: 0 = not tried, 1 = available, -1 = not worth it (mean group size < 1.5)
+    mutable int32_t* grp_start = nullptr;
+    mutable int32_t ngroups = 0;
+    mutable int grp_state = 0;
+    bool owns_extras = true;  // false when ci16 / cbase / grp_start are borrowed from the matrix whose pattern this one shares
 };
 
 int lsa_set_error(lsa_ctx* ctx, int code, const char* fmt, ...);

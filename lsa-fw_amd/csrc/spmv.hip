@@ -132,6 +132,89 @@ __global__ __launch_bounds__(256) void spmv_subwave16_kernel(int32_t n, const in
     }
 }
 
+// Row groups: the rows of one mesh node (ux, uy[, uz][, p]) have one and the same column pattern.  A sub-wave takes a
+// whole group: the column indices are read once (from the group's first row) and every x entry is gathered once and used
+// for all rows of the group -- 1 / g of the index bytes and of the gather instructions (g = 2.2 rows on the 2D
+// Taylor-Hood pattern), and g independent value loads in flight per lane.  Rows of a group are consecutive and equally
+// long, so row k of the group starts at p0 + k * len: no extra row-pointer loads.
+// (Tried and dropped: one 16-byte record {first entry, length, first row, rows} per group with the next group's record
+// requested ahead, instead of row pointers behind a group pointer: 692 vs 635 us on SROOF.)
+template <typename MT, typename VT, int LPR, bool C16>
+__global__ __launch_bounds__(256) void spmv_group_kernel(int32_t ngroups, const int32_t* __restrict__ gstart, const int32_t* __restrict__ rp,
+                                                         const int32_t* __restrict__ ci, const uint16_t* __restrict__ ci16,
+                                                         const int32_t* __restrict__ cbase, const MT* __restrict__ val, const VT* __restrict__ x,
+                                                         VT* __restrict__ y) {
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t lane = (int32_t)(gid % LPR);
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) / LPR;
+    for (int64_t grp = gid / LPR; grp < ngroups; grp += stride) {
+        const int32_t r0 = gstart[grp], g = gstart[grp + 1] - r0;
+        const int32_t p0 = rp[r0], len = rp[r0 + 1] - p0;
+        const VT* xr = x;
+        if constexpr (C16) xr += cbase[r0];
+        VT acc[4] = {scalar_traits<VT>::zero(), scalar_traits<VT>::zero(), scalar_traits<VT>::zero(), scalar_traits<VT>::zero()};
+        for (int32_t p = lane; p < len; p += LPR) {
+            int32_t col;
+            if constexpr (C16) col = ci16[p0 + p];
+            else col = ci[p0 + p];
+            const MT* v = val + p0 + p;
+            MT a[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < g) a[k] = v[(size_t)k * len];
+            const VT xv = xr[col];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < g) fma_acc(acc[k], a[k], xv);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < g) {
+#pragma unroll
+                for (int m = LPR / 2; m > 0; m >>= 1) acc[k] = s_add(acc[k], shfl_xor_t<VT>(acc[k], m));
+            }
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < g) y[r0 + k] = acc[k];
+        }
+    }
+}
+
+// builds A->grp_start from the host pattern; false when grouping does not pay (mean group below 1.5 rows)
+static bool ensure_groups(const lsa_mat* A) {
+    if (A->grp_state != 0) return A->grp_state > 0;
+    A->grp_state = -1;
+    const int32_t n = A->n;
+    if (n < 1 || (int64_t)A->h_rp.size() != (int64_t)n + 1 || (int64_t)A->h_ci.size() != A->nnz) return false;
+    std::vector<int32_t> gs;
+    gs.reserve((size_t)n / 2 + 2);
+    gs.push_back(0);
+    int32_t cur = 1;
+    for (int32_t r = 1; r < n; ++r) {
+        const int32_t a0 = A->h_rp[(size_t)r - 1], a1 = A->h_rp[r], b1 = A->h_rp[(size_t)r + 1];
+        const bool same = cur < 4 && (a1 - a0) == (b1 - a1) && (a1 == a0 || memcmp(&A->h_ci[a0], &A->h_ci[a1], sizeof(int32_t) * (size_t)(a1 - a0)) == 0);
+        if (same) ++cur;
+        else {
+            gs.push_back(r);
+            cur = 1;
+        }
+    }
+    gs.push_back(n);
+    const int32_t ng = (int32_t)gs.size() - 1;
+    if ((double)n / (double)ng < 1.5) return false;
+    if (hipMalloc((void**)&A->grp_start, gs.size() * sizeof(int32_t)) != hipSuccess) return false;
+    if (hipMemcpy(A->grp_start, gs.data(), gs.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(A->grp_start);
+        A->grp_start = nullptr;
+        return false;
+    }
+    A->ngroups = ng;
+    A->grp_state = 1;
+    return true;
+}
+
 // builds A->ci16 / A->cbase from the host pattern; false when a row spans 65 536 columns or more
 static bool ensure_ci16(const lsa_mat* A) {
     if (A->ci16_state != 0) return A->ci16_state > 0;
@@ -178,6 +261,12 @@ static int spmv_lanes_per_row(const lsa_mat* A, int variant) {
     }
     return (lpr == 4 || lpr == 8 || lpr == 32 || lpr == 64) ? lpr : 16;
 }
+static bool spmv_wants_groups(const lsa_mat* A, int variant) {
+    if (variant & 0x4000) return false;
+    if (variant & (0x100 | 0x200 | 0x400)) return false;
+    // one host pass over the pattern, worth it where the SpMV is a bandwidth question
+    return (variant & 0x2000) || A->nnz >= (int64_t)4 << 20;
+}
 static bool spmv_wants_ci16(const lsa_mat* A, int variant) {
     const size_t msize = A->dtype == LSA_C128 ? 16 : 8;
     return ((variant & 0x800) || (variant == 0 && msize == 16 && A->nnz >= (int64_t)4 << 20)) && !(variant & 0x100) && !(variant & 0x200);
@@ -205,6 +294,20 @@ static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, 
     // default (no variant word): compressed indices for matrices where the SpMV is a bandwidth question (>= 4 M entries;
     // building them is one host pass over the pattern, not worth it for the 0.9 M-entry matrices rebuilt per shift)
     // (complex matrices only: with 8-byte values the 2-byte index loads cost more than they save -- f64 SROOF 565 -> 592 us)
+    if (!NT && spmv_wants_groups(A, variant) && ensure_groups(A)) {
+        // with grouped rows the column indices are 1 / g of what they were: 2-byte offsets no longer pay (measured on SROOF:
+        // 635 us with 32-bit indices against 663 us with 16-bit ones); they stay available through the variant word
+        const bool c16 = (variant & 0x800) && ensure_ci16(A);
+        int64_t gwant = ((int64_t)A->ngroups * LPR + threads - 1) / threads;
+        const int gblocks = (int)(gwant < 1 ? 1 : (gwant > cap ? cap : gwant));
+        if (c16)
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, true>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, A->grp_start, A->rp, A->ci,
+                               (const uint16_t*)A->ci16, (const int32_t*)A->cbase, (const MT*)A->val, (const VT*)x, (VT*)y);
+        else
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, A->grp_start, A->rp, A->ci,
+                               (const uint16_t*)nullptr, (const int32_t*)nullptr, (const MT*)A->val, (const VT*)x, (VT*)y);
+        return;
+    }
     if (spmv_wants_ci16(A, variant) && !NT && ensure_ci16(A)) {
         hipLaunchKernelGGL((spmv_subwave16_kernel<MT, VT, LPR>), dim3(blocks), dim3(threads), 0, ctx->stream, A->n, A->rp, (const uint16_t*)A->ci16,
                            (const int32_t*)A->cbase, (const MT*)A->val, (const VT*)x, (VT*)y);
@@ -331,16 +434,25 @@ int lsa_spmv_info(lsa_ctx* ctx, const lsa_mat* A, int xdtype, char* kernel, int3
     if (!ctx || !A) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_spmv_info: null argument");
     const int variant = spmv_variant();
     const int lpr = spmv_lanes_per_row(A, variant);
-    const bool c16 = spmv_wants_ci16(A, variant) && ensure_ci16(A);
+    const bool grouped = !(variant & 0x100) && spmv_wants_groups(A, variant) && ensure_groups(A);
+    const bool c16 = grouped ? ((variant & 0x800) && ensure_ci16(A)) : (spmv_wants_ci16(A, variant) && ensure_ci16(A));
     const char* mt = A->dtype == LSA_C128 ? "cplx" : "double";
     const char* vt = xdtype == LSA_C128 ? "cplx" : "double";
-    const char* base = c16 ? "spmv_subwave16_kernel" : (variant & 0x200) ? "spmv_xcd_kernel" : (variant & 0x400) ? "spmv_subwave2_kernel" : "spmv_subwave_kernel";
-    if (kernel && kernel_len > 0) snprintf(kernel, (size_t)kernel_len, "%s<%s,%s,%d>", base, mt, vt, lpr);
+    const char* base = grouped ? "spmv_group_kernel" : c16 ? "spmv_subwave16_kernel" : (variant & 0x200) ? "spmv_xcd_kernel" : (variant & 0x400) ? "spmv_subwave2_kernel" : "spmv_subwave_kernel";
+    if (kernel && kernel_len > 0) {
+        if (grouped) snprintf(kernel, (size_t)kernel_len, "%s<%s,%s,%d,%s>", base, mt, vt, lpr, c16 ? "true" : "false");
+        else snprintf(kernel, (size_t)kernel_len, "%s<%s,%s,%d>", base, mt, vt, lpr);
+    }
     if (bytes_moved) {
-        const int64_t ms = A->dtype == LSA_C128 ? 16 : 8, vs = xdtype == LSA_C128 ? 16 : 8;
+        const int64_t ms = A->dtype == LSA_C128 ? 16 : 8, vs = xdtype == LSA_C128 ? 16 : 8, is = c16 ? 2 : 4;
         // per entry: value + column index (2 bytes when compressed); per row: row pointer (+ the row's first column when
-        // compressed), one x entry read and one y entry written
-        *bytes_moved = A->nnz * (ms + (c16 ? 2 : 4)) + (int64_t)A->n * (4 + (c16 ? 4 : 0) + 2 * vs);
+        // compressed), one x entry read and one y entry written.  Grouped: the indices of the first row of a group only,
+        // two row pointers, a group pointer (and the first column) per group.
+        if (grouped) {
+            const double gmean = (double)A->n / (double)A->ngroups;
+            *bytes_moved = A->nnz * ms + (int64_t)((double)A->nnz * (double)is / gmean) + (int64_t)A->ngroups * (8 + 4 + (c16 ? 4 : 0)) + (int64_t)A->n * 2 * vs;
+        } else
+            *bytes_moved = A->nnz * (ms + is) + (int64_t)A->n * (4 + (c16 ? 4 : 0) + 2 * vs);
     }
     return LSA_OK;
 }

@@ -29,17 +29,21 @@ dC = lsa_hip.CsrMatrix.from_scipy(ctx, big)
 dx = lsa_hip.DeviceVector.from_numpy(ctx, x)
 dy = lsa_hip.DeviceVector(ctx, n, np.complex128)
 bytes_c = 20.0 * nnz + 36.0 * n
-variants = {}
-for lpr in (8, 16):
-    for nt in (0, 1):
-        for two in (0, 1):
-            for per_cu in (16, 256):
-                variants[f"lpr{lpr} nt{nt} two{two} wg/cu{per_cu}"] = lpr | (nt << 8) | (two << 10) | (per_cu << 16)
-variants["lpr16 ci16 wg/cu64"] = 16 | 0x800
-variants["lpr16 ci16 wg/cu256"] = 16 | 0x800 | (256 << 16)
-variants["lpr8 ci16 wg/cu64"] = 8 | 0x800
-variants["default"] = 0
-variants["plain 32-bit indices"] = 0x1000
+variants = {
+    "default (groups + ci16)": 0,
+    "groups + ci16, lpr8": 8 | 0x2000 | 0x800,
+    "groups + ci16, lpr32": 32 | 0x2000 | 0x800,
+    "groups, 32-bit indices": 16 | 0x2000 | 0x1000,
+    "groups, 32-bit, lpr8": 8 | 0x2000 | 0x1000,
+    "groups, 32-bit, lpr8, wg/cu256": 8 | 0x2000 | 0x1000 | (256 << 16),
+    "groups, 32-bit, wg/cu256": 16 | 0x2000 | 0x1000 | (256 << 16),
+    "groups, 32-bit, wg/cu32": 16 | 0x2000 | 0x1000 | (32 << 16),
+    "groups + ci16, wg/cu16": 16 | 0x2000 | 0x800 | (16 << 16),
+    "groups + ci16, wg/cu256": 16 | 0x2000 | 0x800 | (256 << 16),
+    "ci16, no groups (round 1 default)": 16 | 0x800 | 0x4000,
+    "plain 32-bit, no groups": 0x1000 | 0x4000,
+    "xcd chunks": 16 | 0x200,
+}
 best = {}
 for rnd in range(3):
     for name, v in variants.items():
@@ -47,6 +51,11 @@ for rnd in range(3):
         dC.time_matvec(dx, dy, 3)
         ms = dC.time_matvec(dx, dy, 20)
         best.setdefault(name, []).append(ms)
-ref = None
+xr = big @ x
+for name, v in variants.items():  # every variant computes the same product
+    os.environ["LSA_SPMV_VARIANT"] = str(v)
+    dC.matvec(dx, dy)
+    err = np.linalg.norm(dy.numpy() - xr) / np.linalg.norm(xr)
+    assert err < 1e-13, (name, err)
 for name, ms in sorted(best.items(), key=lambda kv: np.median(kv[1])):
-    print(f"{name:24s} median {np.median(ms) * 1e3:7.1f} us  min {min(ms) * 1e3:7.1f} us  -> {bytes_c / np.median(ms) / 1e6:7.1f} GB/s", flush=True)
+    print(f"{name:36s} median {np.median(ms) * 1e3:7.1f} us  min {min(ms) * 1e3:7.1f} us  -> {bytes_c / np.median(ms) / 1e6:7.1f} GB/s", flush=True)

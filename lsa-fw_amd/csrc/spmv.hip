@@ -299,7 +299,8 @@ static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, 
         // 635 us with 32-bit indices against 663 us with 16-bit ones); they stay available through the variant word
         const bool c16 = (variant & 0x800) && ensure_ci16(A);
         int64_t gwant = ((int64_t)A->ngroups * LPR + threads - 1) / threads;
-        const int gblocks = (int)(gwant < 1 ? 1 : (gwant > cap ? cap : gwant));
+        const int64_t gcap = (variant >> 16) > 0 ? cap : (int64_t)ctx->num_cu * 256;  // more, shorter workgroups: 2 % faster than 64 per CU
+        const int gblocks = (int)(gwant < 1 ? 1 : (gwant > gcap ? gcap : gwant));
         if (c16)
             hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, true>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, A->grp_start, A->rp, A->ci,
                                (const uint16_t*)A->ci16, (const int32_t*)A->cbase, (const MT*)A->val, (const VT*)x, (VT*)y);

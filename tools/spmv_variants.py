@@ -30,19 +30,14 @@ dx = lsa_hip.DeviceVector.from_numpy(ctx, x)
 dy = lsa_hip.DeviceVector(ctx, n, np.complex128)
 bytes_c = 20.0 * nnz + 36.0 * n
 variants = {
-    "default (groups + ci16)": 0,
-    "groups + ci16, lpr8": 8 | 0x2000 | 0x800,
-    "groups + ci16, lpr32": 32 | 0x2000 | 0x800,
-    "groups, 32-bit indices": 16 | 0x2000 | 0x1000,
-    "groups, 32-bit, lpr8": 8 | 0x2000 | 0x1000,
-    "groups, 32-bit, lpr8, wg/cu256": 8 | 0x2000 | 0x1000 | (256 << 16),
-    "groups, 32-bit, wg/cu256": 16 | 0x2000 | 0x1000 | (256 << 16),
-    "groups, 32-bit, wg/cu32": 16 | 0x2000 | 0x1000 | (32 << 16),
-    "groups + ci16, wg/cu16": 16 | 0x2000 | 0x800 | (16 << 16),
+    "default (groups, 32-bit, 256 wg/cu)": 0,
+    "groups, 32-bit, wg/cu64": 16 | 0x2000 | 0x1000 | (64 << 16),
+    "groups, 32-bit, wg/cu1024": 16 | 0x2000 | 0x1000 | (1024 << 16),
+    "groups, 32-bit, wg/cu4096": 16 | 0x2000 | 0x1000 | (4096 << 16),
+    "groups, 32-bit, lpr8, wg/cu1024": 8 | 0x2000 | 0x1000 | (1024 << 16),
     "groups + ci16, wg/cu256": 16 | 0x2000 | 0x800 | (256 << 16),
     "ci16, no groups (round 1 default)": 16 | 0x800 | 0x4000,
     "plain 32-bit, no groups": 0x1000 | 0x4000,
-    "xcd chunks": 16 | 0x200,
 }
 best = {}
 for rnd in range(3):

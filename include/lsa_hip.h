@@ -58,6 +58,9 @@ typedef struct {
     double seconds_solve;    /* wall seconds spent inside lsa_op_apply / lsa_krylov_extend */
     int32_t stagnated_solves; /* inner solves accepted at a stagnated true residual in (10 rtol, 1000 rtol]: the caller warns */
     int32_t pc_fallback;     /* 1 if the exact LU did not fit the device memory and ILU(k) + GMRES took its place */
+    int32_t backward_accepted; /* direct solves whose ||b - C x|| / ||b|| missed rtol but whose backward error
+                                  ||b - C x|| / (||C||_F ||x||) is <= 1e-12: shifts next to an eigenvalue */
+    int32_t reserved;
 } lsa_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -202,6 +205,10 @@ int lsa_ndlu_refactor(lsa_ctx *ctx, lsa_ndlu *f, const lsa_mat *C);
 void lsa_ndlu_destroy(lsa_ndlu *f);
 /* x = C^-1 b */
 int lsa_ndlu_solve(lsa_ctx *ctx, lsa_ndlu *f, const lsa_vec *b, lsa_vec *x);
+/* x = C^-T b (conj = 0) or C^-H b (conj != 0) on the same factors: the sweeps of the transposed forest.  The adjoint
+ * eigenproblem (Sensitivity/__init__.py:47-57,247-287 forms A^H, M^H explicitly and factorises again) needs no second
+ * factorisation and no transposed matrix. */
+int lsa_ndlu_solve_adjoint(lsa_ctx *ctx, lsa_ndlu *f, int conj, const lsa_vec *b, lsa_vec *x);
 int lsa_ndlu_solve_time(lsa_ctx *ctx, lsa_ndlu *f, const lsa_vec *b, lsa_vec *x, int iters, double *avg_ms);
 /* apply_bytes: algorithmic bytes of one solve (every factor scalar once + the vectors); apply_launches: dependent
  * launches of one solve (two per tree level) */
@@ -237,6 +244,10 @@ int lsa_op_create(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, const double
 void lsa_op_destroy(lsa_op *op);
 int lsa_op_apply(lsa_ctx *ctx, lsa_op *op, const lsa_vec *x, lsa_vec *y);
 int lsa_op_stats(const lsa_op *op, lsa_stats *out);
+/* Adjoint form of a shift-invert operator on the SAME factors: y = Kfac^-H Kmul^H x = (A - sigma M)^-H M^H x, the operator of
+ * the adjoint eigenproblem (A^H, M^H) at the target conj(sigma) (Sensitivity/__init__.py:230-311, which forms the two
+ * transposes and factorises again).  Transposed sweeps of the nested-dissection LU, transposed SpMV; one rank. */
+int lsa_op_set_adjoint(lsa_ctx *ctx, lsa_op *op, int on);
 /* Projected operator  y = P Kfac^-1 Kmul x  with P = diag(keep): keep[i] in {0, 1}, host array of n doubles (NULL
  * removes the projection).  Stands in for the velocity-subspace projection of ArpackEigenSolver's matvec
  * (Solver/eigen2.py:164-201: pressure dofs zeroed before and after the inner solve); the input side of the

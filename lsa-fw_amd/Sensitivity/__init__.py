@@ -5,9 +5,11 @@ Restates the two ``EigenSolver`` calls and the linear algebra around them in
 
 * ``solve_direct_mode``   (``:158-228``): shift-invert at the target, LU-class inner solves, pair nearest the target
   (``:200-201``);
-* ``solve_adjoint_mode``  (``:230-311``): eigenproblem of the explicitly formed ``(A^H, M^H)`` (``:47-57,247-248``) at
-  ``conj(sigma)``, ``TARGET_REAL`` ordering (``:256-262``), pair nearest ``conj(sigma)`` (``:277-278``), scaling so that
-  ``a^H M v = 1`` with the conjugating dot (``:281-287``);
+* ``solve_adjoint_mode``  (``:230-311``): eigenproblem of ``(A^H, M^H)`` at ``conj(sigma)``, ``TARGET_REAL`` ordering
+  (``:256-262``), pair nearest ``conj(sigma)`` (``:277-278``), scaling so that ``a^H M v = 1`` with the conjugating dot
+  (``:281-287``).  The reference forms both transposes explicitly (``:47-57,247-248``); here the operator
+  ``(A - sigma M)^-H M^H`` is applied on the device with transposed sweeps of the factors of ``A - sigma M`` and
+  transposed SpMVs (``EigenSolver(..., adjoint=True)``): no transposed matrix exists anywhere;
 * ``compute_wavemaker``   (``:404-445``) reduced to its nodal algebra on dof arrays:
   ``Sw = |a_u| |v_u| / |<a_u, M v_u>|`` per velocity node (the UFL projection to the pressure space needs dolfinx and
   is out of scope).
@@ -21,18 +23,12 @@ from __future__ import annotations
 import logging
 
 import numpy as np
-import scipy.sparse as sp
 
 from FEM.utils import iPETScMatrix
 from Solver.eigen import EigenSolver, EigensolverConfig
 from Solver.utils import PreconditionerType, iEpsProblemType, iEpsWhich, iSTType
 
 logger = logging.getLogger(__name__)
-
-
-def _hermitian(A: iPETScMatrix) -> iPETScMatrix:
-    """Explicit conjugate transpose, as ``Sensitivity/__init__.py:47-57`` forms it."""
-    return iPETScMatrix(sp.csr_matrix(A.as_scipy_array().conj().T))
 
 
 def _as_array(vec) -> np.ndarray:
@@ -43,7 +39,7 @@ class EigenSensitivitySolver:
     """Direct / adjoint eigenpair around a target for a pre-assembled pair ``(A, M)``."""
 
     def __init__(self, A, M, *, target: complex | None = None, tol_direct: float = 1e-6, tol_adjoint: float = 1e-3,
-                 max_it: int = 500, max_modes: int = 5, adjoint_shift_nudge: float = 1e-2, **solver_kwargs) -> None:
+                 max_it: int = 500, max_modes: int = 5, adjoint_shift_nudge: float = 0.0, **solver_kwargs) -> None:
         self._A = A if isinstance(A, iPETScMatrix) else iPETScMatrix.from_matrix(A)
         self._M = M if isinstance(M, iPETScMatrix) else iPETScMatrix.from_matrix(M)
         self._target = target
@@ -51,10 +47,10 @@ class EigenSensitivitySolver:
         self._max_it, self._max_modes = max_it, max_modes
         self._kw = solver_kwargs
         # The reference shifts the adjoint problem exactly at conj(sigma) of the converged direct mode, which makes
-        # A^H - conj(sigma) M^H singular to working precision; its LU tolerates that, an iterative inner solve cannot
-        # reach a residual tolerance on a singular system, and every inner iteration count grows as the shift approaches
-        # an eigenvalue.  The shift is therefore moved by a relative 1e-2: the wanted mode keeps the largest Ritz value
-        # (~1e2/|sigma|, converges in a few outer steps) and is itself unchanged.
+        # A^H - conj(sigma) M^H singular to working precision.  The exact LU handles that as the reference's does: the
+        # solves are accepted on their backward error (``stats["backward_accepted"]``).  ``adjoint_shift_nudge`` > 0 moves
+        # the shift by that relative amount (needed only with an iterative inner solve, which cannot reach a residual
+        # tolerance on a singular system).
         self._nudge = adjoint_shift_nudge
         self._sigma: complex | None = None
         self._v: np.ndarray | None = None
@@ -86,7 +82,7 @@ class EigenSensitivitySolver:
         if sigma is None or v is None:
             raise RuntimeError("Direct eigenpair must be computed before adjoint solve.")
         cfg = EigensolverConfig(num_eig=self._max_modes, problem_type=iEpsProblemType.GNHEP, atol=self._tol_adjoint, max_it=self._max_it)
-        es_adj = EigenSolver(_hermitian(self._A), _hermitian(self._M), cfg, check_hermitian=False, **self._kw)
+        es_adj = EigenSolver(self._A, self._M, cfg, check_hermitian=False, adjoint=True, **self._kw)
         es_adj.solver.set_st_type(iSTType.SINVERT)
         es_adj.solver.set_st_pc_type(PreconditionerType.LU)
         es_adj.solver.set_target(np.conj(sigma) * (1.0 + self._nudge))

@@ -301,7 +301,7 @@ class iEpsSolver:
     def __init__(self, A=None, M=None, comm=None, *, device: int = 0, ksp_type: KSPType = KSPType.GMRES,
                  ksp_rtol: float | None = None, restart: int = 1000, ksp_max_it: int = 4000, ilu_levels: int | None = None,
                  ilu_shift: float = 0.0, ordering: str = "rcm", seed: int = 0, layout: str = "single",
-                 project_out: np.ndarray | None = None, lu: str = "nd") -> None:
+                 project_out: np.ndarray | None = None, lu: str = "nd", adjoint: bool = False) -> None:
         if M is not None and A is None:
             raise ValueError("Cannot set right-hand operator M without left-hand operator A.")
         self._A = self._M = None
@@ -321,6 +321,10 @@ class iEpsSolver:
         if lu not in ("nd", "band"):
             raise ValueError("lu must be 'nd' (nested-dissection multifrontal LU) or 'band' (block-tridiagonal LU of the RCM order)")
         self._lu = lu
+        # adjoint=True: eigenpairs of (A^H, M^H) -- left eigenvectors of (A, M) -- through the operator
+        # (A - conj(target) M)^-H M^H applied on the factors of A - conj(target) M: no transposed matrix is formed
+        # (reference: Sensitivity/__init__.py:47-57,247-248 builds A^H and M^H explicitly)
+        self._adjoint = bool(adjoint)
         self._device, self._seed = device, seed
         if layout not in ("single", "sharded"):
             raise ValueError("layout must be 'single' or 'sharded'")
@@ -396,7 +400,7 @@ class iEpsSolver:
 
     def _signature(self):
         return (id(self._A), id(self._M), self._st_type, self._target, self._pc_type, self._ilu_levels, self._ordering, self._device,
-                self._layout, self._lu)  # (the antishift only changes the multiplied matrix, built per solve)
+                self._layout, self._lu, self._adjoint)  # (the antishift only changes the multiplied matrix, built per solve)
 
     def prepare(self) -> None:
         """Host-side analysis + upload: shared pattern, fill-reducing / pivot-safe ordering, CSR -> HBM.
@@ -534,17 +538,22 @@ class iEpsSolver:
                 "symmetric factorisation.  Use set_target at the centre of the interval with TARGET_MAGNITUDE and enough pairs.")
         # (like SLEPc, an interval set without iEpsWhich.ALL has no effect)
         lam_key = _lambda_rank_key(which, self._target)
+        if self._adjoint and (not sinvert or cayley or prep["pc_code"] != 2 or prep["part"] is not None):
+            raise NotImplementedError("adjoint=True needs shift-invert with the exact LU (PreconditionerType.LU, lu='nd') in the single-GPU layout")
         ksp_rtol = self._ksp_rtol if self._ksp_rtol is not None else float(np.clip(self._tol * 1e-2, 1e-13, 1e-8))
         op = basis = None
         try:
             op = lsa_hip.ShiftInvertOperator(
-                ctx, prep["dA"], prep["dM"], sigma, mode=2 if cayley else 0 if sinvert else 1, antishift=nu, ilu_levels=prep["levels"],
+                ctx, prep["dA"], prep["dM"], np.conj(sigma) if self._adjoint else sigma, mode=2 if cayley else 0 if sinvert else 1, antishift=nu,
+                ilu_levels=prep["levels"],
                 ilu_shift=self._ilu_shift,
                 ksp_rtol=ksp_rtol, ksp_restart=_restart_length(self._restart_len, n), ksp_maxit=self._ksp_max_it, pc_type=prep["pc_code"],
                 A_diag=prep["dAd"], M_diag=prep["dMd"], forest=prep["forest"],
                 rows=None if prep["forest"] is None else (_dist_rank_world()[0] * prep["part"].b_pad,
                                                           _dist_rank_world()[0] * prep["part"].b_pad + int(np.diff(prep["part"].starts)[_dist_rank_world()[0]])),
             )
+            if self._adjoint:
+                op.set_adjoint(True)
             part = prep["part"]
             keep = None
             if self._project_out is not None:
@@ -582,6 +591,8 @@ class iEpsSolver:
             if self._stats.get("pc_fallback"):
                 logger.warning("The exact LU did not fit the device memory: the inner solves ran ILU(%d)-preconditioned GMRES instead.",
                                prep["levels"])
+            if self._stats.get("backward_accepted"):
+                logger.info("%d inner solves were accepted on their backward error (the shift lies next to an eigenvalue).", self._stats["backward_accepted"])
             if self._stats.get("stagnated_solves") or self._stats.get("max_rel_res", 0.0) > 10.0 * ksp_rtol:
                 logger.warning("Inner solves stagnated above the requested tolerance: worst true relative residual %.2e (ksp_rtol %.1e, %d "
                                "solves accepted at the rounding floor). Eigenpairs are those of an inexactly applied operator; check "
@@ -602,9 +613,11 @@ class iEpsSolver:
 
         self.prepare()
         prep = self._prepared
-        if prep["part"] is not None:  # sharded layout: no rank holds the whole matrix on its device
+        if prep["part"] is not None or self._adjoint:  # sharded layout: no rank holds the whole matrix on its device; adjoint: A^H, M^H
             A = self._A.as_scipy_array()
             M = None if self._M is None else self._M.as_scipy_array()
+            if self._adjoint:
+                A, M = A.conj().T, (None if M is None else M.conj().T)
             lam, V = self._eigenvalues, self._eigenvectors
             Av, Mv = A @ V, (M @ V if M is not None else V)
             num = np.linalg.norm(Av - Mv * lam[np.newaxis, :], axis=0)

@@ -239,3 +239,4 @@ void blk_release(lsa_ilu* pc);
 // ---- nested-dissection multifrontal LU (ndlu.hip) -------------------------------------------------------
 struct lsa_ndlu;
 int ndlu_solve_dev(lsa_ctx* ctx, lsa_ndlu* f, int vdtype, const void* b, void* x);
+int ndlu_solve_adjoint_dev(lsa_ctx* ctx, lsa_ndlu* f, int conj, int vdtype, const void* b, void* x);

@@ -60,7 +60,7 @@ struct TileList {
 };
 
 struct NdLevel {
-    int32_t node_begin = 0, node_count = 0, max_m = 0;
+    int32_t node_begin = 0, node_count = 0, max_m = 0, max_f = 0;
     std::vector<int32_t> sorted_m;          // own sizes of the level's nodes (descending)
     std::vector<int32_t> upd_tile_prefix;   // update tiles of the first k nodes
     TileList upd, unperm, gemm[3], copyback;
@@ -578,6 +578,66 @@ __global__ __launch_bounds__(256) void nd_bwd_kernel(const NdNodeDev* __restrict
     }
 }
 
+// ---- sweeps of the transposed / conjugate-transposed system on the same factors (the adjoint eigenproblem of
+// Sensitivity/__init__.py:230-311 needs (A - sigma M)^-H without a second factorisation) --------------------------------------
+// C^T has the fronts F^T, so with the stored blocks  inv = F11^-1, S1 = -F21 inv, S2 = inv F12:
+//     up:    z = [inv | S2]^T v   (the node's first m rows, read down their columns);  y[own] = z[:m];  update = v_B - z[m:]
+//     down:  x[own] = y[own] + S1^T x[boundary]
+// Column access of row-major fronts: 64 lanes run along a row (coalesced), four slices of the rows per workgroup.
+template <bool CONJ, typename MT>
+__device__ __forceinline__ MT maybe_conj(MT a) {
+    if constexpr (CONJ) return s_conj(a);
+    else return a;
+}
+
+template <typename MT, typename VT, bool CONJ, bool DOWN>
+__global__ __launch_bounds__(256) void nd_sweepT_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ front,
+                                                        const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
+                                                        const VT* __restrict__ rhs, VT* __restrict__ x, VT* __restrict__ ubuf) {
+    __shared__ VT vs[kCH];
+    __shared__ VT part[4][64];
+    const NdNodeDev nd = lnodes[blockIdx.x];
+    const int32_t m = nd.m, f = nd.f, b = f - m;
+    const int32_t ncols = DOWN ? m : f;       // outputs of this sweep
+    const int32_t K = DOWN ? b : m;           // rows summed over
+    const int32_t c0 = (int32_t)blockIdx.y * 64;
+    if (c0 >= ncols || (DOWN && b == 0)) return;
+    const int32_t* ix = idx + nd.idx_off;
+    const int32_t* ge = gell + nd.ge_off;
+    const MT* F = front + nd.front_off + (DOWN ? (size_t)m * f : 0);
+    const int tid = threadIdx.x, lane = tid & 63, sl = tid >> 6;
+    const int32_t col = min(c0 + lane, ncols - 1);
+    VT acc = scalar_traits<VT>::zero();
+    for (int32_t k0 = 0; k0 < K; k0 += kCH) {
+        const int32_t kn = min(kCH, K - k0);
+        for (int32_t j = tid; j < kn; j += 256) {
+            if (DOWN) vs[j] = x[ix[m + k0 + j]];
+            else vs[j] = gather_updates(ge, nd.nchild, f, k0 + j, ubuf, rhs[ix[k0 + j]]);
+        }
+        __syncthreads();
+        const MT* Fc = F + (size_t)k0 * f + col;
+        int32_t k = sl;
+        for (; k + 12 < kn; k += 16) {
+            const MT a0 = Fc[(size_t)k * f], a1 = Fc[(size_t)(k + 4) * f], a2 = Fc[(size_t)(k + 8) * f], a3 = Fc[(size_t)(k + 12) * f];
+            fma_acc(acc, maybe_conj<CONJ>(a0), vs[k]);
+            fma_acc(acc, maybe_conj<CONJ>(a1), vs[k + 4]);
+            fma_acc(acc, maybe_conj<CONJ>(a2), vs[k + 8]);
+            fma_acc(acc, maybe_conj<CONJ>(a3), vs[k + 12]);
+        }
+        for (; k < kn; k += 4) fma_acc(acc, maybe_conj<CONJ>(Fc[(size_t)k * f]), vs[k]);
+        __syncthreads();
+    }
+    part[sl][lane] = acc;
+    __syncthreads();
+    if (sl == 0 && c0 + lane < ncols) {
+        const VT z = s_add(s_add(part[0][lane], part[1][lane]), s_add(part[2][lane], part[3][lane]));
+        const int32_t r = c0 + lane;
+        if (DOWN) x[ix[r]] = s_add(x[ix[r]], z);
+        else if (r < m) x[ix[r]] = z;
+        else ubuf[nd.u_off + (r - m)] = s_sub(gather_updates(ge, nd.nchild, f, r, ubuf, scalar_traits<VT>::zero()), z);
+    }
+}
+
 }  // namespace
 
 struct lsa_ndlu {
@@ -705,6 +765,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
             L.fwd_tiles = std::max(L.fwd_tiles, (S.f[(size_t)t] + kRT - 1) / kRT);
+            L.max_f = std::max(L.max_f, S.f[(size_t)t]);
             if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.m[(size_t)t] + kRT - 1) / kRT);
         }
         if (L.fwd_tiles > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a front of more than %d rows is not supported", 65535 * kRT);
@@ -874,6 +935,44 @@ int nd_apply(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
 }
 
 }  // namespace
+
+namespace {
+template <typename MT, typename VT, bool CONJ>
+int nd_apply_T(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
+    hipStream_t st = ctx->stream;
+    const MT* front = (const MT*)f->d_front;
+    const NdSymbolic& S = f->S;
+    for (size_t li = 0; li <= f->levels.size(); ++li) {
+        if ((int32_t)li == S.phase_b_level && S.nranks > 1 && S.xu_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, f->d_ubuf, (size_t)S.xu_slot * sizeof(VT)));
+        if (li == f->levels.size()) break;
+        const NdLevel& L = f->levels[li];
+        if (L.fwd_tiles > 0)
+            hipLaunchKernelGGL((nd_sweepT_kernel<MT, VT, CONJ, false>), dim3(L.node_count, (L.max_f + 63) / 64), dim3(256), 0, st, f->d_lnodes + L.node_begin,
+                               front, f->d_idx, f->d_gell, b, x, (VT*)f->d_ubuf);
+    }
+    for (size_t l = f->levels.size(); l-- > 0;) {
+        const NdLevel& L = f->levels[l];
+        if (L.bwd_tiles > 0)
+            hipLaunchKernelGGL((nd_sweepT_kernel<MT, VT, CONJ, true>), dim3(L.node_count, (L.max_m + 63) / 64), dim3(256), 0, st, f->d_lnodes + L.node_begin,
+                               front, f->d_idx, f->d_gell, b, x, (VT*)f->d_ubuf);
+    }
+    LSA_HIP_CHECK(ctx, hipGetLastError());
+    return LSA_OK;
+}
+}  // namespace
+
+// x = C^-T b (conj == 0) or C^-H b (conj != 0) on the factors of C
+int ndlu_solve_adjoint_dev(lsa_ctx* ctx, lsa_ndlu* f, int conj, int vdtype, const void* b, void* x) {
+    if (f->dtype == LSA_C128 && vdtype != LSA_C128) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve_adjoint: complex factors need complex vectors");
+    if (f->S.n == 0) return LSA_OK;
+    if (b == x) {
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(f->d_tmp, b, (size_t)f->S.n * esize(vdtype), hipMemcpyDeviceToDevice, ctx->stream));
+        b = f->d_tmp;
+    }
+    if (f->dtype == LSA_C128) return conj ? nd_apply_T<cplx, cplx, true>(ctx, f, (const cplx*)b, (cplx*)x) : nd_apply_T<cplx, cplx, false>(ctx, f, (const cplx*)b, (cplx*)x);
+    if (vdtype == LSA_C128) return nd_apply_T<double, cplx, false>(ctx, f, (const cplx*)b, (cplx*)x);  // real factors: C^H = C^T
+    return nd_apply_T<double, double, false>(ctx, f, (const double*)b, (double*)x);
+}
 
 // x = C^-1 b on device pointers (b and x distinct or identical: an aliased right-hand side is copied first)
 int ndlu_solve_dev(lsa_ctx* ctx, lsa_ndlu* f, int vdtype, const void* b, void* x) {
@@ -1113,6 +1212,14 @@ int lsa_ndlu_solve(lsa_ctx* ctx, lsa_ndlu* f, const lsa_vec* b, lsa_vec* x) {
     if (!ctx || !f || !b || !x) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve: null argument");
     if (b->n != f->S.n || x->n != f->S.n || b->dtype != x->dtype) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve: shape/dtype mismatch");
     LSA_CHECK(ndlu_solve_dev(ctx, f, b->dtype, b->d, x->d));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    return LSA_OK;
+}
+
+int lsa_ndlu_solve_adjoint(lsa_ctx* ctx, lsa_ndlu* f, int conj, const lsa_vec* b, lsa_vec* x) {
+    if (!ctx || !f || !b || !x) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve_adjoint: null argument");
+    if (b->n != f->S.n || x->n != f->S.n || b->dtype != x->dtype) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve_adjoint: shape/dtype mismatch");
+    LSA_CHECK(ndlu_solve_adjoint_dev(ctx, f, conj, b->dtype, b->d, x->d));
     LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     return LSA_OK;
 }

@@ -50,6 +50,8 @@ class lsa_stats(ctypes.Structure):
         ("seconds_solve", ctypes.c_double),
         ("stagnated_solves", ctypes.c_int32),
         ("pc_fallback", ctypes.c_int32),
+        ("backward_accepted", ctypes.c_int32),
+        ("reserved", ctypes.c_int32),
     ]
 
 
@@ -117,6 +119,7 @@ SIGNATURES = {
     "lsa_ndlu_refactor": (ctypes.c_int, [_P, _P, _P]),
     "lsa_ndlu_destroy": (None, [_P]),
     "lsa_ndlu_solve": (ctypes.c_int, [_P, _P, _P, _P]),
+    "lsa_ndlu_solve_adjoint": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P]),
     "lsa_ndlu_solve_time": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.POINTER(_DBL)]),
     "lsa_ndlu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64),
                                      ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I32), ctypes.POINTER(_DBL), ctypes.POINTER(_DBL)]),
@@ -127,6 +130,7 @@ SIGNATURES = {
     "lsa_op_destroy": (None, [_P]),
     "lsa_op_apply": (ctypes.c_int, [_P, _P, _P, _P]),
     "lsa_op_stats": (ctypes.c_int, [_P, ctypes.POINTER(lsa_stats)]),
+    "lsa_op_set_adjoint": (ctypes.c_int, [_P, _P, ctypes.c_int]),
     "lsa_op_set_projection": (ctypes.c_int, [_P, _P, _P]),
     "lsa_krylov_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
     "lsa_krylov_destroy": (None, [_P]),
@@ -600,6 +604,10 @@ class NdLu:
     def solve(self, b: DeviceVector, x: DeviceVector) -> None:
         self.ctx.check(self.ctx._lib.lsa_ndlu_solve(self.ctx.handle, self.handle, b.handle, x.handle))
 
+    def solve_adjoint(self, b: DeviceVector, x: DeviceVector, conj: bool = True) -> None:
+        """x = C^-H b (``conj``) or C^-T b on the same factors."""
+        self.ctx.check(self.ctx._lib.lsa_ndlu_solve_adjoint(self.ctx.handle, self.handle, int(conj), b.handle, x.handle))
+
     def time_solve(self, b: DeviceVector, x: DeviceVector, iters: int) -> float:
         ms = _DBL(0.0)
         self.ctx.check(self.ctx._lib.lsa_ndlu_solve_time(self.ctx.handle, self.handle, b.handle, x.handle, int(iters), ctypes.byref(ms)))
@@ -659,6 +667,10 @@ class ShiftInvertOperator:
 
     def apply(self, x: DeviceVector, y: DeviceVector) -> None:
         self.ctx.check(self.ctx._lib.lsa_op_apply(self.ctx.handle, self.handle, x.handle, y.handle))
+
+    def set_adjoint(self, on: bool = True) -> None:
+        """Apply ``(A - sigma M)^-H M^H`` on the same factors (``lsa_op_set_adjoint``)."""
+        self.ctx.check(self.ctx._lib.lsa_op_set_adjoint(self.ctx.handle, self.handle, int(on)))
 
     def set_projection(self, keep: np.ndarray | None) -> None:
         """Projected operator ``y = P Kfac^-1 Kmul x``, ``P = diag(keep)`` with 0/1 entries (``None`` removes it)."""

@@ -237,7 +237,7 @@ def test_direct_adjoint_pair():
     lam, v = sens.solve_direct_mode()
     ref, _, _ = shift_invert.solve(es.A, es.M, sigma, k=1, tol=1e-13)
     assert abs(lam - ref[0]) <= 1e-8 * abs(ref[0])
-    a = sens.solve_adjoint_mode()
+    a = sens.solve_adjoint_mode()  # shift exactly at conj(lam), as in the reference: solves accepted on their backward error
     assert abs(sens._sigma_adj - np.conj(lam)) <= 1e-8 * abs(lam)
     assert np.vdot(a, es.M @ v) == pytest.approx(1.0, abs=1e-10)
     # a is a left eigenvector: a^H (A - lam M) = 0
@@ -246,6 +246,36 @@ def test_direct_adjoint_pair():
     ux, uy = es.node_offset, es.node_offset + 1
     sw = sens.compute_wavemaker(ux, uy)
     assert sw.shape == ux.shape and np.all(sw >= 0) and np.isfinite(sw).all() and sw.max() > 0
+
+
+def test_adjoint_solver_matches_the_explicit_transposes():
+    """EigenSolver(adjoint=True) -- (A - conj(tau) M)^-H M^H on the factors of A - conj(tau) M -- finds the eigenpairs of the
+    explicitly transposed pair (the reference's construction, Sensitivity/__init__.py:47-57) at the target tau."""
+    from oracle import fem, shift_invert
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    es = fem.cylinder_case("S5k")
+    tau = np.conj(fem.SIGMA_RE50)
+    AH, MH = es.A.conj().T.tocsr(), es.M.conj().T.tocsr()
+    ref, _, _ = shift_invert.solve(AH, MH, tau, k=6, tol=1e-13, ncv=40)
+    s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=6, atol=1e-10, ncv=40), check_hermitian=False, adjoint=True)
+    s.solver.set_st_type(iSTType.SINVERT)
+    s.solver.set_target(tau)
+    s.solver.set_st_pc_type(PreconditionerType.LU)
+    pairs = s.solve()
+    lam = np.array([p[0] for p in pairs])
+    for r in ref:
+        assert np.min(np.abs(lam - r)) <= 1e-8 * abs(r)
+    assert s.solver.residuals()[:6].max() <= 1e-8  # ||A^H a - lam M^H a|| / (...)
+    a = s.solver.get_eigenvector_array(0)
+    assert np.linalg.norm(AH @ a - lam[0] * (MH @ a)) <= 1e-8 * (np.linalg.norm(AH @ a) + abs(lam[0]) * np.linalg.norm(MH @ a))
+    with pytest.raises(NotImplementedError):  # the adjoint sweeps exist for the exact LU only
+        t = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=2, atol=1e-8, ncv=20), check_hermitian=False, adjoint=True, ilu_levels=2)
+        t.solver.set_st_type(iSTType.SINVERT)
+        t.solver.set_target(tau)
+        t.solver.set_st_pc_type(PreconditionerType.ILU)
+        t.solve()
 
 
 @pytest.mark.parametrize("jobs", [1, 2])

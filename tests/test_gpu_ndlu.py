@@ -80,6 +80,28 @@ def test_ndlu_real_factors_real_and_complex_vectors(hip_ctx):
     assert np.linalg.norm(xc - (lu.solve(bc.real) + 1j * lu.solve(bc.imag))) <= 1e-10 * np.linalg.norm(xc)
 
 
+@pytest.mark.parametrize("case,sigma,leaf", [("S5k", SIGMA, 0), ("S5k", 0.05, 48), ("S30k", SIGMA, 0)])
+def test_ndlu_transposed_sweeps_solve_the_adjoint_systems(hip_ctx, case, sigma, leaf):
+    """C^-T b and C^-H b from the factors of C (no second factorisation, no transposed matrix)."""
+    import lsa_hip
+
+    es, C = _shifted(case, sigma)
+    if np.isrealobj(sigma):
+        C = sp.csr_matrix(C.real)
+    f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, C), leaf)
+    rng = np.random.default_rng(13)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    db = lsa_hip.DeviceVector.from_numpy(hip_ctx, b)
+    dx = lsa_hip.DeviceVector(hip_ctx, es.n, np.complex128)
+    for conj in (True, False):
+        f.solve_adjoint(db, dx, conj=conj)
+        x = dx.numpy()
+        Ct = C.conj().T if conj else C.T
+        assert np.linalg.norm(Ct @ x - b) <= 1e-12 * np.linalg.norm(b)
+    f.solve(db, dx)  # the plain solve is untouched by the adjoint sweeps
+    assert np.linalg.norm(C @ dx.numpy() - b) <= 1e-12 * np.linalg.norm(b)
+
+
 @pytest.mark.parametrize("n", [1, 2, 3, 9, 65, 130, 519])
 def test_ndlu_ragged_sizes_and_general_patterns(hip_ctx, n):
     """Tiny and odd sizes, structurally unsymmetric random patterns, weak diagonals (row pivoting inside the blocks)."""

@@ -185,7 +185,7 @@ int lsa_nd_sym_export_dist(const lsa_nd_sym *h, int32_t *kind, int64_t *front_of
 /* Analysis (from C's host copy of the pattern; reused from the context when the last destroyed or prepared factorisation
  * had the same pattern) + numeric factorisation on the device.  If a pivot block comes out singular and C has zero
  * diagonal entries, the analysis is redone once with those unknowns as constraints.  LSA_ERR_ZERO_PIVOT when a pivot block
- * is singular to 1e-13 max|C| after that, LSA_ERR_OOM when the fronts do not fit. */
+ * is singular to 1e-15 max|C| after that, LSA_ERR_OOM when the fronts do not fit. */
 int lsa_ndlu_create(lsa_ctx *ctx, const lsa_mat *C, int32_t leaf_size, lsa_ndlu **out);
 /* Analysis only, parked in the context: the pattern of P (any matrix with C's pattern, e.g. A) and the scalar type the
  * factors will have.  The next lsa_ndlu_create on that pattern then runs the numeric phase alone.  Lets a caller keep

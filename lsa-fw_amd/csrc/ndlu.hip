@@ -14,7 +14,7 @@
 // the O(n / B) block steps of a banded elimination, and sum(m^2 + 2 m b) scalars instead of n * bandwidth.
 //
 // Pivoting: rows are chosen by magnitude inside the pivot block of each front and never physically interchanged (the
-// permutation is undone once, when the inverse is gathered).  A pivot below 1e-13 * max|C| is reported as
+// permutation is undone once, when the inverse is gathered).  A pivot below 1e-15 * max|C| is reported as
 // LSA_ERR_ZERO_PIVOT; the operator layer (solver.hip) verifies every solve against b - C x.
 #include <algorithm>
 #include <chrono>
@@ -834,7 +834,9 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
     double max2;
     memcpy(&max2, &mbits, sizeof max2);
     if (!std::isfinite(max2)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "lsa_ndlu: the matrix holds non-finite values");
-    const double tiny2 = 1e-26 * max2;  // (1e-13 * max|C|)^2
+    // (1e-15 * max|C|)^2: rounding level.  A shift next to an eigenvalue (the adjoint problem of the reference is shifted exactly at
+    // a converged eigenvalue) gives legitimate pivots of 1e-12 max|C|; those solves are judged by their backward error.
+    const double tiny2 = 1e-30 * max2;
     const int32_t* tl = f->d_tiles;
     for (size_t li = 0; li < f->levels.size(); ++li) {
         const NdLevel& L = f->levels[li];
@@ -895,7 +897,7 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
     }
     LSA_HIP_CHECK(ctx, hipGetLastError());
     if (hflag[1] < 0)
-        return lsa_set_error(ctx, LSA_ERR_ZERO_PIVOT, "lsa_ndlu: a pivot block on rank %d is singular to 1e-13 * max|C| (column %d of its node)", -hflag[1] - 1,
+        return lsa_set_error(ctx, LSA_ERR_ZERO_PIVOT, "lsa_ndlu: a pivot block on rank %d is singular to 1e-15 * max|C| (column %d of its node)", -hflag[1] - 1,
                              hflag[2]);
     if (hflag[1] != 0) {
         const int32_t t = hflag[1] - 1;
@@ -904,7 +906,7 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
         memcpy(&mag2, &hi, sizeof mag2);
         return lsa_set_error(ctx, LSA_ERR_ZERO_PIVOT,
                              "lsa_ndlu: the pivot block of tree node %d (%d unknowns, front %d, level %d) is singular at its column %d: largest "
-                             "candidate pivot %.3e against max|C| = %.3e (threshold 1e-13 max|C|); the matrix is singular, or needs pivoting "
+                             "candidate pivot %.3e against max|C| = %.3e (threshold 1e-15 max|C|); the matrix is singular, or needs pivoting "
                              "across fronts",
                              t, S.m[(size_t)t], S.f[(size_t)t], S.level[(size_t)t], hflag[2], std::sqrt(mag2), std::sqrt(max2));
     }

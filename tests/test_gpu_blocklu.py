@@ -162,9 +162,11 @@ def test_eigensolver_with_lu_preconditioner_matches_oracle():
 
 
 def test_lu_request_falls_back_to_ilu_when_the_band_does_not_fit():
-    """PreconditionerType.LU on a matrix whose band cannot be inverted in HBM (a periodic chain in natural order:
-    bandwidth n - 1): ``lsa_blu_create`` refuses, the operator is built on ILU(2) + GMRES instead and the eigenvalues
-    still match the oracle."""
+    """PreconditionerType.LU with the block-tridiagonal LU (``lu="band"``) on a matrix whose band cannot be inverted in HBM
+    (a periodic chain in natural order: bandwidth n - 1): ``lsa_blu_create`` reports LSA_ERR_OOM -- the only failure that
+    is answered by a leaner method --, the operator is built on ILU(2) + GMRES instead, says so (``stats["pc_fallback"]``,
+    a warning) and the eigenvalues still match the oracle.  The nested-dissection LU (the default) has no band to fit:
+    it solves the same problem directly."""
     from oracle import shift_invert
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
@@ -176,11 +178,17 @@ def test_lu_request_falls_back_to_ilu_when_the_band_does_not_fit():
     A = sp.csr_matrix(A)
     sigma = 1.7
     ref, _, _ = shift_invert.solve(A, None, sigma, k=3, tol=1e-12, ncv=30)
-    solver = EigenSolver(A, None, EigensolverConfig(num_eig=3, atol=1e-10, ncv=30), check_hermitian=False, ordering="natural")
-    solver.solver.set_st_type(iSTType.SINVERT)
-    solver.solver.set_target(sigma)
-    solver.solver.set_st_pc_type(PreconditionerType.LU)
-    lam = np.array([p[0] for p in solver.solve()])
-    for r in ref:
-        assert np.min(np.abs(lam - r)) <= 1e-8 * abs(r)
-    assert solver.solver.stats["gmres_iters"] > 0  # inner solves were iterative: the block LU was not available
+    for kind in ("band", "nd"):
+        solver = EigenSolver(A, None, EigensolverConfig(num_eig=3, atol=1e-10, ncv=30), check_hermitian=False, ordering="natural", lu=kind)
+        solver.solver.set_st_type(iSTType.SINVERT)
+        solver.solver.set_target(sigma)
+        solver.solver.set_st_pc_type(PreconditionerType.LU)
+        lam = np.array([p[0] for p in solver.solve()])
+        for r in ref:
+            assert np.min(np.abs(lam - r)) <= 1e-8 * abs(r)
+        st = solver.solver.stats
+        if kind == "band":  # inner solves were iterative: the block LU was not available
+            assert st["pc_fallback"] == 1 and st["gmres_iters"] > 0
+        else:
+            assert st["pc_fallback"] == 0 and st["gmres_iters"] == 0
+        solver.solver.release()

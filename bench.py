@@ -213,21 +213,169 @@ def lu_apply_rate(es, sigma, device):
     return out
 
 
-def cpu_baseline(es, sigma, args):
-    """The oracle (scipy ARPACK + SuperLU) on the same problem, same k / ncv / tolerance, on the host cores."""
-    from oracle import shift_invert
+def _slepc_reference(es, sigma, args):
+    """Row B1 of BASELINE.md: the reference's own stack (slepc4py Krylov-Schur, ST sinvert, -st_pc_type lu) when the box has it.
+    The GPU boxes receive only this repository, so this normally reports that SLEPc is absent."""
+    try:
+        from petsc4py import PETSc
+        from slepc4py import SLEPc
+    except Exception as exc:  # noqa: BLE001
+        return {"available": False, "why": f"{type(exc).__name__}: {exc}"}
+    A, M = es.A.astype(np.complex128), es.M.astype(np.complex128)
+    pA = PETSc.Mat().createAIJ(size=A.shape, csr=(A.indptr, A.indices, A.data))
+    pM = PETSc.Mat().createAIJ(size=M.shape, csr=(M.indptr, M.indices, M.data))
+    eps = SLEPc.EPS().create()
+    eps.setOperators(pA, pM)
+    eps.setProblemType(SLEPc.EPS.ProblemType.GNHEP)
+    eps.setDimensions(args.k, args.ncv)
+    eps.setTolerances(args.atol, 500)
+    eps.setTarget(sigma)
+    eps.setWhichEigenpairs(SLEPc.EPS.Which.TARGET_MAGNITUDE)
+    st = eps.getST()
+    st.setType(SLEPc.ST.Type.SINVERT)
+    st.getKSP().setType("preonly")
+    st.getKSP().getPC().setType("lu")
+    t0 = time.perf_counter()
+    eps.solve()
+    dt = time.perf_counter() - t0
+    return {"available": True, "eigenpairs_per_s": min(eps.getConverged(), args.k) / dt, "seconds": dt,
+            "lambda": [complex(eps.getEigenvalue(i)) for i in range(min(eps.getConverged(), args.k))]}
 
+
+def _cpu_worker(args) -> None:
+    """Child process of cpu_baseline (no GPU): one oracle solve with the BLAS thread count of its environment."""
+    from oracle import shift_invert
+    from synthetic import fem
+
+    es = fem.cylinder_case(args.case)
+    sigma = SWEEP_SIGMAS[2]
     t0 = time.perf_counter()
     lam, V, res, info = shift_invert.solve(es.A, es.M, sigma, k=args.k, tol=args.atol, ncv=args.ncv, return_info=True)
     dt = time.perf_counter() - t0
-    nconv = int(np.sum(res <= RESIDUAL_TOL))
-    return {
-        "value": nconv / dt, "unit": "eigenpairs/s", "cores": 1, "kind": "port",
-        "sample": f"one full solve of the same {args.case} problem (k={args.k}, ncv={args.ncv}, tol={args.atol:g}): {dt:.1f} s "
-                  f"(SuperLU factor {info['seconds_factor']:.1f} s, {info['op_applies']} applies), scipy ARPACK+SuperLU, "
-                  f"one thread (BLAS threads = {os.environ.get('OPENBLAS_NUM_THREADS')}); host has {os.cpu_count()} cores; "
-                  f"SLEPc itself is not installed",
-    }, lam
+    print(json.dumps({"seconds": dt, "eigenpairs_per_s": int(np.sum(res <= RESIDUAL_TOL)) / dt, "factor": info["seconds_factor"],
+                      "applies": info["op_applies"], "lam": [[z.real, z.imag] for z in lam]}), flush=True)
+
+
+def cpu_baseline(es, sigma, args):
+    """The oracle (scipy ARPACK + SuperLU, the algorithm Solver/eigen2.py states) on the same problem, same k / ncv /
+    tolerance, on the host cores: once with one BLAS thread and once with 8 (each in a child process started with that
+    thread count: resizing a live OpenBLAS pool under SuperLU crashed); the faster run is the baseline.  SuperLU itself is
+    sequential; more BLAS threads were measured slower on these supernode sizes.  A slepc4py run is added when the box has it."""
+    import subprocess
+
+    runs = []
+    for threads in (1, 8):
+        env = dict(os.environ)
+        for var in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+            env[var] = str(threads)
+        env["HIP_VISIBLE_DEVICES"] = ""  # the checker never touches the GPU
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--cpu-worker", "--case", args.case, "--k", str(args.k), "--ncv", str(args.ncv), "--atol", str(args.atol)]
+        try:
+            proc = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+            rec = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith("{")][-1])
+        except Exception as exc:  # noqa: BLE001
+            log(f"cpu baseline with {threads} thread(s) failed: {type(exc).__name__}: {exc}")
+            continue
+        rec["threads"] = threads
+        runs.append(rec)
+    if not runs:
+        raise RuntimeError("no CPU baseline run finished")
+    best = max(runs, key=lambda r: r["eigenpairs_per_s"])
+    slepc = _slepc_reference(es, sigma, args)
+    out = {
+        "value": best["eigenpairs_per_s"], "unit": "eigenpairs/s", "cores": best["threads"], "kind": "port",
+        "sample": f"one full solve of the same {args.case} problem (k={args.k}, ncv={args.ncv}, tol={args.atol:g}) per thread count, scipy "
+                  f"ARPACK+SuperLU: " + "; ".join(f"{r['threads']} BLAS thread(s) {r['seconds']:.1f} s (SuperLU factor {r['factor']:.1f} s, "
+                                                  f"{r['applies']} applies)" for r in runs)
+                  + f"; host has {os.cpu_count()} cores; slepc4py: " + ("ran" if slepc.get("available") else "not installed"),
+        "runs": [{k: v for k, v in r.items() if k != "lam"} for r in runs],
+    }
+    if slepc.get("available"):
+        out["slepc"] = {"eigenpairs_per_s": slepc["eigenpairs_per_s"], "seconds": slepc["seconds"]}
+    return out, np.array([complex(a, b) for a, b in best["lam"]])
+
+
+def sptrsv_roofline(args, device):
+    """The sparse triangular solves of the exact LU (upward + downward sweep over the elimination forest = L and U solve) on
+    the factors of the refined mesh S500k: HIP-event time per pair against the algorithmic bytes (every factor scalar once +
+    the vectors).  SURVEY 8(d)'s figure for an ILU(0) pair, (20 nnz + 52 n) bytes of the UNfactored matrix, is given beside it."""
+    import lsa_hip
+    from synthetic import fem
+
+    es = fem.cylinder_case(args.roof_case)
+    C = sp.csr_matrix((es.A.data - fem.SIGMA_RE50 * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+    ctx = lsa_hip.Context(device)
+    try:
+        dC = lsa_hip.CsrMatrix.from_scipy(ctx, C)
+        f = lsa_hip.NdLu(ctx, dC)
+        rng = np.random.default_rng(0)
+        b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+        db = lsa_hip.DeviceVector.from_numpy(ctx, b)
+        dx = lsa_hip.DeviceVector(ctx, es.n, np.complex128)
+        f.time_solve(db, dx, 5)
+        ms = f.time_solve(db, dx, 50)
+        resid = float(np.linalg.norm(C @ dx.numpy() - b) / np.linalg.norm(b))
+        f.refactor(dC)
+        info = f.info()
+        out = {"case": args.roof_case, "n": es.n, "nnz": int(C.nnz), "kernel": "nd_fwd_kernel + nd_bwd_kernel<cplx,cplx> (one launch per forest level and sweep)",
+               "ms_per_pair": ms, "algorithmic_bytes": info["apply_bytes"], "achieved": info["apply_bytes"] / ms / 1e6, "unit": "GB/s",
+               "frac": info["apply_bytes"] / ms / 1e6 / HBM_PEAK_GBS, "dependent_launches": info["apply_launches"], "factor_scalars": info["factor_entries"],
+               "seconds_refactor": info["seconds_numeric"], "relative_residual": resid,
+               "ilu0_pair_bytes_of_the_unfactored_matrix": 20.0 * C.nnz + 52.0 * es.n}
+        f = db = dx = dC = None
+    finally:
+        import gc
+
+        gc.collect()
+        ctx.close()
+    return out
+
+
+def roofline_3d(args, device):
+    """The same two kernels on the 3D Taylor-Hood row pattern of BASELINE config 4 (unit cube, Kuhn tetrahedra, ~90 entries per
+    row): SpMV on 24 block-diagonal replicas of C40k (0.9 M rows, 84 M entries, 1.7 GB: beyond the Infinity Cache) and the LU
+    sweeps on the factors of one C40k."""
+    import lsa_hip
+    from synthetic import fem
+
+    es = fem.cube_case("C40k")
+    C = sp.csr_matrix((es.A.data - (fem.SIGMA_CUBE + 0.5j) * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+    reps, n1, nnz1 = 24, C.shape[0], C.nnz
+    rp = np.concatenate([[0], (C.indptr[1:][None, :] + (np.arange(reps) * nnz1)[:, None]).ravel()]).astype(np.int32)
+    ci = (C.indices[None, :] + (np.arange(reps, dtype=np.int64) * n1)[:, None]).ravel().astype(np.int32)
+    big = sp.csr_matrix((np.tile(C.data, reps), ci, rp), shape=(n1 * reps, n1 * reps))
+    ctx = lsa_hip.Context(device)
+    try:
+        rng = np.random.default_rng(0)
+        x = rng.standard_normal(big.shape[0]) + 1j * rng.standard_normal(big.shape[0])
+        dB = lsa_hip.CsrMatrix.from_scipy(ctx, big)
+        dx = lsa_hip.DeviceVector.from_numpy(ctx, x)
+        dy = lsa_hip.DeviceVector(ctx, big.shape[0], np.complex128)
+        dB.time_matvec(dx, dy, 5)
+        ms = dB.time_matvec(dx, dy, args.roof_iters)
+        info = dB.matvec_info(np.complex128)
+        bytes_c = 20.0 * big.nnz + 36.0 * big.shape[0]
+        out = {"spmv": {"n": big.shape[0], "nnz": int(big.nnz), "kernel": info["kernel"], "ms_per_launch": ms, "algorithmic_bytes": bytes_c,
+                        "achieved": bytes_c / ms / 1e6, "frac": bytes_c / ms / 1e6 / HBM_PEAK_GBS, "moved_bytes": info["bytes_moved"]}}
+        del dB, dx, dy
+        dC = lsa_hip.CsrMatrix.from_scipy(ctx, C)
+        f = lsa_hip.NdLu(ctx, dC)
+        b = rng.standard_normal(n1) + 1j * rng.standard_normal(n1)
+        db = lsa_hip.DeviceVector.from_numpy(ctx, b)
+        dz = lsa_hip.DeviceVector(ctx, n1, np.complex128)
+        f.time_solve(db, dz, 5)
+        ms2 = f.time_solve(db, dz, 30)
+        li = f.info()
+        out["lu_sweeps"] = {"case": "C40k", "n": n1, "ms_per_pair": ms2, "algorithmic_bytes": li["apply_bytes"], "achieved": li["apply_bytes"] / ms2 / 1e6,
+                            "frac": li["apply_bytes"] / ms2 / 1e6 / HBM_PEAK_GBS, "max_front": li["max_front"], "levels": li["levels"],
+                            "seconds_factor": li["seconds_numeric"], "relative_residual": float(np.linalg.norm(C @ dz.numpy() - b) / np.linalg.norm(b))}
+        f = db = dz = dC = None
+    finally:
+        import gc
+
+        gc.collect()
+        ctx.close()
+    return out
 
 
 def main() -> None:
@@ -252,7 +400,12 @@ def main() -> None:
     ap.add_argument("--roof-iters", type=int, default=50)
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)  # child process of the cpu_baseline leg
     args = ap.parse_args()
+    if args.cpu_worker:
+        args.case = args.case or "S30k"
+        _cpu_worker(args)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -404,7 +557,9 @@ def main() -> None:
         }
         if world == 1 and not args.no_other_pc:
             for name, fn in (("two_solves_in_flight", lambda: solves_in_flight(es, sigma, args, device)),
-                             ("lu_apply", lambda: lu_apply_rate(es, sigma, device))):
+                             ("lu_apply", lambda: lu_apply_rate(es, sigma, device)),
+                             ("sptrsv_roofline", lambda: sptrsv_roofline(args, device)),
+                             ("pattern_3d", lambda: roofline_3d(args, device))):
                 try:  # secondary figures must never cost the bench line
                     out["config"][name] = fn()
                 except Exception as exc:  # noqa: BLE001

@@ -139,15 +139,24 @@ __global__ __launch_bounds__(256) void spmv_subwave16_kernel(int32_t n, const in
 // long, so row k of the group starts at p0 + k * len: no extra row-pointer loads.
 // (Tried and dropped: one 16-byte record {first entry, length, first row, rows} per group with the next group's record
 // requested ahead, instead of row pointers behind a group pointer: 692 vs 635 us on SROOF.)
-template <typename MT, typename VT, int LPR, bool C16>
-__global__ __launch_bounds__(256) void spmv_group_kernel(int32_t ngroups, const int32_t* __restrict__ gstart, const int32_t* __restrict__ rp,
-                                                         const int32_t* __restrict__ ci, const uint16_t* __restrict__ ci16,
-                                                         const int32_t* __restrict__ cbase, const MT* __restrict__ val, const VT* __restrict__ x,
-                                                         VT* __restrict__ y) {
+// XCD: workgroup b runs on XCD b % 8 (observed dispatch order; speed only), each with its own L2.  With groups interleaved
+// over workgroups every XCD gathers the whole of x; here workgroup b takes the contiguous chunk of groups number
+// (b % 8) * (G / 8) + b / 8, so an XCD walks one eighth of the rows and touches one eighth of x (plus the band).
+template <typename MT, typename VT, int LPR, bool C16, bool XCD>
+__global__ __launch_bounds__(256) void spmv_group_kernel(int32_t ngroups, int32_t chunk, const int32_t* __restrict__ gstart,
+                                                         const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                         const uint16_t* __restrict__ ci16, const int32_t* __restrict__ cbase,
+                                                         const MT* __restrict__ val, const VT* __restrict__ x, VT* __restrict__ y) {
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int32_t lane = (int32_t)(gid % LPR);
-    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) / LPR;
-    for (int64_t grp = gid / LPR; grp < ngroups; grp += stride) {
+    int64_t stride = ((int64_t)gridDim.x * blockDim.x) / LPR, grp = gid / LPR, gend = ngroups;
+    if constexpr (XCD) {
+        const int64_t G = gridDim.x, vb = (int64_t)(blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3);
+        stride = 256 / LPR;
+        grp = vb * chunk + threadIdx.x / LPR;
+        gend = min((int64_t)ngroups, (vb + 1) * chunk);
+    }
+    for (; grp < gend; grp += stride) {
         const int32_t r0 = gstart[grp], g = gstart[grp + 1] - r0;
         const int32_t p0 = rp[r0], len = rp[r0 + 1] - p0;
         const VT* xr = x;
@@ -301,12 +310,19 @@ static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, 
         int64_t gwant = ((int64_t)A->ngroups * LPR + threads - 1) / threads;
         const int64_t gcap = (variant >> 16) > 0 ? cap : (int64_t)ctx->num_cu * 256;  // more, shorter workgroups: 2 % faster than 64 per CU
         const int gblocks = (int)(gwant < 1 ? 1 : (gwant > gcap ? gcap : gwant));
+        if ((variant & 0x8000) && !c16 && A->ngroups >= 8 * 64) {
+            const int G = ((gblocks + 7) / 8) * 8;
+            const int32_t chunk = (A->ngroups + G - 1) / G;
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false, true>), dim3(G), dim3(threads), 0, ctx->stream, A->ngroups, chunk, A->grp_start, A->rp,
+                               A->ci, (const uint16_t*)nullptr, (const int32_t*)nullptr, (const MT*)A->val, (const VT*)x, (VT*)y);
+            return;
+        }
         if (c16)
-            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, true>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, A->grp_start, A->rp, A->ci,
-                               (const uint16_t*)A->ci16, (const int32_t*)A->cbase, (const MT*)A->val, (const VT*)x, (VT*)y);
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, true, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, 0, A->grp_start, A->rp,
+                               A->ci, (const uint16_t*)A->ci16, (const int32_t*)A->cbase, (const MT*)A->val, (const VT*)x, (VT*)y);
         else
-            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, A->grp_start, A->rp, A->ci,
-                               (const uint16_t*)nullptr, (const int32_t*)nullptr, (const MT*)A->val, (const VT*)x, (VT*)y);
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, 0, A->grp_start, A->rp,
+                               A->ci, (const uint16_t*)nullptr, (const int32_t*)nullptr, (const MT*)A->val, (const VT*)x, (VT*)y);
         return;
     }
     if (spmv_wants_ci16(A, variant) && !NT && ensure_ci16(A)) {

@@ -32,6 +32,9 @@ bytes_c = 20.0 * nnz + 36.0 * n
 variants = {
     "default (groups, 32-bit, 256 wg/cu)": 0,
     "groups, 32-bit, wg/cu64": 16 | 0x2000 | 0x1000 | (64 << 16),
+    "groups, xcd chunks, wg/cu256": 16 | 0x2000 | 0x1000 | 0x8000 | (256 << 16),
+    "groups, xcd chunks, wg/cu64": 16 | 0x2000 | 0x1000 | 0x8000 | (64 << 16),
+    "groups, xcd chunks, wg/cu1024": 16 | 0x2000 | 0x1000 | 0x8000 | (1024 << 16),
     "groups, 32-bit, wg/cu1024": 16 | 0x2000 | 0x1000 | (1024 << 16),
     "groups, 32-bit, wg/cu4096": 16 | 0x2000 | 0x1000 | (4096 << 16),
     "groups, 32-bit, lpr8, wg/cu1024": 8 | 0x2000 | 0x1000 | (1024 << 16),

@@ -146,7 +146,7 @@ def pmc_traffic(args, kernel: str):
     squash = lambda t: "".join(t.split()).replace("void", "")  # noqa: E731
     for path in sorted((ROOT / "profiles").glob("r*_spmv_traffic.json"), reverse=True):
         rec = json.loads(path.read_text()).get("c128", {})
-        if squash(kernel) and squash(kernel) in squash(rec.get("kernel", "")):
+        if squash(kernel) and squash(rec.get("kernel", "")).startswith(squash(kernel)):
             return float(rec["traffic_bytes"])
     return None
 

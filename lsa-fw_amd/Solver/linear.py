@@ -4,8 +4,8 @@ Drop-in for the static ``LinearSolver.solve`` of ``/root/reference/Solver/linear
 same signature and the same two supported ``ksp_type`` values,
 
 * ``KSPType.PREONLY`` -- the reference pairs it with ``PreconditionerType.LU`` (``:60-64``): here the exact
-  block-tridiagonal LU on the device (``lsa_blu_*``), with ILU(k)-preconditioned GMRES as fall-back when the band does
-  not fit HBM;
+  nested-dissection multifrontal LU on the device (``lsa_ndlu_*``; the dissection is internal, so no host ordering),
+  with ILU(k)-preconditioned GMRES as fall-back only when the factors do not fit the device memory;
 * ``KSPType.GMRES``   -- the reference runs it with ``PreconditionerType.NONE`` (``:60-64``, "< 200 iterations" on the
   cylinder Stokes system, ``doc/models/solver-linear.md:104``): here the device GMRES, unpreconditioned by default like
   the reference, or with ``pc=PreconditionerType.ILU`` to use the ILU(k) factors + blocked SpTRSV.
@@ -49,8 +49,8 @@ class LinearSolver:
             raise ValueError(f"Right-hand side has shape {rhs.shape}, expected ({mat.shape[0]},)")
         cplx = np.iscomplexobj(mat.data) or np.iscomplexobj(rhs)
         vdt = np.complex128 if cplx else np.float64
-        factored = ksp_type is KSPType.PREONLY or pc is not PreconditionerType.NONE
-        perm = pivot_safe_rcm(mat) if factored and mat.shape[0] > 8 else np.arange(mat.shape[0])
+        # ILU(k) wants a banded, pivot-safe order; the exact LU dissects the pattern itself
+        perm = pivot_safe_rcm(mat) if (ksp_type is KSPType.GMRES and pc is not PreconditionerType.NONE and mat.shape[0] > 8) else np.arange(mat.shape[0])
         ctx = lsa_hip.Context(device)
         try:
             dA = lsa_hip.CsrMatrix.from_scipy(ctx, _permute(mat, perm))
@@ -60,11 +60,17 @@ class LinearSolver:
             its = 0
             if ksp_type is KSPType.PREONLY:
                 try:
-                    lsa_hip.BlockLu(ctx, dA).solve(db, dx)
-                except lsa_hip.LsaError as exc:  # band too wide for HBM, or a singular Schur block
-                    logger.warning("block LU unavailable (%s); using ILU(%d)-GMRES", exc, ilu_levels)
-                    its, _ = lsa_hip.gmres(ctx, dA, lsa_hip.Ilu(ctx, dA, levels=ilu_levels), db, dx, rtol=min(rtol, 1e-12),
+                    lsa_hip.NdLu(ctx, dA).solve(db, dx)
+                except lsa_hip.LsaError as exc:
+                    if exc.status != -8:  # only running out of device memory is answered by a leaner method
+                        raise
+                    logger.warning("exact LU does not fit the device memory (%s); using ILU(%d)-GMRES", exc, ilu_levels)
+                    p2 = pivot_safe_rcm(mat)
+                    dA2 = lsa_hip.CsrMatrix.from_scipy(ctx, _permute(mat, p2))
+                    db2 = lsa_hip.DeviceVector.from_numpy(ctx, np.ascontiguousarray(rhs[p2], dtype=vdt))
+                    its, _ = lsa_hip.gmres(ctx, dA2, lsa_hip.Ilu(ctx, dA2, levels=ilu_levels), db2, dx, rtol=min(rtol, 1e-12),
                                            restart=restart, maxit=max(max_it, 4000))
+                    perm = p2
             else:
                 pco = None if pc is PreconditionerType.NONE else lsa_hip.Ilu(ctx, dA, levels=ilu_levels)
                 its, _ = lsa_hip.gmres(ctx, dA, pco, db, dx, rtol=rtol, restart=min(restart, max_it), maxit=max_it)

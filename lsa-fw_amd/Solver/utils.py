@@ -522,6 +522,9 @@ class iEpsSolver:
         import lsa_hip
         from lsa_hip.krylov_schur import krylov_schur
 
+        if self._which is iEpsWhich.ALL:
+            self._solve_interval()
+            return
         self.prepare()
         prep = self._prepared
         ctx, n, sinvert, sigma, perm = prep["ctx"], prep["n"], prep["sinvert"], prep["sigma"], prep["perm"]
@@ -530,13 +533,7 @@ class iEpsSolver:
         cayley = prep["cayley"]
         nu = complex(sigma if self._antishift is None else self._antishift)  # STCayleySetAntishift defaults to the shift
         which = self._which or (iEpsWhich.TARGET_MAGNITUDE if sinvert else iEpsWhich.LARGEST_MAGNITUDE)
-        if which is iEpsWhich.ALL:
-            # SLEPc computes "all eigenvalues in [a, b]" by spectrum slicing: shift-invert sweeps whose completeness rests on
-            # inertia counts of a symmetric-indefinite factorisation.  The block LU here pivots rows and has no inertia.
-            raise NotImplementedError(
-                "iEpsWhich.ALL (spectrum slicing over set_interval) is not available on the HIP path: it needs the inertia of a "
-                "symmetric factorisation.  Use set_target at the centre of the interval with TARGET_MAGNITUDE and enough pairs.")
-        # (like SLEPc, an interval set without iEpsWhich.ALL has no effect)
+        # (like SLEPc, an interval set without iEpsWhich.ALL has no effect; ALL is handled by _solve_interval)
         lam_key = _lambda_rank_key(which, self._target)
         if self._adjoint and (not sinvert or cayley or prep["pc_code"] != 2 or prep["part"] is not None):
             raise NotImplementedError("adjoint=True needs shift-invert with the exact LU (PreconditionerType.LU, lu='nd') in the single-GPU layout")
@@ -605,6 +602,87 @@ class iEpsSolver:
         self._eigenvectors = np.asfortranarray(X[:, order])  # column access (one eigenvector) must be contiguous
         self._residual_estimates = res.residuals[order]
         self._restarts = res.restarts
+
+    def _solve_interval(self) -> None:
+        """``iEpsWhich.ALL`` + ``set_interval(a, b)`` (reference: ``Solver/utils.py:248-254``, SLEPc's spectrum slicing):
+        every eigenvalue of a Hermitian problem in ``[a, b]``, by a sweep of shift-invert solves.
+
+        SLEPc proves completeness with inertia counts of a symmetric-indefinite factorisation; the LU here pivots rows and
+        has none.  Completeness rests instead on the order in which shift-invert Krylov-Schur converges on a Hermitian
+        problem -- nearest the shift first: a solve that returned the m nearest eigenvalues has found everything within
+        the distance of the m-th.  Shifts advance from a to b so that those covered intervals overlap; a gap is closed by a
+        shift inside it.  Pairs found from two shifts are merged when their eigenvalues agree and their vectors are
+        parallel (a repeated eigenvalue keeps its independent vectors).  A multiple eigenvalue whose copies never show up in
+        a single-vector Krylov space can still be under-counted: the one guarantee SLEPc's inertia gives and this does not."""
+        if self._interval is None:
+            raise ValueError("iEpsWhich.ALL needs an interval: call set_interval(a, b) first")
+        if self._problem_type not in _HERMITIAN:
+            raise ValueError("iEpsWhich.ALL (all eigenvalues in an interval) is defined for Hermitian problem types (HEP, GHEP) only, as in SLEPc")
+        a, b = self._interval[0], self._interval[1]
+        if not (np.isfinite(a) and np.isfinite(b) and a < b):
+            raise ValueError(f"bad interval [{a}, {b}]")
+        saved = (self._which, self._st_type, self._target, self._nev, self._ncv)
+        n = self._A.shape[0]
+        ncv = min(self._ncv if self._ncv is not None else 32, n)
+        per_shift = max(1, min(ncv // 2, 16))
+        found_lam: list[float] = []
+        found_vec: list[np.ndarray] = []
+        stats_total: dict = {}
+        restarts = 0
+
+        def merge(lam, vecs):
+            for lv, v in zip(lam, vecs.T):
+                dup = any(abs(lv - l0) <= 1e-7 * max(1.0, abs(lv)) and abs(np.vdot(v0, v)) > 0.9 for l0, v0 in zip(found_lam, found_vec))
+                if not dup and a <= lv <= b:
+                    found_lam.append(float(lv))
+                    found_vec.append(v.copy())
+
+        try:
+            self._which, self._st_type = iEpsWhich.TARGET_MAGNITUDE, iSTType.SINVERT
+            self._nev, self._ncv = per_shift, ncv
+            covered = a  # everything in [a, covered] has been found
+            span = b - a
+            sigma = a + 1e-3 * span * (1.0 + 1e-2)  # not exactly on the end point (an eigenvalue could sit there)
+            pending: list[float] = []
+            for _ in range(200):
+                self._target = complex(sigma)
+                if getattr(self, "_prepared", None) is not None:  # the uploaded matrices do not depend on the shift
+                    self._prepared["sig"] = self._signature()
+                    self._prepared["sigma"] = self._target
+                self.solve()
+                restarts += self._restarts
+                for k, v in self._stats.items():
+                    if isinstance(v, (int, float)) and k not in ("last_rel_res", "max_rel_res"):
+                        stats_total[k] = stats_total.get(k, 0) + v
+                lam = np.real(self._eigenvalues)
+                merge(lam, self._eigenvectors)
+                # the m nearest eigenvalues were returned: the ball of the m-th is complete; with fewer than asked for, the
+                # spectrum is exhausted on this side of the cover
+                dist = np.sort(np.abs(lam - sigma))
+                radius = dist[-1] if len(dist) >= per_shift else max(span, dist[-1] if len(dist) else span)
+                left, right = sigma - radius, sigma + radius
+                if left > covered + 1e-12 * span:  # a gap between the cover and this ball: put a shift into it first
+                    pending.append(sigma)
+                    sigma = 0.5 * (covered + left)
+                    continue
+                covered = max(covered, right)
+                while pending and pending[-1] <= covered:  # postponed shifts that the cover has reached in the meantime
+                    pending.pop()
+                if covered >= b:
+                    break
+                sigma = covered + max(0.5 * radius, 1e-6 * span)
+            else:
+                raise RuntimeError("interval sweep did not cover [a, b] in 200 shifts")
+        finally:
+            self._which, self._st_type, self._target, self._nev, self._ncv = saved
+            if getattr(self, "_prepared", None) is not None:
+                self._prepared["sig"] = None  # the next solve() prepares for its own settings
+        order = np.argsort(found_lam)
+        self._eigenvalues = np.array(found_lam, dtype=np.complex128)[order]
+        self._eigenvectors = np.asfortranarray(np.column_stack([found_vec[i] for i in order])) if found_lam else np.zeros((n, 0), dtype=np.complex128)
+        self._residual_estimates = np.zeros(len(found_lam))
+        self._restarts = restarts
+        self._stats = stats_total
 
     def residuals(self) -> np.ndarray:
         """Relative residuals ``||A v - lam M v|| / (||A v|| + |lam| ||M v||)`` of the converged pairs, evaluated on the

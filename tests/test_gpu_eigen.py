@@ -359,17 +359,85 @@ def test_vibrating_membrane_benchmark_published_values():
     assert np.max(np.abs(vals - ana) / ana) <= 2e-4  # P2 on 32 x 32: the 6.06e-5 average of the report is over 15 modes
 
 
-def test_spectrum_slicing_request_fails_loudly():
-    """``set_interval`` + ``iEpsWhich.ALL`` asks SLEPc for spectrum slicing (inertia-based); the HIP path refuses instead
-    of silently returning something else.  Without ALL the interval is ignored, as in SLEPc."""
+def test_all_eigenvalues_in_an_interval():
+    """``set_interval`` + ``iEpsWhich.ALL`` (reference: Solver/utils.py:248-254; SLEPc: spectrum slicing): every eigenvalue of a
+    Hermitian problem inside [a, b], ascending, by a sweep of shift-invert solves.  Without ALL the interval has no effect,
+    as in SLEPc; for non-Hermitian problem types ALL is an error, as in SLEPc."""
+    import json
+    from pathlib import Path
+
+    from oracle import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import iEpsProblemType, iEpsWhich
 
-    A = np.diag([1.0, 2.0, 3.0, 4.0, 5.0])
+    A = np.diag(np.arange(1.0, 41.0)) + 0.01 * (np.eye(40, k=1) + np.eye(40, k=-1))
+    exact = np.linalg.eigvalsh(A)
     solver = EigenSolver(A, None, EigensolverConfig(problem_type=iEpsProblemType.HEP, num_eig=2, atol=1e-10))
-    solver.solver.set_interval(1.5, 3.5)
+    solver.solver.set_interval(7.5, 19.5)
     lam = sorted(ev for ev, _ in solver.solve())  # interval without ALL: no effect (largest magnitude by default)
-    assert np.allclose(lam, [4.0, 5.0], atol=1e-8)
+    assert np.allclose(lam, exact[-2:], atol=1e-8)
     solver.solver.set_which_eigenpairs(iEpsWhich.ALL)
-    with pytest.raises(NotImplementedError, match="spectrum slicing"):
-        solver.solve()
+    solver.solver.solve()
+    got = np.array([solver.solver.get_eigenvalue(i) for i in range(solver.solver.get_num_converged())])
+    want = exact[(exact >= 7.5) & (exact <= 19.5)]
+    assert len(got) == len(want) == 12 and np.allclose(got, want, atol=1e-8) and np.all(np.diff(got) > 0)
+    for i in range(len(got)):  # eigenvectors come with the values
+        v = solver.solver.get_eigenvector_array(i)
+        assert np.linalg.norm(A @ v - got[i] * v) <= 1e-7
+    # the membrane pair of the reference's benchmark: the four modes below 11.5 (3.084, 4.935, 8.019, 10.49), lambda = 1 of
+    # the Dirichlet rows excluded by the interval
+    ref = json.loads((Path(__file__).parent / "golden" / "reference_known_answers.json").read_text())["membrane_32x32_p2"]
+    Am, Mm, _ = fem.assemble_membrane(32, 32, *ref["domain"])
+    ms = EigenSolver(Am, Mm, EigensolverConfig(problem_type=iEpsProblemType.GHEP, num_eig=4, atol=1e-9), check_hermitian=False)
+    ms.solver.set_interval(2.0, 11.5)
+    ms.solver.set_which_eigenpairs(iEpsWhich.ALL)
+    ms.solver.solve()
+    gm = np.array([ms.solver.get_eigenvalue(i) for i in range(ms.solver.get_num_converged())])
+    assert len(gm) == 4 and np.allclose(gm[:3], ref["published"], atol=5e-7)
+    assert abs(gm[3] - fem.membrane_analytic(4)[3]) <= 2e-3
+    # not Hermitian: refused like SLEPc; no interval: refused
+    bad = EigenSolver(A + np.triu(np.ones((40, 40)), 2), None, EigensolverConfig(problem_type=iEpsProblemType.NHEP, num_eig=2, atol=1e-8))
+    bad.solver.set_interval(1.0, 2.0)
+    bad.solver.set_which_eigenpairs(iEpsWhich.ALL)
+    with pytest.raises(ValueError, match="Hermitian"):
+        bad.solver.solve()
+    noint = EigenSolver(A, None, EigensolverConfig(problem_type=iEpsProblemType.HEP, num_eig=2, atol=1e-8))
+    noint.solver.set_which_eigenpairs(iEpsWhich.ALL)
+    with pytest.raises(ValueError, match="interval"):
+        noint.solver.solve()
+
+
+def test_which_policies_without_a_target():
+    """Every EPSWhich ordering of the reference's enum (Solver/utils.py:152-187) on a small non-normal matrix, plain SHIFT
+    transformation: the returned pairs are the extreme ones in that ordering."""
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import iEpsWhich
+
+    rng = np.random.default_rng(8)
+    n = 60
+    lam_true = np.concatenate([np.linspace(-3, 3, 30) + 1j * np.linspace(-2, 5, 30), 0.3 * (rng.standard_normal(30) + 1j * rng.standard_normal(30))])
+    X = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    A = X @ np.diag(lam_true) @ np.linalg.inv(X)
+    keys = {iEpsWhich.LARGEST_MAGNITUDE: lambda z: -abs(z), iEpsWhich.LARGEST_REAL: lambda z: -z.real, iEpsWhich.SMALLEST_REAL: lambda z: z.real,
+            iEpsWhich.LARGEST_IMAGINARY: lambda z: -z.imag, iEpsWhich.SMALLEST_IMAGINARY: lambda z: z.imag}
+    for which, key in keys.items():
+        s = EigenSolver(A, None, EigensolverConfig(num_eig=3, atol=1e-10, ncv=40, max_it=2000), check_hermitian=False)
+        s.solver.set_which_eigenpairs(which)
+        got = np.array([ev for ev, _ in s.solve()][:3])
+        want = sorted(lam_true, key=key)[:3]
+        for w in want:
+            assert np.min(np.abs(got - w)) <= 1e-7 * max(1.0, abs(w)), (which, w, got)
+    # the target orderings under shift-invert
+    for which, dist in ((iEpsWhich.TARGET_REAL, lambda z, t: abs(z.real - t.real)), (iEpsWhich.TARGET_IMAGINARY, lambda z, t: abs(z.imag - t.imag))):
+        from Solver.utils import iSTType
+
+        t = 1.1 + 2.2j
+        s = EigenSolver(A, None, EigensolverConfig(num_eig=2, atol=1e-10, ncv=50, max_it=2000), check_hermitian=False)
+        s.solver.set_st_type(iSTType.SINVERT)
+        s.solver.set_target(t)
+        s.solver.set_which_eigenpairs(which)
+        got = np.array([ev for ev, _ in s.solve()])
+        conv = np.array([lam_true[np.argmin(abs(lam_true - g))] for g in got])
+        assert np.all(abs(conv - got) <= 1e-7)  # every returned value is an eigenvalue ...
+        d = np.array([dist(g, t) for g in got])
+        assert np.all(np.diff(d) >= -1e-9)  # ... returned in the requested order

@@ -258,6 +258,9 @@ int lsa_op_set_projection(lsa_ctx *ctx, lsa_op *op, const double *keep);
 /* Basis of up to ncv+1 complex vectors of length n, resident in HBM, column-major. */
 int lsa_krylov_create(lsa_ctx *ctx, lsa_op *op, int32_t ncv, lsa_krylov **out);
 void lsa_krylov_destroy(lsa_krylov *k);
+/* perm[i] = the caller's index of row i of the basis (the solve runs in a permuted numbering): lsa_krylov_ritz_vectors then
+ * returns its vectors in the caller's numbering, rows scattered on the device.  NULL removes it. */
+int lsa_krylov_set_row_permutation(lsa_ctx *ctx, lsa_krylov *k, const int32_t *perm);
 /* v_0 = v / ||v||  (host complex vector of length n) */
 int lsa_krylov_set_start(lsa_ctx *ctx, lsa_krylov *k, const void *host_v);
 /* v_j = host vector orthonormalised (CGS2) against v_0..v_{j-1}: used to continue after an exact breakdown

@@ -29,6 +29,13 @@ class iPETScVector:
         self._a = np.array(data, copy=True).ravel()
 
     @classmethod
+    def _adopt(cls, data: np.ndarray) -> "iPETScVector":
+        """Wrap an array the caller hands over (no copy; may be a strided view of memory nobody else writes)."""
+        out = cls.__new__(cls)
+        out._a = data.reshape(-1)
+        return out
+
+    @classmethod
     def from_array(cls, data: np.ndarray) -> "iPETScVector":
         return cls(np.asarray(data))
 

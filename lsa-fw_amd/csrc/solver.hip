@@ -339,6 +339,13 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, PcRef pc, int dtype, const void* b
     return LSA_OK;
 }
 
+// out[perm[i], c] = in[i, c]  (column-major n x ncols; grid.y = column)
+__global__ void scatter_rows_kernel(int64_t n, const int32_t* __restrict__ perm, const cplx* __restrict__ in, cplx* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const size_t off = (size_t)blockIdx.y * (size_t)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[off + (size_t)perm[i]] = in[off + (size_t)i];
+}
+
 template <typename T>
 __global__ void shift_diag_kernel(int32_t n, int32_t row0, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                   T* __restrict__ val, cplx shift, int32_t* __restrict__ missing) {
@@ -400,6 +407,7 @@ struct lsa_krylov {
     lsa_op* op;
     int64_t n;
     int32_t ncv;
+    int32_t* row_perm = nullptr;  // device: row i of the basis is unknown row_perm[i] of the caller (lsa_krylov_set_row_permutation)
     void *V, *V2, *w, *qdev;
     OrthWork ow;
     std::vector<zc> hcol;
@@ -725,10 +733,27 @@ int lsa_krylov_create(lsa_ctx* ctx, lsa_op* op, int32_t ncv, lsa_krylov** out) {
 void lsa_krylov_destroy(lsa_krylov* k) {
     if (!k) return;
     if (k->ctx && k->ctx->stream) (void)hipStreamSynchronize(k->ctx->stream);
+    if (k->row_perm) (void)hipFree(k->row_perm);
     for (void* p : {k->V, k->V2, k->w, k->qdev})
         if (p) (void)hipFree(p);
     k->ow.release();
     delete k;
+}
+
+int lsa_krylov_set_row_permutation(lsa_ctx* ctx, lsa_krylov* k, const int32_t* perm) {
+    if (!ctx || !k) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_set_row_permutation: null argument");
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (k->row_perm) (void)hipFree(k->row_perm);
+    k->row_perm = nullptr;
+    if (!perm) return LSA_OK;
+    std::vector<char> seen((size_t)k->n, 0);
+    for (int64_t i = 0; i < k->n; ++i) {
+        if (perm[i] < 0 || perm[i] >= k->n || seen[(size_t)perm[i]]) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_set_row_permutation: not a permutation of 0..n-1");
+        seen[(size_t)perm[i]] = 1;
+    }
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&k->row_perm, sizeof(int32_t) * (size_t)std::max<int64_t>(k->n, 1)));
+    LSA_HIP_CHECK(ctx, hipMemcpy(k->row_perm, perm, sizeof(int32_t) * (size_t)k->n, hipMemcpyHostToDevice));
+    return LSA_OK;
 }
 
 int lsa_krylov_set_start(lsa_ctx* ctx, lsa_krylov* k, const void* host_v) {
@@ -826,8 +851,18 @@ int lsa_krylov_ritz_vectors(lsa_ctx* ctx, lsa_krylov* k, int32_t m, int32_t nvec
             LSA_CHECK(k_scale_by_inv_norm(ctx, LSA_C128, k->n, k->w, k->ow.nrm2, col));
         }
     }
-    LSA_HIP_CHECK(ctx, hipMemcpyAsync(X, k->V2, vb * (size_t)nvec, hipMemcpyDeviceToHost, ctx->stream));
-    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    const void* src = k->V2;
+    void* tmp = nullptr;
+    if (k->row_perm) {  // rows back into the caller's numbering on the device (a fancy-indexed scatter of n x nvec on the host costs more than the solve's Schur forms)
+        LSA_HIP_ALLOC(ctx, hipMalloc(&tmp, vb * (size_t)nvec));
+        const int blocks = (int)std::min<int64_t>((k->n + 255) / 256, (int64_t)ctx->num_cu * 16);
+        hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks, nvec), dim3(256), 0, ctx->stream, k->n, k->row_perm, (const cplx*)k->V2, (cplx*)tmp);
+        src = tmp;
+    }
+    hipError_t e = hipMemcpyAsync(X, src, vb * (size_t)nvec, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (tmp) (void)hipFree(tmp);
+    if (e != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_krylov_ritz_vectors: download failed: %s", hipGetErrorString(e));
     return LSA_OK;
 }
 

@@ -134,6 +134,7 @@ SIGNATURES = {
     "lsa_op_set_projection": (ctypes.c_int, [_P, _P, _P]),
     "lsa_krylov_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
     "lsa_krylov_destroy": (None, [_P]),
+    "lsa_krylov_set_row_permutation": (ctypes.c_int, [_P, _P, _P]),
     "lsa_krylov_set_start": (ctypes.c_int, [_P, _P, _P]),
     "lsa_krylov_inject": (ctypes.c_int, [_P, _P, _I32, _P]),
     "lsa_krylov_extend": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32, ctypes.POINTER(_I32)]),
@@ -704,6 +705,11 @@ class KrylovBasis:
         h = ctypes.c_void_p()
         ctx.check(ctx._lib.lsa_krylov_create(ctx.handle, op.handle, self.ncv, ctypes.byref(h)))
         self.handle = h
+
+    def set_row_permutation(self, perm: np.ndarray | None) -> None:
+        """``perm[i]`` = the caller's index of basis row ``i``: Ritz vectors then come back in the caller's numbering."""
+        p = None if perm is None else np.ascontiguousarray(perm, dtype=np.int32)
+        self.ctx.check(self.ctx._lib.lsa_krylov_set_row_permutation(self.ctx.handle, self.handle, None if p is None else _ptr(p)))
 
     def inject(self, j: int, v: np.ndarray) -> None:
         v = np.ascontiguousarray(v, dtype=np.complex128)

@@ -8,6 +8,7 @@
 // vertices of the middle level that touch the next one.
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -626,6 +627,71 @@ int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_siz
             L.resize(keepn);
         }
         for (int32_t t = 0; t < nt; ++t) own[(size_t)t].insert(own[(size_t)t].end(), moved[(size_t)t].begin(), moved[(size_t)t].end());
+    }
+    // The top of the forest is a chain of small pivot blocks, one dependent launch per level and sweep in the solve (6.6 us
+    // each on this part) for a few hundred KB of data.  The levels under each root are merged into the root, top down, while
+    // the merged pivot block stays below `top_limit` unknowns: one dense block whose inverse is applied in a single launch
+    // (and has no boundary: nothing to do in the downward sweep) instead of 2 x (levels) launches.  It costs a longer
+    // Gauss-Jordan chain in the factorisation.  Measured at 30 k unknowns with a limit of 1100: 23 -> 19 launches, the solve
+    // 151 -> 140 us, the factorisation 8.1 -> 18.6 ms (the 980-row pivot block's panels take 85 us each): a loss, so the
+    // default is off; LSA_ND_TOP=<unknowns> turns it on.
+    int32_t top_limit = 0;  // off: the longer Gauss-Jordan chain costs more than the launches it saves (S30k: + 10 ms per factorisation for - 11 us per solve)
+    if (const char* e = getenv("LSA_ND_TOP")) top_limit = atoi(e);
+    if (top_limit > 0 && nt > 1) {
+        std::vector<std::vector<int32_t>> kids((size_t)nt);
+        std::vector<int32_t> height((size_t)nt, 0);
+        for (int32_t t = nt - 1; t >= 0; --t)  // parents are created before their children
+            if (par[(size_t)t] >= 0) {
+                kids[(size_t)par[(size_t)t]].push_back(t);
+                height[(size_t)par[(size_t)t]] = std::max(height[(size_t)par[(size_t)t]], height[(size_t)t] + 1);
+            }
+        std::vector<int32_t> into((size_t)nt, -1);  // node -> the root it is merged into
+        for (int32_t r = 0; r < nt; ++r) {
+            if (par[(size_t)r] >= 0) continue;
+            int64_t cum = (int64_t)own[(size_t)r].size();
+            std::vector<int32_t> layer{r};
+            while (true) {
+                std::vector<int32_t> next;
+                int64_t add = 0;
+                for (int32_t t : layer)
+                    for (int32_t c : kids[(size_t)t])
+                        if (!kids[(size_t)c].empty()) {  // leaves stay: they carry the bulk of the unknowns
+                            next.push_back(c);
+                            add += (int64_t)own[(size_t)c].size();
+                        }
+                if (next.empty() || cum + add > top_limit) break;
+                for (int32_t c : next) into[(size_t)c] = r;
+                cum += add;
+                layer.swap(next);
+            }
+        }
+        bool any = false;
+        for (int32_t t = 0; t < nt; ++t) any |= into[(size_t)t] >= 0;
+        if (any) {
+            // merged nodes hand their unknowns to the root (deeper nodes first: the order inside one pivot block is free) and
+            // their remaining children to it
+            for (int32_t t = nt - 1; t >= 0; --t)
+                if (into[(size_t)t] >= 0) {
+                    std::vector<int32_t>& dst = own[(size_t)into[(size_t)t]];
+                    dst.insert(dst.begin(), own[(size_t)t].begin(), own[(size_t)t].end());
+                    own[(size_t)t].clear();
+                }
+            std::vector<int32_t> remap((size_t)nt, -1);
+            std::vector<std::vector<int32_t>> own2;
+            std::vector<int32_t> par2;
+            for (int32_t t = 0; t < nt; ++t)
+                if (into[(size_t)t] < 0) {
+                    remap[(size_t)t] = (int32_t)own2.size();
+                    own2.push_back(std::move(own[(size_t)t]));
+                    int32_t p = par[(size_t)t];
+                    while (p >= 0 && into[(size_t)p] >= 0) p = into[(size_t)p];
+                    par2.push_back(p);  // still an old id: parents precede children, so remap[p] is known
+                }
+            for (int32_t& p : par2)
+                if (p >= 0) p = remap[(size_t)p];
+            own.swap(own2);
+            par.swap(par2);
+        }
     }
     return nd_finish(S, n, rp, ci, g, own, par, nullptr, 0, 1, fail);
 }

@@ -130,9 +130,10 @@ __device__ __forceinline__ unsigned long long pivot_key(double mag2, int32_t row
 template <typename T, int NT, int RPT>
 __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
                                                          T* __restrict__ front, int32_t* __restrict__ ipiv, int32_t* __restrict__ rowq,
-                                                         int32_t k0, int32_t* __restrict__ flag, double tiny2) {
+                                                         int32_t k0, int32_t* __restrict__ flag, double tiny2, T* __restrict__ ybuf) {
     __shared__ unsigned long long skey[kW];
     __shared__ T prow_s[2][kW];
+    __shared__ int32_t prows[kW];
     const int32_t t = lvl_nodes[blockIdx.x];
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, ld = nd.f;
@@ -171,6 +172,7 @@ __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restri
         const int32_t p = 65535 - (int32_t)(key & 0xFFFFull);
         if (tid == 0) {
             piv[k0 + jj] = p;
+            prows[jj] = p;
             if (!(__longlong_as_double((long long)(key & ~0xFFFFull)) > tiny2) && atomicCAS(&flag[1], 0, t + 1) == 0) {
                 flag[2] = k0 + jj;
                 flag[3] = (int32_t)(key >> 32);  // high word of |pivot|^2
@@ -217,15 +219,24 @@ __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restri
                 if (j < w) a[(size_t)i * ld + k0 + j] = r[q][j];
         }
     }
+    // the pivot rows' values in the other columns (untouched so far), staged for the update launch: its workgroups may then
+    // split the rows among themselves (the owner of a pivot row overwrites it while the others still need its old values)
+    __syncthreads();
+    T* yb = ybuf + (size_t)kW * nd.piv_off;
+    for (int32_t e = tid; e < w * m; e += NT) {
+        const int32_t j = e / m, c = e - j * m;
+        yb[(size_t)j * m + c] = a[(size_t)prows[j] * ld + c];
+    }
 }
 
 // the same elimination for pivot blocks of more than 2048 rows: the panel stays in memory (L2), rows are walked
 template <typename T>
 __global__ __launch_bounds__(1024) void nd_gj_panel_big_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
                                                                T* __restrict__ front, int32_t* __restrict__ ipiv, int32_t* __restrict__ rowq,
-                                                               int32_t k0, int32_t* __restrict__ flag, double tiny2) {
+                                                               int32_t k0, int32_t* __restrict__ flag, double tiny2, T* __restrict__ ybuf) {
     __shared__ unsigned long long skey[kW];
     __shared__ T prow_s[kW];
+    __shared__ int32_t prows[kW];
     const int32_t t = lvl_nodes[blockIdx.x];
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, ld = nd.f;
@@ -251,6 +262,7 @@ __global__ __launch_bounds__(1024) void nd_gj_panel_big_kernel(const int32_t* __
         const int32_t p = 65535 - (int32_t)(key & 0xFFFFull);
         if (tid == 0) {
             piv[k0 + jj] = p;
+            prows[jj] = p;
             if (!(__longlong_as_double((long long)(key & ~0xFFFFull)) > tiny2) && atomicCAS(&flag[1], 0, t + 1) == 0) {
                 flag[2] = k0 + jj;
                 flag[3] = (int32_t)(key >> 32);
@@ -285,16 +297,23 @@ __global__ __launch_bounds__(1024) void nd_gj_panel_big_kernel(const int32_t* __
         }
         __syncthreads();
     }
+    T* yb = ybuf + (size_t)kW * nd.piv_off;
+    for (int32_t e = tid; e < w * m; e += 1024) {
+        const int32_t j = e / m, c = e - j * m;
+        yb[(size_t)j * m + c] = a[(size_t)prows[j] * ld + c];
+    }
 }
 
 // rank-w update of the columns outside the panel: A[i, J] = (i is one of the panel's pivot rows ? 0 : A[i, J]) + W[i, :] Y,
-// Y = the pivot rows' old values in J, W = the eliminated panel.  A workgroup owns kUpdCols columns for all rows.
+// Y = the pivot rows' old values in J (staged by the panel launch), W = the eliminated panel.  A workgroup owns kUpdCols
+// columns x kUpdRows rows: large pivot blocks (the top of a 2D forest, every upper level of a 3D one) get enough workgroups.
+constexpr int kUpdRows = 256;
 template <typename T>
 __global__ __launch_bounds__(256) void nd_gj_update_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
-                                                           T* __restrict__ front, const int32_t* __restrict__ ipiv, int32_t k0) {
-    __shared__ T Y[kW][kUpdCols];
-    __shared__ int32_t prow_s[kW];
-    const int32_t t = tiles[2 * blockIdx.x], c0 = tiles[2 * blockIdx.x + 1];
+                                                           T* __restrict__ front, const int32_t* __restrict__ ipiv, int32_t k0,
+                                                           const T* __restrict__ ybuf) {
+    const int32_t t = tiles[2 * blockIdx.x], packed = tiles[2 * blockIdx.x + 1];
+    const int32_t c0 = (packed & 0xFFFF) * kUpdCols, r0 = (packed >> 16) * kUpdRows;
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, ld = nd.f;
     const int32_t w = min(kW, m - k0);
@@ -302,25 +321,18 @@ __global__ __launch_bounds__(256) void nd_gj_update_kernel(const int32_t* __rest
     T* a = front + nd.front_off;
     const int tid = threadIdx.x;
     const int32_t c = c0 + (tid & 15);
-    const bool live = c < m && (c < k0 || c >= k0 + w);
-    if (tid < kW) prow_s[tid] = tid < w ? ipiv[nd.piv_off + k0 + tid] : -1;
-    __syncthreads();
-    if (tid < kW * kUpdCols) {
-        const int j = tid >> 4;
-        if (j < w && live) Y[j][tid & 15] = a[(size_t)prow_s[j] * ld + c];
-        else Y[j][tid & 15] = scalar_traits<T>::zero();
-    }
-    __syncthreads();
+    if (!(c < m && (c < k0 || c >= k0 + w))) return;
+    const T* yb = ybuf + (size_t)kW * nd.piv_off;
     int32_t pr[kW];
     T y[kW];
 #pragma unroll
     for (int j = 0; j < kW; ++j) {
-        pr[j] = prow_s[j];
-        y[j] = Y[j][tid & 15];
+        pr[j] = j < w ? ipiv[nd.piv_off + k0 + j] : -1;
+        y[j] = j < w ? yb[(size_t)j * m + c] : scalar_traits<T>::zero();
     }
-    if (!live) return;
+    const int32_t r1 = min(m, r0 + kUpdRows);
 #pragma unroll 4
-    for (int32_t i = tid >> 4; i < m; i += 16) {
+    for (int32_t i = r0 + (tid >> 4); i < r1; i += 16) {
         T* ai = a + (size_t)i * ld;
         bool is_piv = false;
 #pragma unroll
@@ -652,7 +664,7 @@ struct lsa_ndlu {
     int32_t* d_asm_src = nullptr;
     int32_t *d_ipiv = nullptr, *d_rowq = nullptr, *d_flag = nullptr, *d_xflag = nullptr;
     unsigned long long* d_maxabs = nullptr;
-    void *d_front = nullptr, *d_scratch = nullptr, *d_ubuf = nullptr, *d_tmp = nullptr;
+    void *d_front = nullptr, *d_scratch = nullptr, *d_ubuf = nullptr, *d_tmp = nullptr, *d_ybuf = nullptr;
     double seconds_analyse = 0.0, seconds_numeric = 0.0;
     int32_t solve_launches = 0;
 };
@@ -663,7 +675,7 @@ void nd_free(lsa_ndlu* f) {
     if (!f) return;
     for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
                     (void*)f->d_lvl_nodes, (void*)f->d_asm_dst, (void*)f->d_asm_src, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_xflag, (void*)f->d_maxabs,
-                    f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp})
+                    f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp, f->d_ybuf})
         if (p) (void)hipFree(p);
     delete f;
 }
@@ -743,7 +755,8 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         L.upd_tile_prefix.assign(1, 0);
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            for (int32_t c0 = 0; c0 < S.m[(size_t)t]; c0 += kUpdCols) push(L.upd, t, c0);
+            for (int32_t r0 = 0; r0 < S.m[(size_t)t]; r0 += kUpdRows)
+                for (int32_t c0 = 0; c0 < S.m[(size_t)t]; c0 += kUpdCols) push(L.upd, t, (c0 / kUpdCols) | ((r0 / kUpdRows) << 16));
             L.upd_tile_prefix.push_back(L.upd.count);
         }
         begin_list(L.unperm);
@@ -800,6 +813,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_scratch, (size_t)max_scratch * es));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ubuf, (size_t)std::max<int64_t>(S.u_off[(size_t)nt], 1) * 16));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_tmp, nn * 16));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ybuf, nn * kW * es));
     f->solve_launches = 0;
     for (const NdLevel& L : f->levels) f->solve_launches += (L.fwd_tiles > 0) + (L.bwd_tiles > 0);
     return LSA_OK;
@@ -808,7 +822,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
 template <typename T, int NT, int RPT>
 void launch_panel(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t active, int32_t k0, double tiny2) {
     hipLaunchKernelGGL((nd_gj_panel_kernel<T, NT, RPT>), dim3(active), dim3(NT), 0, ctx->stream, f->d_lvl_nodes + L.node_begin, f->d_nodes,
-                       (T*)f->d_front, f->d_ipiv, f->d_rowq, k0, f->d_flag, tiny2);
+                       (T*)f->d_front, f->d_ipiv, f->d_rowq, k0, f->d_flag, tiny2, (T*)f->d_ybuf);
 }
 
 template <typename T>
@@ -857,10 +871,11 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
             else if (L.max_m <= 2048) launch_panel<T, 1024, 2>(ctx, f, L, active, k0, tiny2);
             else
                 hipLaunchKernelGGL((nd_gj_panel_big_kernel<T>), dim3(active), dim3(1024), 0, st, f->d_lvl_nodes + L.node_begin, f->d_nodes, front,
-                                   f->d_ipiv, f->d_rowq, k0, f->d_flag, tiny2);
+                                   f->d_ipiv, f->d_rowq, k0, f->d_flag, tiny2, (T*)f->d_ybuf);
             const int32_t utiles = L.upd_tile_prefix[(size_t)active];
             if (utiles > 0 && L.max_m > kW)
-                hipLaunchKernelGGL((nd_gj_update_kernel<T>), dim3(utiles), dim3(256), 0, st, tl + 2 * L.upd.off, f->d_nodes, front, f->d_ipiv, k0);
+                hipLaunchKernelGGL((nd_gj_update_kernel<T>), dim3(utiles), dim3(256), 0, st, tl + 2 * L.upd.off, f->d_nodes, front, f->d_ipiv, k0,
+                                   (const T*)f->d_ybuf);
         }
         if (L.unperm.count > 0)
             hipLaunchKernelGGL((nd_unperm_kernel<T>), dim3(L.unperm.count), dim3(256), 0, st, tl + 2 * L.unperm.off, f->d_nodes, front, f->d_ipiv,

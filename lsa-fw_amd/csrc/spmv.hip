@@ -5,6 +5,8 @@
 // column/value loads of a row are contiguous across lanes (coalesced HBM row reads) and the gathers of x
 // hit L2 / Infinity Cache (FEM rows after RCM reference a narrow band of x).  Partial sums are combined
 // with DPP/shuffle butterflies inside the sub-wave.  LPR is picked from the mean row length.
+#include <algorithm>
+
 #include "lsa_internal.h"
 
 template <typename T>
@@ -143,7 +145,7 @@ __global__ __launch_bounds__(256) void spmv_subwave16_kernel(int32_t n, const in
 // over workgroups every XCD gathers the whole of x; here workgroup b takes the contiguous chunk of groups number
 // (b % 8) * (G / 8) + b / 8, so an XCD walks one eighth of the rows and touches one eighth of x (plus the band).
 template <typename MT, typename VT, int LPR, bool C16, bool XCD>
-__global__ __launch_bounds__(256) void spmv_group_kernel(int32_t ngroups, int32_t chunk, const int32_t* __restrict__ gstart,
+__global__ __launch_bounds__(256) void spmv_group_kernel(int32_t ngroups, int32_t chunk, const int2* __restrict__ gstart,
                                                          const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                          const uint16_t* __restrict__ ci16, const int32_t* __restrict__ cbase,
                                                          const MT* __restrict__ val, const VT* __restrict__ x, VT* __restrict__ y) {
@@ -157,7 +159,8 @@ __global__ __launch_bounds__(256) void spmv_group_kernel(int32_t ngroups, int32_
         gend = min((int64_t)ngroups, (vb + 1) * chunk);
     }
     for (; grp < gend; grp += stride) {
-        const int32_t r0 = gstart[grp], g = gstart[grp + 1] - r0;
+        const int2 gr = gstart[grp];
+        const int32_t r0 = gr.x, g = gr.y;
         const int32_t p0 = rp[r0], len = rp[r0 + 1] - p0;
         const VT* xr = x;
         if constexpr (C16) xr += cbase[r0];
@@ -213,6 +216,21 @@ static bool ensure_groups(const lsa_mat* A) {
     gs.push_back(n);
     const int32_t ng = (int32_t)gs.size() - 1;
     if ((double)n / (double)ng < 1.5) return false;
+    // (first row, rows) per group; optionally ordered by row length (LSA_SPMV_SORT=1): the four sub-waves of a wavefront then
+    // walk rows of one length instead of waiting for the longest of four
+    std::vector<int32_t> pairs((size_t)ng * 2);
+    std::vector<int32_t> order((size_t)ng);
+    for (int32_t q = 0; q < ng; ++q) order[(size_t)q] = q;
+    if (const char* e = getenv("LSA_SPMV_SORT"))
+        if (atoi(e) != 0)
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) {
+                return A->h_rp[(size_t)gs[(size_t)x] + 1] - A->h_rp[gs[(size_t)x]] > A->h_rp[(size_t)gs[(size_t)y] + 1] - A->h_rp[gs[(size_t)y]];
+            });
+    for (int32_t q = 0; q < ng; ++q) {
+        pairs[(size_t)2 * q] = gs[(size_t)order[(size_t)q]];
+        pairs[(size_t)2 * q + 1] = gs[(size_t)order[(size_t)q] + 1] - gs[(size_t)order[(size_t)q]];
+    }
+    gs.swap(pairs);
     if (hipMalloc((void**)&A->grp_start, gs.size() * sizeof(int32_t)) != hipSuccess) return false;
     if (hipMemcpy(A->grp_start, gs.data(), gs.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) {
         (void)hipFree(A->grp_start);
@@ -313,15 +331,15 @@ static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, 
         if ((variant & 0x8000) && !c16 && A->ngroups >= 8 * 64) {
             const int G = ((gblocks + 7) / 8) * 8;
             const int32_t chunk = (A->ngroups + G - 1) / G;
-            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false, true>), dim3(G), dim3(threads), 0, ctx->stream, A->ngroups, chunk, A->grp_start, A->rp,
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false, true>), dim3(G), dim3(threads), 0, ctx->stream, A->ngroups, chunk, (const int2*)A->grp_start, A->rp,
                                A->ci, (const uint16_t*)nullptr, (const int32_t*)nullptr, (const MT*)A->val, (const VT*)x, (VT*)y);
             return;
         }
         if (c16)
-            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, true, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, 0, A->grp_start, A->rp,
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, true, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, 0, (const int2*)A->grp_start, A->rp,
                                A->ci, (const uint16_t*)A->ci16, (const int32_t*)A->cbase, (const MT*)A->val, (const VT*)x, (VT*)y);
         else
-            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, 0, A->grp_start, A->rp,
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, 0, (const int2*)A->grp_start, A->rp,
                                A->ci, (const uint16_t*)nullptr, (const int32_t*)nullptr, (const MT*)A->val, (const VT*)x, (VT*)y);
         return;
     }

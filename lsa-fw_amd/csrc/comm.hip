@@ -30,11 +30,16 @@ Rccl& rccl() {
     static Rccl r;
     if (r.handle || !r.why.empty()) return r;
     const char* env = getenv("LSA_RCCL_PATH");
-    const char* candidates[] = {env, "/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
+    if (env && *env) r.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+    // an RCCL the process has loaded already (PyTorch's, when the launcher runs the nccl backend) is used as it is: one
+    // runtime per process, a second communicator inside it; otherwise ROCm's own copy is opened
+    const char* loaded[] = {"librccl.so", "librccl.so.1"};
+    for (const char* c : loaded)
+        if (!r.handle) r.handle = dlopen(c, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+    const char* candidates[] = {"/opt/rocm/lib/librccl.so.1", "librccl.so.1", "librccl.so"};
     for (const char* c : candidates) {
-        if (!c || !*c) continue;
-        r.handle = dlopen(c, RTLD_NOW | RTLD_LOCAL);
         if (r.handle) break;
+        r.handle = dlopen(c, RTLD_NOW | RTLD_LOCAL);
     }
     if (!r.handle) {
         r.why = "librccl.so not found (set LSA_RCCL_PATH)";

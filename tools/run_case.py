@@ -18,14 +18,16 @@ ap.add_argument("--pc", default="lu")
 ap.add_argument("--k", type=int, default=20)
 ap.add_argument("--atol", type=float, default=1e-10)
 ap.add_argument("--levels", type=int, default=2)
+ap.add_argument("--ncv", type=int, default=80)
 args = ap.parse_args()
 t0 = time.time()
-es = fem.cylinder_case(args.case)
+es = fem.cube_case(args.case) if args.case.startswith("C") else fem.cylinder_case(args.case)
+sigma = fem.SIGMA_CUBE if args.case.startswith("C") else fem.SIGMA_RE50
 print(f"{args.case}: n={es.n} nnz={es.A.nnz} assembled in {time.time() - t0:.1f}s", flush=True)
 kw = {"ilu_levels": args.levels} if args.pc == "ilu" else {}
-s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=args.k, atol=args.atol, ncv=80), check_hermitian=False, **kw)
+s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=args.k, atol=args.atol, ncv=args.ncv), check_hermitian=False, **kw)
 s.solver.set_st_type(iSTType.SINVERT)
-s.solver.set_target(fem.SIGMA_RE50)
+s.solver.set_target(sigma)
 s.solver.set_st_pc_type(PreconditionerType.LU if args.pc == "lu" else PreconditionerType.ILU)
 t0 = time.time()
 s.solver.prepare()

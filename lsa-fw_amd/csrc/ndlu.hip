@@ -31,8 +31,6 @@ int k_allgather_inplace(lsa_ctx* ctx, void* vec, size_t bytes_per_rank);  // com
 
 namespace {
 
-constexpr int kW = 8;        // pivot columns per panel
-constexpr int kUpdCols = 16; // columns of one update tile
 constexpr int kRT = 32;      // front rows per solve tile
 constexpr int kCH = 1024;    // vector entries staged in LDS per pass of a solve tile
 constexpr int kGT = 64;      // GEMM tile edge
@@ -62,8 +60,7 @@ struct TileList {
 struct NdLevel {
     int32_t node_begin = 0, node_count = 0, max_m = 0, max_f = 0;
     std::vector<int32_t> sorted_m;          // own sizes of the level's nodes (descending)
-    std::vector<int32_t> upd_tile_prefix;   // update tiles of the first k nodes
-    TileList upd, unperm, gemm[3], copyback;
+    TileList unperm, gemm[3], copyback;
     int32_t fwd_tiles = 0, bwd_tiles = 0;  // grid.y of the sweep kernels: tiles of the tallest node (0 = nothing to do)
     std::vector<TileList> ext;  // one per child rank
     int64_t scratch = 0;
@@ -124,38 +121,48 @@ __device__ __forceinline__ unsigned long long pivot_key(double mag2, int32_t row
     return ((unsigned long long)__double_as_longlong(mag2) & ~0xFFFFull) | (unsigned long long)(65535 - row);
 }
 
-// Gauss-Jordan elimination of panel p (columns [k0, k0 + w)) of the pivot blocks of a level: one workgroup per node,
-// thread per row (RPT rows per thread), the panel's columns in registers.  Rows are not interchanged: a row that has
-// served as a pivot is excluded from later searches (rowq), the permutation is undone by nd_unperm_kernel.
-template <typename T, int NT, int RPT>
+// ---- blocked Gauss-Jordan inversion of the pivot blocks of a level ---------------------------------------------------------
+// Columns are eliminated in blocks of kNB; inside a block in panels of W columns (W = 8 for pivot blocks of up to 2048 rows,
+// narrower for taller ones so that a thread's rows of the panel stay in registers).  Rows are never interchanged: a row
+// that has served as a pivot is excluded from later searches (rowq), the permutation is undone by nd_unperm_kernel.
+//   panel launch    one workgroup per node, thread per row (RPT rows per thread): eliminates the panel's W columns and
+//                   stages the pivot rows' values in the other columns OF THE BLOCK;
+//   block update    rank-W update of the block's other columns (16 columns x 256 rows per workgroup);
+//   after the block the pivot rows' values in all other columns are staged (nd_gj_stage_kernel) and one rank-kNB product
+//                   A[:, J] = (pivot row ? 0 : A[:, J]) + Wb Yb  updates the rest (nd_gj_gemm_kernel, 64 x 64 tiles):
+// the columns outside a block are touched once per kNB pivots instead of once per 8 (the update of a 6 000-row pivot block
+// streamed 1.1 GB per 8 pivots, and its panel did not fit the registers of one workgroup at W = 8).
+constexpr int kNB = 32;
+
+template <typename T, int NT, int RPT, int W>
 __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
                                                          T* __restrict__ front, int32_t* __restrict__ ipiv, int32_t* __restrict__ rowq,
-                                                         int32_t k0, int32_t* __restrict__ flag, double tiny2, T* __restrict__ ybuf) {
-    __shared__ unsigned long long skey[kW];
-    __shared__ T prow_s[2][kW];
-    __shared__ int32_t prows[kW];
+                                                         int32_t kb, int32_t k0, int32_t* __restrict__ flag, double tiny2, T* __restrict__ ysm) {
+    __shared__ unsigned long long skey[W];
+    __shared__ T prow_s[2][W];
+    __shared__ int32_t prows[W];
     const int32_t t = lvl_nodes[blockIdx.x];
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, ld = nd.f;
-    const int32_t w = min(kW, m - k0);
+    const int32_t w = min(W, m - k0);
     if (w <= 0) return;
     T* a = front + nd.front_off;
     int32_t* piv = ipiv + nd.piv_off;
     int32_t* rq = rowq + nd.piv_off;
     const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < kW) skey[tid] = 0ull;
-    T r[RPT][kW];
+    if (tid < W) skey[tid] = 0ull;
+    T r[RPT][W];
     bool used[RPT];
 #pragma unroll
     for (int q = 0; q < RPT; ++q) {
         const int32_t i = tid + NT * q;
         used[q] = i >= m || rq[min(i, m - 1)] >= 0;
 #pragma unroll
-        for (int c = 0; c < kW; ++c) r[q][c] = (i < m && c < w) ? a[(size_t)i * ld + k0 + c] : scalar_traits<T>::zero();
+        for (int c = 0; c < W; ++c) r[q][c] = (i < m && c < w) ? a[(size_t)i * ld + k0 + c] : scalar_traits<T>::zero();
     }
     __syncthreads();
 #pragma unroll
-    for (int jj = 0; jj < kW; ++jj) {
+    for (int jj = 0; jj < W; ++jj) {
         if (jj >= w) break;
         unsigned long long key = 0ull;
 #pragma unroll
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restri
                 if (s_abs2(pv) == 0.0) s_from(pv, 1.0, 0.0);
                 const T pinv = s_inv(pv);
 #pragma unroll
-                for (int j = 0; j < kW; ++j) {
+                for (int j = 0; j < W; ++j) {
                     const T v = (j == jj) ? pinv : s_mul(pinv, r[q][j]);
                     prow_s[jj & 1][j] = v;
                     r[q][j] = v;
@@ -195,9 +202,9 @@ __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restri
             }
         }
         __syncthreads();
-        T prow[kW];
+        T prow[W];
 #pragma unroll
-        for (int j = 0; j < kW; ++j) prow[j] = prow_s[jj & 1][j];
+        for (int j = 0; j < W; ++j) prow[j] = prow_s[jj & 1][j];
 #pragma unroll
         for (int q = 0; q < RPT; ++q) {
             const int32_t i = tid + NT * q;
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restri
             const T nfm = s_sub(scalar_traits<T>::zero(), fm);
             r[q][jj] = scalar_traits<T>::zero();
 #pragma unroll
-            for (int j = 0; j < kW; ++j) fma_acc(r[q][j], nfm, prow[j]);
+            for (int j = 0; j < W; ++j) fma_acc(r[q][j], nfm, prow[j]);
         }
     }
 #pragma unroll
@@ -215,133 +222,134 @@ __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restri
         const int32_t i = tid + NT * q;
         if (i < m) {
 #pragma unroll
-            for (int j = 0; j < kW; ++j)
+            for (int j = 0; j < W; ++j)
                 if (j < w) a[(size_t)i * ld + k0 + j] = r[q][j];
         }
     }
-    // the pivot rows' values in the other columns (untouched so far), staged for the update launch: its workgroups may then
-    // split the rows among themselves (the owner of a pivot row overwrites it while the others still need its old values)
+    // the pivot rows' values in the block's other columns (untouched by this launch), for the block update
     __syncthreads();
-    T* yb = ybuf + (size_t)kW * nd.piv_off;
-    for (int32_t e = tid; e < w * m; e += NT) {
-        const int32_t j = e / m, c = e - j * m;
-        yb[(size_t)j * m + c] = a[(size_t)prows[j] * ld + c];
+    const int32_t nbw = min(kNB, m - kb);
+    T* yb = ysm + (size_t)t * (8 * kNB);
+    for (int32_t e = tid; e < w * nbw; e += NT) {
+        const int32_t j = e / nbw, c = e - j * nbw;
+        yb[j * kNB + c] = a[(size_t)prows[j] * ld + kb + c];
     }
 }
 
-// the same elimination for pivot blocks of more than 2048 rows: the panel stays in memory (L2), rows are walked
-template <typename T>
-__global__ __launch_bounds__(1024) void nd_gj_panel_big_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
-                                                               T* __restrict__ front, int32_t* __restrict__ ipiv, int32_t* __restrict__ rowq,
-                                                               int32_t k0, int32_t* __restrict__ flag, double tiny2, T* __restrict__ ybuf) {
-    __shared__ unsigned long long skey[kW];
-    __shared__ T prow_s[kW];
-    __shared__ int32_t prows[kW];
+// rank-w update of the block's other columns: A[i, c] = (i is one of the panel's pivot rows ? 0 : A[i, c]) + W[i, :] Y[:, c]
+// grid: (node of the level, 16-column tile of the block, 256-row tile)
+template <typename T, int W>
+__global__ __launch_bounds__(256) void nd_gj_block_update_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
+                                                                 T* __restrict__ front, const int32_t* __restrict__ ipiv, int32_t kb, int32_t k0,
+                                                                 const T* __restrict__ ysm) {
     const int32_t t = lvl_nodes[blockIdx.x];
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, ld = nd.f;
-    const int32_t w = min(kW, m - k0);
-    if (w <= 0) return;
-    T* a = front + nd.front_off;
-    int32_t* piv = ipiv + nd.piv_off;
-    int32_t* rq = rowq + nd.piv_off;
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < kW) skey[tid] = 0ull;
-    __syncthreads();
-    for (int jj = 0; jj < w; ++jj) {
-        unsigned long long key = 0ull;
-        for (int32_t i = tid; i < m; i += 1024) {
-            if (__hip_atomic_load(&rq[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= 0) continue;
-            const unsigned long long kq = pivot_key(s_abs2(a[(size_t)i * ld + k0 + jj]), i);
-            key = kq > key ? kq : key;
-        }
-        key = wave_max_key(key);
-        if (lane == 0) atomicMax(&skey[jj], key);
-        __syncthreads();
-        key = skey[jj];
-        const int32_t p = 65535 - (int32_t)(key & 0xFFFFull);
-        if (tid == 0) {
-            piv[k0 + jj] = p;
-            prows[jj] = p;
-            if (!(__longlong_as_double((long long)(key & ~0xFFFFull)) > tiny2) && atomicCAS(&flag[1], 0, t + 1) == 0) {
-                flag[2] = k0 + jj;
-                flag[3] = (int32_t)(key >> 32);
-            }
-            __hip_atomic_store(&rq[p], k0 + jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (tid < w) {
-            T pv = a[(size_t)p * ld + k0 + jj];
-            if (s_abs2(pv) == 0.0) s_from(pv, 1.0, 0.0);
-            const T pinv = s_inv(pv);
-            prow_s[tid] = (tid == jj) ? pinv : s_mul(pinv, a[(size_t)p * ld + k0 + tid]);
-        }
-        __syncthreads();
-        T prow[kW];
-#pragma unroll
-        for (int j = 0; j < kW; ++j) prow[j] = j < w ? prow_s[j] : scalar_traits<T>::zero();
-        for (int32_t i = tid; i < m; i += 1024) {
-            T* ai = a + (size_t)i * ld + k0;
-            if (i == p) {
-                for (int j = 0; j < w; ++j) ai[j] = prow[j];
-                continue;
-            }
-            const T fm = ai[jj];
-            if (s_abs2(fm) == 0.0) continue;
-            const T nfm = s_sub(scalar_traits<T>::zero(), fm);
-            ai[jj] = scalar_traits<T>::zero();
-            for (int j = 0; j < w; ++j) {
-                T v = ai[j];
-                fma_acc(v, nfm, prow[j]);
-                ai[j] = v;
-            }
-        }
-        __syncthreads();
-    }
-    T* yb = ybuf + (size_t)kW * nd.piv_off;
-    for (int32_t e = tid; e < w * m; e += 1024) {
-        const int32_t j = e / m, c = e - j * m;
-        yb[(size_t)j * m + c] = a[(size_t)prows[j] * ld + c];
-    }
-}
-
-// rank-w update of the columns outside the panel: A[i, J] = (i is one of the panel's pivot rows ? 0 : A[i, J]) + W[i, :] Y,
-// Y = the pivot rows' old values in J (staged by the panel launch), W = the eliminated panel.  A workgroup owns kUpdCols
-// columns x kUpdRows rows: large pivot blocks (the top of a 2D forest, every upper level of a 3D one) get enough workgroups.
-constexpr int kUpdRows = 256;
-template <typename T>
-__global__ __launch_bounds__(256) void nd_gj_update_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
-                                                           T* __restrict__ front, const int32_t* __restrict__ ipiv, int32_t k0,
-                                                           const T* __restrict__ ybuf) {
-    const int32_t t = tiles[2 * blockIdx.x], packed = tiles[2 * blockIdx.x + 1];
-    const int32_t c0 = (packed & 0xFFFF) * kUpdCols, r0 = (packed >> 16) * kUpdRows;
-    const NdNodeDev nd = nodes[t];
-    const int32_t m = nd.m, ld = nd.f;
-    const int32_t w = min(kW, m - k0);
-    if (w <= 0) return;
-    T* a = front + nd.front_off;
+    const int32_t w = min(W, m - k0);
+    const int32_t r0 = (int32_t)blockIdx.z * 256;
     const int tid = threadIdx.x;
-    const int32_t c = c0 + (tid & 15);
-    if (!(c < m && (c < k0 || c >= k0 + w))) return;
-    const T* yb = ybuf + (size_t)kW * nd.piv_off;
-    int32_t pr[kW];
-    T y[kW];
+    const int32_t cb = (int32_t)blockIdx.y * 16 + (tid & 15);  // column inside the block
+    const int32_t c = kb + cb;
+    if (w <= 0 || r0 >= m || cb >= kNB || c >= m || (c >= k0 && c < k0 + w)) return;
+    T* a = front + nd.front_off;
+    const T* yb = ysm + (size_t)t * (8 * kNB);
+    int32_t pr[W];
+    T y[W];
 #pragma unroll
-    for (int j = 0; j < kW; ++j) {
+    for (int j = 0; j < W; ++j) {
         pr[j] = j < w ? ipiv[nd.piv_off + k0 + j] : -1;
-        y[j] = j < w ? yb[(size_t)j * m + c] : scalar_traits<T>::zero();
+        y[j] = j < w ? yb[j * kNB + cb] : scalar_traits<T>::zero();
     }
-    const int32_t r1 = min(m, r0 + kUpdRows);
+    const int32_t r1 = min(m, r0 + 256);
 #pragma unroll 4
     for (int32_t i = r0 + (tid >> 4); i < r1; i += 16) {
         T* ai = a + (size_t)i * ld;
         bool is_piv = false;
 #pragma unroll
-        for (int j = 0; j < kW; ++j) is_piv |= (i == pr[j]);
+        for (int j = 0; j < W; ++j) is_piv |= (i == pr[j]);
         T acc = is_piv ? scalar_traits<T>::zero() : ai[c];
 #pragma unroll
-        for (int j = 0; j < kW; ++j)
+        for (int j = 0; j < W; ++j)
             if (j < w) fma_acc(acc, ai[k0 + j], y[j]);
         ai[c] = acc;
+    }
+}
+
+// Yb[j][c] = A[pivot row of column kb + j][c] for the nb columns of the finished block: the rows the product below needs,
+// staged because that product overwrites them.  grid: (node, 256-column chunk)
+template <typename T>
+__global__ __launch_bounds__(256) void nd_gj_stage_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
+                                                          const T* __restrict__ front, const int32_t* __restrict__ ipiv, int32_t kb,
+                                                          T* __restrict__ ybuf) {
+    const int32_t t = lvl_nodes[blockIdx.x];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, ld = nd.f;
+    const int32_t nb = min(kNB, m - kb);
+    const int32_t c = (int32_t)blockIdx.y * 256 + threadIdx.x;
+    if (nb <= 0 || m <= kNB || c >= m) return;
+    const T* a = front + nd.front_off;
+    T* yb = ybuf + (size_t)kNB * nd.piv_off;
+    for (int32_t j = 0; j < nb; ++j) yb[(size_t)j * m + c] = a[(size_t)ipiv[nd.piv_off + kb + j] * ld + c];
+}
+
+// the columns outside the finished block: A[i, c] = (i is a pivot row of the block ? 0 : A[i, c]) + sum_j Wb[i, j] Yb[j, c]
+// grid: (node, 64-row tile, 64-column tile); 4 x 4 per thread; the whole K = nb <= 32 extent in one pass through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void nd_gj_gemm_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
+                                                         T* __restrict__ front, const int32_t* __restrict__ rowq, int32_t kb,
+                                                         const T* __restrict__ ybuf) {
+    __shared__ T Ws[kNB][kGT + 1];
+    __shared__ T Ys[kNB][kGT + 1];
+    const int32_t t = lvl_nodes[blockIdx.x];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, ld = nd.f;
+    const int32_t nb = min(kNB, m - kb);
+    const int32_t row0 = (int32_t)blockIdx.y * kGT, col0 = (int32_t)blockIdx.z * kGT;
+    if (nb <= 0 || row0 >= m || col0 >= m) return;
+    if (col0 >= kb && col0 + kGT <= kb + nb) return;  // tile inside the block
+    T* a = front + nd.front_off;
+    const T* yb = ybuf + (size_t)kNB * nd.piv_off;
+    const int32_t* rq = rowq + nd.piv_off;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    for (int e = tid; e < kNB * kGT; e += 256) {
+        // Ws[j][q] = Wb[row0 + q][j]: lanes along j (a row's block columns are contiguous);  Ys[j][q] = Yb[j][col0 + q]: lanes along q
+        const int qa = e / kNB, ja = e - qa * kNB;
+        const int32_t gr = row0 + qa;
+        Ws[ja][qa] = (ja < nb && gr < m) ? a[(size_t)gr * ld + kb + ja] : scalar_traits<T>::zero();
+        const int jb = e / kGT, qb = e - jb * kGT;
+        const int32_t gc = col0 + qb;
+        Ys[jb][qb] = (jb < nb && gc < m) ? yb[(size_t)jb * m + gc] : scalar_traits<T>::zero();
+    }
+    __syncthreads();
+    T acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = scalar_traits<T>::zero();
+    for (int k = 0; k < nb; ++k) {
+        T av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = Ws[k][ty * 4 + i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = Ys[k][tx + 16 * j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fma_acc(acc[i][j], av[i], bv[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int32_t gr = row0 + ty * 4 + i;
+        if (gr >= m) continue;
+        const int32_t q = rq[gr];
+        const bool is_piv = q >= kb && q < kb + nb;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int32_t gc = col0 + tx + 16 * j;
+            if (gc >= m || (gc >= kb && gc < kb + nb)) continue;
+            T* cptr = a + (size_t)gr * ld + gc;
+            *cptr = is_piv ? acc[i][j] : s_add(*cptr, acc[i][j]);
+        }
     }
 }
 
@@ -664,7 +672,7 @@ struct lsa_ndlu {
     int32_t* d_asm_src = nullptr;
     int32_t *d_ipiv = nullptr, *d_rowq = nullptr, *d_flag = nullptr, *d_xflag = nullptr;
     unsigned long long* d_maxabs = nullptr;
-    void *d_front = nullptr, *d_scratch = nullptr, *d_ubuf = nullptr, *d_tmp = nullptr, *d_ybuf = nullptr;
+    void *d_front = nullptr, *d_scratch = nullptr, *d_ubuf = nullptr, *d_tmp = nullptr, *d_ybuf = nullptr, *d_ysm = nullptr;
     double seconds_analyse = 0.0, seconds_numeric = 0.0;
     int32_t solve_launches = 0;
 };
@@ -675,7 +683,7 @@ void nd_free(lsa_ndlu* f) {
     if (!f) return;
     for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
                     (void*)f->d_lvl_nodes, (void*)f->d_asm_dst, (void*)f->d_asm_src, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_xflag, (void*)f->d_maxabs,
-                    f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp, f->d_ybuf})
+                    f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp, f->d_ybuf, f->d_ysm})
         if (p) (void)hipFree(p);
     delete f;
 }
@@ -751,14 +759,6 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
                 for (int32_t i0 = 0; i0 < bc; i0 += 16) push(L.ext[(size_t)r], c, i0);
             }
         }
-        begin_list(L.upd);
-        L.upd_tile_prefix.assign(1, 0);
-        for (int32_t q = 0; q < L.node_count; ++q) {
-            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            for (int32_t r0 = 0; r0 < S.m[(size_t)t]; r0 += kUpdRows)
-                for (int32_t c0 = 0; c0 < S.m[(size_t)t]; c0 += kUpdCols) push(L.upd, t, (c0 / kUpdCols) | ((r0 / kUpdRows) << 16));
-            L.upd_tile_prefix.push_back(L.upd.count);
-        }
         begin_list(L.unperm);
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
@@ -787,7 +787,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
             for (int32_t r0 = 0; r0 < S.f[(size_t)t]; r0 += 16) push(L.copyback, t, r0);
         }
-        if (L.max_m > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a pivot block of %d rows exceeds the 65 535 the pivot key encodes", L.max_m);
+        if (L.max_m > 16384) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a pivot block of %d rows exceeds the 16 384 the panel kernels hold in registers", L.max_m);
     }
     LSA_CHECK(upload(ctx, nodes, &f->d_nodes));
     {
@@ -813,16 +813,38 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_scratch, (size_t)max_scratch * es));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ubuf, (size_t)std::max<int64_t>(S.u_off[(size_t)nt], 1) * 16));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_tmp, nn * 16));
-    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ybuf, nn * kW * es));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ybuf, nn * kNB * es));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ysm, (size_t)std::max(nt, 1) * 8 * kNB * es));
     f->solve_launches = 0;
     for (const NdLevel& L : f->levels) f->solve_launches += (L.fwd_tiles > 0) + (L.bwd_tiles > 0);
     return LSA_OK;
 }
 
-template <typename T, int NT, int RPT>
-void launch_panel(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t active, int32_t k0, double tiny2) {
-    hipLaunchKernelGGL((nd_gj_panel_kernel<T, NT, RPT>), dim3(active), dim3(NT), 0, ctx->stream, f->d_lvl_nodes + L.node_begin, f->d_nodes,
-                       (T*)f->d_front, f->d_ipiv, f->d_rowq, k0, f->d_flag, tiny2, (T*)f->d_ybuf);
+template <typename T, int NT, int RPT, int W>
+void launch_block(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t kb, double tiny2) {
+    hipStream_t st = ctx->stream;
+    const int32_t* lv = f->d_lvl_nodes + L.node_begin;
+    T* front = (T*)f->d_front;
+    auto active_at = [&](int32_t k) {  // nodes are sorted by own size: those that still have column k form a prefix
+        return (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), k, std::greater<int32_t>()) - L.sorted_m.begin());
+    };
+    const int32_t kend = std::min(kb + kNB, L.max_m);
+    for (int32_t k0 = kb; k0 < kend; k0 += W) {
+        const int32_t active = active_at(k0);
+        if (active == 0) break;
+        hipLaunchKernelGGL((nd_gj_panel_kernel<T, NT, RPT, W>), dim3(active), dim3(NT), 0, st, lv, f->d_nodes, front, f->d_ipiv, f->d_rowq, kb, k0, f->d_flag,
+                           tiny2, (T*)f->d_ysm);
+        if (std::min(kNB, L.max_m - kb) > W)  // the block has columns besides this panel
+            hipLaunchKernelGGL((nd_gj_block_update_kernel<T, W>), dim3(active, kNB / 16, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, front,
+                               f->d_ipiv, kb, k0, (const T*)f->d_ysm);
+    }
+    if (L.max_m > kNB) {  // columns outside the block exist (in the larger nodes)
+        const int32_t active = active_at(kb);
+        hipLaunchKernelGGL((nd_gj_stage_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, kb,
+                           (T*)f->d_ybuf);
+        const int32_t tiles = (L.max_m + kGT - 1) / kGT;
+        hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, tiles), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb, (const T*)f->d_ybuf);
+    }
 }
 
 template <typename T>
@@ -859,23 +881,16 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
             LSA_CHECK(k_allgather_inplace(ctx, f->d_front, (size_t)S.xfront_slot * sizeof(T)));
         for (const TileList& e : L.ext)
             if (e.count > 0) hipLaunchKernelGGL((nd_extend_add_kernel<T>), dim3(e.count), dim3(256), 0, st, tl + 2 * e.off, f->d_nodes, f->d_cmap, front);
-        for (int32_t k0 = 0; k0 < L.max_m; k0 += kW) {
-            // nodes are sorted by own size: those that still have columns at k0 form a prefix
-            const int32_t active = (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), k0, std::greater<int32_t>()) - L.sorted_m.begin());
-            if (active == 0) break;
-            if (L.max_m <= 64) launch_panel<T, 64, 1>(ctx, f, L, active, k0, tiny2);
-            else if (L.max_m <= 128) launch_panel<T, 128, 1>(ctx, f, L, active, k0, tiny2);
-            else if (L.max_m <= 256) launch_panel<T, 256, 1>(ctx, f, L, active, k0, tiny2);
-            else if (L.max_m <= 512) launch_panel<T, 512, 1>(ctx, f, L, active, k0, tiny2);
-            else if (L.max_m <= 1024) launch_panel<T, 1024, 1>(ctx, f, L, active, k0, tiny2);
-            else if (L.max_m <= 2048) launch_panel<T, 1024, 2>(ctx, f, L, active, k0, tiny2);
-            else
-                hipLaunchKernelGGL((nd_gj_panel_big_kernel<T>), dim3(active), dim3(1024), 0, st, f->d_lvl_nodes + L.node_begin, f->d_nodes, front,
-                                   f->d_ipiv, f->d_rowq, k0, f->d_flag, tiny2, (T*)f->d_ybuf);
-            const int32_t utiles = L.upd_tile_prefix[(size_t)active];
-            if (utiles > 0 && L.max_m > kW)
-                hipLaunchKernelGGL((nd_gj_update_kernel<T>), dim3(utiles), dim3(256), 0, st, tl + 2 * L.upd.off, f->d_nodes, front, f->d_ipiv, k0,
-                                   (const T*)f->d_ybuf);
+        for (int32_t kb = 0; kb < L.max_m; kb += kNB) {
+            if (L.max_m <= 64) launch_block<T, 64, 1, 8>(ctx, f, L, kb, tiny2);
+            else if (L.max_m <= 128) launch_block<T, 128, 1, 8>(ctx, f, L, kb, tiny2);
+            else if (L.max_m <= 256) launch_block<T, 256, 1, 8>(ctx, f, L, kb, tiny2);
+            else if (L.max_m <= 512) launch_block<T, 512, 1, 8>(ctx, f, L, kb, tiny2);
+            else if (L.max_m <= 1024) launch_block<T, 1024, 1, 8>(ctx, f, L, kb, tiny2);
+            else if (L.max_m <= 2048) launch_block<T, 1024, 2, 8>(ctx, f, L, kb, tiny2);
+            else if (L.max_m <= 4096) launch_block<T, 1024, 4, 4>(ctx, f, L, kb, tiny2);
+            else if (L.max_m <= 8192) launch_block<T, 1024, 8, 2>(ctx, f, L, kb, tiny2);
+            else launch_block<T, 1024, 16, 1>(ctx, f, L, kb, tiny2);
         }
         if (L.unperm.count > 0)
             hipLaunchKernelGGL((nd_unperm_kernel<T>), dim3(L.unperm.count), dim3(256), 0, st, tl + 2 * L.unperm.off, f->d_nodes, front, f->d_ipiv,

@@ -482,7 +482,9 @@ class iEpsSolver:
             dM = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, Mp)
         if pc_code == 2 and K is not None and forest is None:
             # pattern-only phase of the nested-dissection LU (ordering, elimination forest, index tables, buffers)
-            cplx_factors = bool(np.iscomplexobj(K)) or (sinvert and complex(sigma).imag != 0.0)
+            # the scalar type the library will give C = A - sigma M (lsa_op_create): complex only for a complex shift or
+            # complex operators (K above is complex whenever the target was stored as a Python complex)
+            cplx_factors = A.dtype.kind == "c" or (M is not None and M.dtype.kind == "c") or (sinvert and complex(sigma).imag != 0.0)
             fac = dAd if dAd is not None else dA
             # Zero-diagonal (pressure) unknowns as constraints, eliminated after their neighbours: needed on 3D Taylor-Hood
             # patterns, where a leaf subdomain can hold more pressure unknowns than its interior supports; costs 20 % more

@@ -39,3 +39,6 @@ res = s.solver.residuals()
 print(f"solve {dt:.2f}s -> {len(pairs) / dt:.2f} eigenpairs/s; converged {len(pairs)}; max residual {res.max():.2e}", flush=True)
 print("stats", s.solver.stats, flush=True)
 print("lambda[:5]", [complex(p[0]) for p in pairs[:5]], flush=True)
+t0 = time.time()
+s.solve()
+print(f"second solve {time.time() - t0:.2f}s; stats {s.solver.stats}", flush=True)

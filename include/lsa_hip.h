@@ -60,7 +60,7 @@ typedef struct {
     int32_t pc_fallback;     /* 1 if the exact LU did not fit the device memory and ILU(k) + GMRES took its place */
     int32_t backward_accepted; /* direct solves whose ||b - C x|| / ||b|| missed rtol but whose backward error
                                   ||b - C x|| / (||C||_F ||x||) is <= 1e-12: shifts next to an eigenvalue */
-    int32_t reserved;
+    int32_t analysis_reused; /* 1 if the exact LU found its pattern-only analysis prepared (lsa_ndlu_prepare) or cached in the context */
 } lsa_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */

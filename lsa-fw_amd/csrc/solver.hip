@@ -560,6 +560,11 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
             }
         } else
             rc = opts->pc_type == 2 ? lsa_ndlu_create(ctx, fac_src, 0, &op->nd) : lsa_blu_create(ctx, fac_src, 0, &op->blu);
+        if (rc == LSA_OK && op->nd) {
+            double sa = 1.0;
+            (void)lsa_ndlu_info(op->nd, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sa, nullptr);
+            op->st.analysis_reused = sa == 0.0 ? 1 : 0;
+        }
         if (rc == LSA_ERR_OOM) {
             fprintf(stderr, "[lsa_hip] exact LU does not fit the device memory (%s): falling back to ILU(%d) + GMRES\n", ctx->err.c_str(),
                     opts->ilu_levels);

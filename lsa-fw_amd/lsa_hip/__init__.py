@@ -51,7 +51,7 @@ class lsa_stats(ctypes.Structure):
         ("stagnated_solves", ctypes.c_int32),
         ("pc_fallback", ctypes.c_int32),
         ("backward_accepted", ctypes.c_int32),
-        ("reserved", ctypes.c_int32),
+        ("analysis_reused", ctypes.c_int32),
     ]
 
 

@@ -41,6 +41,9 @@ def test_cube_c9k_matches_the_oracle():
     assert s.solver.residuals()[:10].max() <= 1e-8
     st = s.solver.stats
     assert st["gmres_iters"] == 0 and st["pc_fallback"] == 0
+    # the pattern-only analysis of prepare() -- float64 factors for this real shift, constraint ordering for the 3D pattern --
+    # is the one the solve used (a complex-typed real shift once made it miss: analysed, failed, analysed again)
+    assert st["analysis_reused"] == 1
     s.solver.release()
 
 

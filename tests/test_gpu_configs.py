@@ -56,7 +56,7 @@ def test_s30k_eigenvalues_match_the_golden_fixture(s30k_golden, k, ncv):
         assert np.min(np.abs(lam - r)) <= 1e-8 * abs(r)
     assert s.solver.residuals()[:k].max() <= 1e-8
     st = s.solver.stats
-    assert st["pc_fallback"] == 0 and st["stagnated_solves"] == 0 and st["max_rel_res"] <= 1e-11
+    assert st["pc_fallback"] == 0 and st["stagnated_solves"] == 0 and st["max_rel_res"] <= 1e-11 and st["analysis_reused"] == 1
     s.solver.release()
 
 

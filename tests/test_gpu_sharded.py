@@ -72,11 +72,12 @@ def _rank_main(rank: int, world: int, port: int, out_dir: str, case: str, pc: st
     from Solver.utils import PreconditionerType, iSTType
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    es = fem.cylinder_case(case)
+    es = fem.cube_case(case) if case.startswith("C") else fem.cylinder_case(case)
+    sigma = fem.SIGMA_CUBE if case.startswith("C") else fem.SIGMA_RE50
     kw = {"ilu_levels": 2} if pc == "ilu" else {}
     solver = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=5, atol=1e-10, ncv=40), check_hermitian=False, layout="sharded", **kw)
     solver.solver.set_st_type(iSTType.SINVERT)
-    solver.solver.set_target(fem.SIGMA_RE50)
+    solver.solver.set_target(sigma)
     solver.solver.set_st_pc_type(PreconditionerType.ILU if pc == "ilu" else PreconditionerType.LU)
     pairs = solver.solve()
     lam = np.array([p[0] for p in pairs[:5]])
@@ -89,8 +90,8 @@ def _rank_main(rank: int, world: int, port: int, out_dir: str, case: str, pc: st
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,pc", [(2, "lu"), (3, "lu"), (4, "lu"), (2, "ilu")])
-def test_sharded_solve_with_several_ranks_on_one_gpu(tmp_path, world, pc):
+@pytest.mark.parametrize("world,pc,case", [(2, "lu", "S2k"), (3, "lu", "S2k"), (4, "lu", "S2k"), (2, "ilu", "S2k"), (4, "lu", "C9k")])
+def test_sharded_solve_with_several_ranks_on_one_gpu(tmp_path, world, pc, case):
     """The whole device path of the sharded layouts with more than one rank.  LU: the subtree-parallel exact
     factorisation (every rank factors its subtrees of the nested-dissection forest, one all-gather of the subtree roots'
     fronts, the replicated top; per operator apply three all-gathers and no inner iteration).  ILU: row shards in the
@@ -106,13 +107,12 @@ def test_sharded_solve_with_several_ranks_on_one_gpu(tmp_path, world, pc):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    case = "S2k"
     mp.spawn(_rank_main, args=(world, port, str(tmp_path), case, pc), nprocs=world, join=True)
     out = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     for o in out[1:]:  # replicated bases, fixed-order reductions: bit-identical on every rank, no all-reduce anywhere
         assert np.array_equal(o["lam"], out[0]["lam"]) and np.array_equal(o["V"], out[0]["V"])
-    es = fem.cylinder_case(case)
-    ref, _, _ = shift_invert.solve(es.A, es.M, fem.SIGMA_RE50, k=5, tol=1e-13)
+    es = fem.cube_case(case) if case.startswith("C") else fem.cylinder_case(case)  # C9k: the 3D pattern (BASELINE config 4's layout, small)
+    ref, _, _ = shift_invert.solve(es.A, es.M, fem.SIGMA_CUBE if case.startswith("C") else fem.SIGMA_RE50, k=5, tol=1e-13)
     for r in ref:
         assert np.min(np.abs(out[0]["lam"] - r)) <= 1e-8 * abs(r)
     assert out[0]["res"].max() <= 1e-8

@@ -475,7 +475,7 @@ int lsa_spmv_info(lsa_ctx* ctx, const lsa_mat* A, int xdtype, char* kernel, int3
     const char* vt = xdtype == LSA_C128 ? "cplx" : "double";
     const char* base = grouped ? "spmv_group_kernel" : c16 ? "spmv_subwave16_kernel" : (variant & 0x200) ? "spmv_xcd_kernel" : (variant & 0x400) ? "spmv_subwave2_kernel" : "spmv_subwave_kernel";
     if (kernel && kernel_len > 0) {
-        if (grouped) snprintf(kernel, (size_t)kernel_len, "%s<%s,%s,%d,%s>", base, mt, vt, lpr, c16 ? "true" : "false");
+        if (grouped) snprintf(kernel, (size_t)kernel_len, "%s<%s,%s,%d,%s,%s>", base, mt, vt, lpr, c16 ? "true" : "false", (variant & 0x8000) && !c16 ? "true" : "false");
         else snprintf(kernel, (size_t)kernel_len, "%s<%s,%s,%d>", base, mt, vt, lpr);
     }
     if (bytes_moved) {

@@ -43,16 +43,24 @@ struct OrthWork {
     }
 };
 
-// CGS2: orthogonalise w against V[:, 0:j], normalise into vnext, and bring the j+1 Hessenberg entries to the
-// host as complex numbers (real dtype is widened).  One stream synchronisation.
-int orthonormalize(lsa_ctx* ctx, int dtype, int64_t n, const void* V, int64_t ldv, int j, void* w, void* vnext,
-                   OrthWork& ow, zc* h_host) {
+// the device part of CGS2: orthogonalise w against V[:, 0:j] and normalise into vnext; the j+1 Hessenberg entries go to
+// `hcol_dev`, nothing is read back
+int orthonormalize_enqueue(lsa_ctx* ctx, int dtype, int64_t n, const void* V, int64_t ldv, int j, void* w, void* vnext, OrthWork& ow,
+                           void* hcol_dev) {
     LSA_CHECK(k_multi_dot(ctx, dtype, n, j, V, ldv, w, ow.h1));
     LSA_CHECK(k_multi_axpy(ctx, dtype, n, j, V, ldv, ow.h1, w, nullptr));
     LSA_CHECK(k_multi_dot(ctx, dtype, n, j, V, ldv, w, ow.h2));
     LSA_CHECK(k_multi_axpy(ctx, dtype, n, j, V, ldv, ow.h2, w, ow.nrm2));
-    LSA_CHECK(k_hess_column(ctx, dtype, j, ow.h1, ow.h2, ow.nrm2, ow.hcol));
+    LSA_CHECK(k_hess_column(ctx, dtype, j, ow.h1, ow.h2, ow.nrm2, hcol_dev));
     LSA_CHECK(k_scale_by_inv_norm(ctx, dtype, n, w, ow.nrm2, vnext));
+    return LSA_OK;
+}
+
+// CGS2 with the Hessenberg entries brought to the host as complex numbers (real dtype is widened).  One stream
+// synchronisation.
+int orthonormalize(lsa_ctx* ctx, int dtype, int64_t n, const void* V, int64_t ldv, int j, void* w, void* vnext,
+                   OrthWork& ow, zc* h_host) {
+    LSA_CHECK(orthonormalize_enqueue(ctx, dtype, n, V, ldv, j, w, vnext, ow, ow.hcol));
     const size_t bytes = (size_t)(j + 1) * esize(dtype);
     LSA_CHECK(lsa_ensure_scratch(ctx, 0, bytes));
     LSA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pinned, ow.hcol, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -411,6 +419,12 @@ struct lsa_krylov {
     void *V, *V2, *w, *qdev;
     OrthWork ow;
     std::vector<zc> hcol;
+    // pipelined Arnoldi steps (exact inner solves): Hessenberg columns and the b - C x checks of a batch of steps stay on
+    // the device until the batch is read back with one synchronisation
+    void* Hdev = nullptr;      // batch x (ncv + 2) complex
+    double* checks = nullptr;  // batch x 2: ||b - C x||^2, ||b||^2
+    int32_t batch = 0;
+    bool pipeline = false;
 };
 
 extern "C" {
@@ -731,6 +745,18 @@ int lsa_krylov_create(lsa_ctx* ctx, lsa_op* op, int32_t ncv, lsa_krylov** out) {
     }
     (void)hipMemsetAsync(k->w, 0, vb, ctx->stream);
     k->hcol.assign((size_t)ncv + 2, zc(0));
+    // Arnoldi steps are queued in batches when the inner solve is one exact LU solve and the exchange (if any) is
+    // stream-ordered (RCCL): LSA_KRYLOV_BATCH steps per read-back (default 16; 0 or 1 = one step at a time)
+    const char* be = getenv("LSA_KRYLOV_BATCH");
+    k->batch = be && *be ? std::max(0, std::min(atoi(be), 256)) : 16;
+    if (k->batch > 1) {
+        if (hipMalloc(&k->Hdev, (size_t)k->batch * (size_t)(ncv + 2) * 16) != hipSuccess ||
+            hipMalloc((void**)&k->checks, (size_t)k->batch * 2 * sizeof(double)) != hipSuccess) {
+            lsa_krylov_destroy(k);
+            return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_krylov_create: out of device memory (pipeline buffers)");
+        }
+        k->pipeline = true;
+    }
     *out = k;
     return LSA_OK;
 }
@@ -739,7 +765,7 @@ void lsa_krylov_destroy(lsa_krylov* k) {
     if (!k) return;
     if (k->ctx && k->ctx->stream) (void)hipStreamSynchronize(k->ctx->stream);
     if (k->row_perm) (void)hipFree(k->row_perm);
-    for (void* p : {k->V, k->V2, k->w, k->qdev})
+    for (void* p : {k->V, k->V2, k->w, k->qdev, k->Hdev, (void*)k->checks})
         if (p) (void)hipFree(p);
     k->ow.release();
     delete k;
@@ -784,6 +810,41 @@ int lsa_krylov_inject(lsa_ctx* ctx, lsa_krylov* k, int32_t j, const void* host_v
     return LSA_OK;
 }
 
+// One batch of Arnoldi steps [j, j + nb) queued without a host round trip: operator apply by one exact LU solve, the
+// check b - C x of that solve, CGS2.  Everything the host decides on (the check, the Hessenberg column, breakdown) is read
+// back once per batch.
+static int krylov_enqueue_step(lsa_ctx* ctx, lsa_krylov* k, int32_t j, int32_t slot) {
+    lsa_op* op = k->op;
+    const int dtype = LSA_C128;
+    const size_t vb = (size_t)k->n * 16;
+    const void* vj = (char*)k->V + (size_t)j * vb;
+    void* vn = (char*)k->V + (size_t)(j + 1) * vb;
+    const void* rhs = vj;
+    if (op->Kmul) {
+        LSA_CHECK(spmv_global(ctx, op->Kmul, dtype, vj, op->t, op->adjoint));
+        rhs = op->t;
+    }
+    PcRef pcr;
+    pcr.blu = op->blu;
+    pcr.nd = op->nd;
+    pcr.nd_dist = op->nd_dist;
+    pcr.adjoint = op->adjoint;
+    LSA_CHECK(pc_global(ctx, pcr, op->Kfac->row0, op->n, dtype, rhs, k->w));
+    LSA_CHECK(spmv_global(ctx, op->Kfac, dtype, k->w, op->gw.z, op->adjoint));
+    LSA_CHECK(k_residual_norms(ctx, dtype, op->n, rhs, op->gw.z, op->gw.w, k->checks + 2 * (size_t)slot));
+    if (op->keep) LSA_CHECK(k_mask(ctx, dtype, op->n, op->keep, k->w));
+    return orthonormalize_enqueue(ctx, dtype, k->n, k->V, k->n, j + 1, k->w, vn, k->ow, (char*)k->Hdev + (size_t)slot * (size_t)(k->ncv + 2) * 16);
+}
+
+// true when an operator apply is one exact LU solve whose result only needs checking, with nothing on the way that
+// synchronises with the host by itself (the host-staged exchange does)
+static bool krylov_can_pipeline(const lsa_ctx* ctx, const lsa_krylov* k) {
+    const lsa_op* op = k->op;
+    if (!k->pipeline || !op->Kfac || !(op->nd || op->blu) || op->pc) return false;
+    if (ctx->nranks > 1 && (!op->nd_dist || ctx->host_gather)) return false;
+    return true;
+}
+
 int lsa_krylov_extend(lsa_ctx* ctx, lsa_krylov* k, int32_t j0, int32_t j1, void* H, int32_t ldh, int32_t* breakdown) {
     if (!ctx || !k || !H) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_extend: null argument");
     if (j0 < 0 || j1 < j0 || j1 > k->ncv || ldh < j1 + 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_extend: bad step range [%d, %d) for ncv %d", j0, j1, k->ncv);
@@ -791,27 +852,92 @@ int lsa_krylov_extend(lsa_ctx* ctx, lsa_krylov* k, int32_t j0, int32_t j1, void*
     const size_t vb = (size_t)k->n * 16;
     if (breakdown) *breakdown = -1;
     cplx* Hh = (cplx*)H;
-    for (int32_t j = j0; j < j1; ++j) {
+    lsa_op* op = k->op;
+    // fills column j of H from hcol (j + 2 entries) and tells whether the step broke down; < 0: non-finite
+    auto take_column = [&](int32_t j, const zc* hcol) -> int {
+        for (int32_t i = 0; i < ldh; ++i) Hh[(size_t)j * ldh + i] = cplx{0.0, 0.0};
+        for (int32_t i = 0; i <= j + 1; ++i) Hh[(size_t)j * ldh + i] = cplx{hcol[i].real(), hcol[i].imag()};
+        const double beta = hcol[j + 1].real();
+        if (!std::isfinite(beta)) return -1;
+        double colmax = 0.0;
+        for (int32_t i = 0; i <= j; ++i) colmax = std::max(colmax, std::abs(hcol[i]));
+        return beta <= 1e-14 * std::max(colmax, 1e-300) ? 1 : 0;
+    };
+    int32_t j = j0;
+    if (krylov_can_pipeline(ctx, k)) {
+        if (!op->gw_ready) {
+            LSA_CHECK(op->gw.alloc(ctx, op->n, std::max(1, std::min({op->opts.ksp_restart, op->opts.ksp_maxit, 40})), LSA_C128));
+            op->gw_ready = true;
+        }
+        const size_t colb = (size_t)(k->ncv + 2) * 16;
+        LSA_CHECK(lsa_ensure_scratch(ctx, 0, (size_t)k->batch * (colb + 2 * sizeof(double))));
+        const double rtol = op->opts.ksp_rtol;
+        while (j < j1 && k->pipeline) {
+            const int32_t nb = std::min<int32_t>(k->batch, j1 - j);
+            const double tq = now_s();
+            for (int32_t s = 0; s < nb; ++s) {
+                int rc = krylov_enqueue_step(ctx, k, j + s, s);
+                if (rc != LSA_OK) {
+                    (void)hipStreamSynchronize(ctx->stream);
+                    op->st.seconds_solve += now_s() - t0;
+                    return rc;
+                }
+            }
+            char* host = (char*)ctx->pinned;
+            LSA_HIP_CHECK(ctx, hipMemcpyAsync(host, k->Hdev, (size_t)nb * colb, hipMemcpyDeviceToHost, ctx->stream));
+            LSA_HIP_CHECK(ctx, hipMemcpyAsync(host + (size_t)k->batch * colb, k->checks, (size_t)nb * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            const double tw = now_s();
+            LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            static const bool timing = getenv("LSA_KRYLOV_TIMING") != nullptr;
+            if (timing) fprintf(stderr, "[lsa_krylov] %d steps queued in %.3f ms, waited %.3f ms\n", nb, 1e3 * (tw - tq), 1e3 * (now_s() - tw));
+            const double* chk = (const double*)(host + (size_t)k->batch * colb);
+            int32_t accepted = 0;
+            for (int32_t s = 0; s < nb; ++s, ++accepted) {
+                const double beta0 = std::sqrt(chk[2 * s]), bnorm = std::sqrt(chk[2 * s + 1]);
+                if (!(beta0 <= rtol * bnorm)) {
+                    // this solve needs the slower judgement (backward error, refinement) of the one-step path, and so will
+                    // its neighbours: the rest of the life of this basis runs one step at a time
+                    k->pipeline = false;
+                    break;
+                }
+                const cplx* hc = (const cplx*)(host + (size_t)s * colb);
+                for (int32_t i = 0; i <= j + s + 1; ++i) k->hcol[i] = zc(hc[i].re, hc[i].im);
+                ++op->st.op_applies;
+                op->st.spmv_calls += op->Kmul ? 2 : 1;
+                op->st.sptrsv_calls += 2;
+                op->st.last_rel_res = bnorm > 0.0 ? beta0 / bnorm : 0.0;
+                op->st.max_rel_res = std::max(op->st.max_rel_res, op->st.last_rel_res);
+                const int what = take_column(j + s, k->hcol.data());
+                if (what < 0) {
+                    op->st.seconds_solve += now_s() - t0;
+                    return lsa_set_error(ctx, LSA_ERR_NONFINITE, "Arnoldi: non-finite norm at step %d", j + s);
+                }
+                if (what > 0) {  // the steps queued behind a breakdown worked on noise: the caller restarts from here
+                    if (breakdown) *breakdown = j + s;
+                    op->st.seconds_solve += now_s() - t0;
+                    return LSA_OK;
+                }
+            }
+            j += accepted;
+        }
+    }
+    for (; j < j1; ++j) {
         const void* vj = (char*)k->V + (size_t)j * vb;
         void* vn = (char*)k->V + (size_t)(j + 1) * vb;
-        int rc = op_apply_dev(ctx, k->op, vj, k->w);
+        int rc = op_apply_dev(ctx, op, vj, k->w);
         if (rc != LSA_OK) {
-            k->op->st.seconds_solve += now_s() - t0;
+            op->st.seconds_solve += now_s() - t0;
             return rc;
         }
         LSA_CHECK(orthonormalize(ctx, LSA_C128, k->n, k->V, k->n, j + 1, k->w, vn, k->ow, k->hcol.data()));
-        for (int32_t i = 0; i < ldh; ++i) Hh[(size_t)j * ldh + i] = cplx{0.0, 0.0};
-        for (int32_t i = 0; i <= j + 1; ++i) Hh[(size_t)j * ldh + i] = cplx{k->hcol[i].real(), k->hcol[i].imag()};
-        const double beta = k->hcol[j + 1].real();
-        if (!std::isfinite(beta)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "Arnoldi: non-finite norm at step %d", j);
-        double colmax = 0.0;
-        for (int32_t i = 0; i <= j; ++i) colmax = std::max(colmax, std::abs(k->hcol[i]));
-        if (beta <= 1e-14 * std::max(colmax, 1e-300)) {
+        const int what = take_column(j, k->hcol.data());
+        if (what < 0) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "Arnoldi: non-finite norm at step %d", j);
+        if (what > 0) {
             if (breakdown) *breakdown = j;
             break;
         }
     }
-    k->op->st.seconds_solve += now_s() - t0;
+    op->st.seconds_solve += now_s() - t0;
     return LSA_OK;
 }
 

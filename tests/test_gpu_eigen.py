@@ -441,3 +441,52 @@ def test_which_policies_without_a_target():
         assert np.all(abs(conv - got) <= 1e-7)  # every returned value is an eigenvalue ...
         d = np.array([dist(g, t) for g in got])
         assert np.all(np.diff(d) >= -1e-9)  # ... returned in the requested order
+
+
+@pytest.mark.parametrize("batch", [16, 5])
+def test_batched_arnoldi_steps_equal_one_step_at_a_time(hip_ctx, monkeypatch, batch):
+    """With an exact LU inner solve the Arnoldi steps are queued in batches (one read-back of the Hessenberg columns and
+    of the b - C x checks per batch, ``LSA_KRYLOV_BATCH``).  The same kernels run in the same order, so H, the basis and
+    the counters are bit-identical to the one-step-at-a-time path; a breakdown inside a batch is reported at its step."""
+    import lsa_hip
+    from oracle import fem
+
+    es = fem.cylinder_case("S2k")
+    dA = lsa_hip.CsrMatrix.from_scipy(hip_ctx, es.A)
+    dM = lsa_hip.CsrMatrix.from_scipy(hip_ctx, es.M)
+    v0 = np.random.default_rng(3).standard_normal(es.n) + 0j
+    out = {}
+    for b in (1, batch):
+        monkeypatch.setenv("LSA_KRYLOV_BATCH", str(b))
+        op = lsa_hip.ShiftInvertOperator(hip_ctx, dA, dM, fem.SIGMA_RE50, pc_type=2)
+        kb = lsa_hip.KrylovBasis(hip_ctx, op, 40)
+        kb.inject(0, v0)
+        H = np.zeros((41, 40), dtype=np.complex128, order="F")
+        assert kb.extend(0, 23, H) == -1
+        assert kb.extend(23, 40, H) == -1
+        Y = np.eye(40, dtype=np.complex128)[:, :3]
+        out[b] = (H.copy(), kb.ritz_vectors(40, Y, False), op.stats())
+    (H1, X1, s1), (Hb, Xb, sb) = out[1], out[batch]
+    assert np.array_equal(H1, Hb) and np.array_equal(X1, Xb)
+    for key in ("op_applies", "spmv_calls", "sptrsv_calls", "gmres_iters", "max_rel_res"):
+        assert s1[key] == sb[key], key
+    assert s1["op_applies"] == 40 and s1["max_rel_res"] <= 1e-11
+
+    # breakdown: the start vector spans a 3-dimensional invariant subspace of a diagonal pair
+    import scipy.sparse as sp
+
+    n = 64
+    D = sp.diags(np.arange(1.0, n + 1)).tocsr()
+    I = sp.identity(n, format="csr")
+    v = np.zeros(n, dtype=np.complex128)
+    v[[4, 9, 20]] = 1.0
+    got = {}
+    for b in (1, batch):
+        monkeypatch.setenv("LSA_KRYLOV_BATCH", str(b))
+        op = lsa_hip.ShiftInvertOperator(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, D), lsa_hip.CsrMatrix.from_scipy(hip_ctx, I), 0.5, pc_type=2)
+        kb = lsa_hip.KrylovBasis(hip_ctx, op, 12)
+        kb.inject(0, v)
+        H = np.zeros((13, 12), dtype=np.complex128, order="F")
+        got[b] = (kb.extend(0, 12, H), H.copy(), op.stats()["op_applies"])
+    assert got[1][0] == got[batch][0] == 2  # three vectors span the subspace: the third step breaks down
+    assert np.array_equal(got[1][1][:, :3], got[batch][1][:, :3]) and got[1][2] == got[batch][2] == 3

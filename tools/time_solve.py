@@ -17,6 +17,7 @@ from Solver.utils import PreconditionerType, iSTType  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--case", default="S30k")
 ap.add_argument("--pc", default="lu")
+ap.add_argument("--plain", action="store_true", help="no cProfile pass: the last thing the process does is one plain warm solve")
 ap.add_argument("--torch", action="store_true", help="initialise PyTorch's HIP context first, as bench.py does")
 args = ap.parse_args()
 if args.torch:
@@ -42,6 +43,11 @@ for _ in range(3):
 t0 = time.time()
 solver.solve()
 print(f"warm EigenSolver.solve() {time.time() - t0:.3f} s")
+if args.plain:
+    t0 = time.time()
+    inner.solve()
+    print(f"last solve {1e3 * (time.time() - t0):.1f} ms; stats {inner.stats}")
+    sys.exit(0)
 pr = cProfile.Profile()
 pr.enable()
 solver.solve()

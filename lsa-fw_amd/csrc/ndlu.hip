@@ -353,6 +353,182 @@ __global__ __launch_bounds__(256) void nd_gj_gemm_kernel(const int32_t* __restri
     }
 }
 
+// ---- tournament pivoting for tall pivot blocks --------------------------------------------------------------------------
+// The panel launches above search a whole column in ONE workgroup: for a 6 000-row pivot block that is 16 dependent launch
+// pairs per 32 columns, each reading its column with a stride of a front row.  Levels whose tallest pivot block has
+// LSA_ND_TP_MIN rows or more choose the 32 pivot rows of a block by a tournament instead (communication-avoiding LU,
+// Grigori, Demmel, Xiang 2011): every 256 rows pick their 32 best rows by Gaussian elimination with partial pivoting on
+// their slice of the block's columns (thread per row, the row in registers); winners meet four sets at a time until one
+// set is left; the last workgroup inverts the 32 x 32 pivot tile.  The block's columns then are one small product per row
+// (nd_tp_colblock_kernel), and the staged rank-32 product above does the rest: 5-7 launches per 32 columns, all of them
+// wide.  The pivot rows reach ipiv / rowq as with the panel launches, so everything downstream is unchanged.
+constexpr int kTR = 256;  // rows per workgroup in the first round
+constexpr int kTA = 4;    // candidate sets per workgroup in the later rounds
+
+__host__ __device__ inline int32_t tp_sets(int32_t m, int32_t round) {  // candidate sets of a pivot block before merge round `round`
+    int32_t n = (m + kTR - 1) / kTR;
+    for (int32_t r = 0; r < round; ++r) n = (n + kTA - 1) / kTA;
+    return n;
+}
+
+template <typename T, bool FIRST, bool LAST>
+__global__ __launch_bounds__(256) void nd_tp_round_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
+                                                          const T* __restrict__ front, int32_t* __restrict__ ipiv, int32_t* __restrict__ rowq, int32_t kb,
+                                                          int32_t round, const int32_t* __restrict__ cand_in, int32_t* __restrict__ cand_out,
+                                                          T* __restrict__ dinv, int32_t* __restrict__ flag, double tiny2) {
+    __shared__ unsigned long long skey[2];
+    __shared__ T prow_s[2][kNB];
+    __shared__ int32_t sel_s[kNB];
+    __shared__ T Ds[LAST ? kNB : 1][kNB + 1];
+    const int32_t t = lvl_nodes[blockIdx.x];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, ld = nd.f;
+    const int32_t w = min(kNB, m - kb);
+    if (w <= 0) return;
+    const int32_t g = (int32_t)blockIdx.y;  // output set
+    const int32_t nin = FIRST ? (m + kTR - 1) / kTR : tp_sets(m, round);
+    if (FIRST ? g >= nin : g * kTA >= nin) return;
+    const T* a = front + nd.front_off;
+    const int32_t* rq = rowq + nd.piv_off;
+    const int64_t coff = ((int64_t)(nd.piv_off / kTR) + t) * kNB;
+    const int tid = threadIdx.x, lane = tid & 63;
+    int32_t row = -1;
+    if (FIRST) {
+        const int32_t i = g * kTR + tid;
+        if (i < m && rq[i] < 0) row = i;
+    } else {
+        const int32_t s = g * kTA + (tid >> 5);
+        if ((tid >> 5) < kTA && s < nin) row = cand_in[coff + (int64_t)s * kNB + (tid & 31)];
+    }
+    T v[kNB];
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) v[c] = (row >= 0 && c < w) ? a[(size_t)row * ld + kb + c] : scalar_traits<T>::zero();
+    if (tid < 2) skey[tid] = 0ull;
+    if (tid < kNB) sel_s[tid] = -1;
+    bool alive = row >= 0;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kNB; ++j) {  // (no early exit: the loop must unroll for v[] to stay in registers; w is uniform)
+        unsigned long long key = (alive && j < w) ? pivot_key(s_abs2(v[j]), tid) : 0ull;
+        key = wave_max_key(key);
+        if (lane == 0 && key) atomicMax(&skey[j & 1], key);
+        __syncthreads();
+        key = skey[j & 1];
+        if (tid == 0) skey[(j + 1) & 1] = 0ull;
+        const bool mine = key != 0ull && tid == 65535 - (int32_t)(key & 0xFFFFull);
+        if (mine) {
+#pragma unroll
+            for (int c = 0; c < kNB; ++c) prow_s[j & 1][c] = v[c];
+            sel_s[j] = row;
+            alive = false;
+        }
+        __syncthreads();
+        if (key != 0ull && alive) {
+            const T pv = prow_s[j & 1][j];
+            if (s_abs2(pv) > 0.0) {
+                const T nf = s_sub(scalar_traits<T>::zero(), s_mul(v[j], s_inv(pv)));
+#pragma unroll
+                for (int c = 0; c < kNB; ++c)
+                    if (c > j) fma_acc(v[c], nf, prow_s[j & 1][c]);
+            }
+        }
+    }
+    __syncthreads();
+    if (!LAST) {
+        if (tid < kNB) cand_out[coff + (int64_t)g * kNB + tid] = sel_s[tid];
+        return;
+    }
+    // the winners are the pivot rows of columns kb .. kb + w - 1, in the order the elimination took them: invert their tile
+    for (int e = tid; e < kNB * kNB; e += 256) {
+        const int j = e / kNB, c = e - j * kNB;
+        const int32_t pr = sel_s[j];
+        T d = scalar_traits<T>::zero();
+        if (j < w && c < w && pr >= 0) d = a[(size_t)pr * ld + kb + c];
+        if (j == c && (j >= w || pr < 0)) s_from(d, 1.0, 0.0);
+        Ds[j][c] = d;
+    }
+    __syncthreads();
+    if (tid < w && sel_s[tid] < 0 && atomicCAS(&flag[1], 0, t + 1) == 0) {  // fewer rows left than columns: cannot happen for a square block
+        flag[2] = kb + tid;
+        flag[3] = 0;
+    }
+    for (int k = 0; k < w; ++k) {
+        T rk[4], fi[4], cur[4];
+        const T pv0 = Ds[k][k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, i = e / kNB, c = e - i * kNB;
+            rk[q] = Ds[k][c];
+            fi[q] = Ds[i][k];
+            cur[q] = Ds[i][c];
+        }
+        __syncthreads();
+        const double mag2 = s_abs2(pv0);
+        if (tid == 0 && !(mag2 > tiny2) && atomicCAS(&flag[1], 0, t + 1) == 0) {
+            flag[2] = kb + k;
+            flag[3] = (int32_t)((unsigned long long)__double_as_longlong(mag2) >> 32);
+        }
+        T pv = pv0;
+        if (mag2 == 0.0) s_from(pv, 1.0, 0.0);
+        const T pinv = s_inv(pv);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = tid + 256 * q, i = e / kNB, c = e - i * kNB;
+            T out;
+            if (i == k) out = (c == k) ? pinv : s_mul(pinv, rk[q]);
+            else if (c == k) out = s_sub(scalar_traits<T>::zero(), s_mul(fi[q], pinv));
+            else out = s_sub(cur[q], s_mul(fi[q], s_mul(pinv, rk[q])));
+            Ds[i][c] = out;
+        }
+        __syncthreads();
+    }
+    T* dv = dinv + (size_t)blockIdx.x * (kNB * kNB);
+    for (int e = tid; e < kNB * kNB; e += 256) dv[e] = Ds[e / kNB][e % kNB];
+    if (tid < w && sel_s[tid] >= 0) {
+        ipiv[nd.piv_off + kb + tid] = sel_s[tid];
+        rowq[nd.piv_off + sel_s[tid]] = kb + tid;
+    }
+}
+
+// the block's own columns after its pivot tile is inverted:  pivot row j <- row j of D^-1,  any other row <- -A[row, K] D^-1
+// grid: (node, 256-row tile), thread per row
+template <typename T>
+__global__ __launch_bounds__(256) void nd_tp_colblock_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
+                                                             T* __restrict__ front, const int32_t* __restrict__ rowq, int32_t kb,
+                                                             const T* __restrict__ dinv) {
+    __shared__ T Ds[kNB][kNB + 1];
+    const int32_t t = lvl_nodes[blockIdx.x];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, ld = nd.f;
+    const int32_t w = min(kNB, m - kb);
+    const int32_t r0 = (int32_t)blockIdx.y * 256;
+    if (w <= 0 || r0 >= m) return;
+    const T* dv = dinv + (size_t)blockIdx.x * (kNB * kNB);
+    for (int e = threadIdx.x; e < kNB * kNB; e += 256) Ds[e / kNB][e % kNB] = dv[e];
+    __syncthreads();
+    const int32_t i = r0 + threadIdx.x;
+    if (i >= m) return;
+    T* ai = front + nd.front_off + (size_t)i * ld + kb;
+    const int32_t q = rowq[nd.piv_off + i];
+    if (q >= kb && q < kb + w) {
+#pragma unroll
+        for (int c = 0; c < kNB; ++c)
+            if (c < w) ai[c] = Ds[q - kb][c];
+        return;
+    }
+    T x[kNB];
+#pragma unroll
+    for (int c = 0; c < kNB; ++c) x[c] = c < w ? ai[c] : scalar_traits<T>::zero();
+#pragma unroll 4
+    for (int c = 0; c < kNB; ++c) {
+        if (c >= w) break;
+        T acc = scalar_traits<T>::zero();
+#pragma unroll
+        for (int j = 0; j < kNB; ++j) fma_acc(acc, x[j], Ds[j][c]);
+        ai[c] = s_sub(scalar_traits<T>::zero(), acc);
+    }
+}
+
 // inverse gathered out of the eliminated block: inv[a][b] = S[p_a][q_b]  (p = pivot row of column a, q = its inverse)
 template <typename T>
 __global__ __launch_bounds__(256) void nd_unperm_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
@@ -673,6 +849,9 @@ struct lsa_ndlu {
     int32_t *d_ipiv = nullptr, *d_rowq = nullptr, *d_flag = nullptr, *d_xflag = nullptr;
     unsigned long long* d_maxabs = nullptr;
     void *d_front = nullptr, *d_scratch = nullptr, *d_ubuf = nullptr, *d_tmp = nullptr, *d_ybuf = nullptr, *d_ysm = nullptr;
+    int32_t *d_cand[2] = {nullptr, nullptr};  // tournament pivoting: candidate rows, two buffers used in turn
+    void* d_dinv = nullptr;                    // ... the inverted pivot tile of every node of the level being eliminated
+    int32_t tp_min = 1 << 30;                  // levels whose tallest pivot block has at least this many rows use it
     double seconds_analyse = 0.0, seconds_numeric = 0.0;
     int32_t solve_launches = 0;
 };
@@ -683,7 +862,7 @@ void nd_free(lsa_ndlu* f) {
     if (!f) return;
     for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
                     (void*)f->d_lvl_nodes, (void*)f->d_asm_dst, (void*)f->d_asm_src, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_xflag, (void*)f->d_maxabs,
-                    f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp, f->d_ybuf, f->d_ysm})
+                    f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp, f->d_ybuf, f->d_ysm, (void*)f->d_cand[0], (void*)f->d_cand[1], f->d_dinv})
         if (p) (void)hipFree(p);
     delete f;
 }
@@ -815,6 +994,19 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_tmp, nn * 16));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ybuf, nn * kNB * es));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ysm, (size_t)std::max(nt, 1) * 8 * kNB * es));
+    {
+        const char* e = getenv("LSA_ND_TP_MIN");
+        f->tp_min = e && *e ? std::max(1, atoi(e)) : 384;
+        int32_t widest = 0;  // nodes of the most populous level that eliminates by tournament
+        for (const NdLevel& L : f->levels)
+            if (L.max_m >= f->tp_min) widest = std::max(widest, L.node_count);
+        if (widest > 0) {
+            const size_t cand = ((size_t)S.n / kTR + (size_t)nt + 1) * kNB * sizeof(int32_t);
+            LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[0], cand));
+            LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[1], cand));
+            LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_dinv, (size_t)widest * kNB * kNB * es));
+        }
+    }
     f->solve_launches = 0;
     for (const NdLevel& L : f->levels) f->solve_launches += (L.fwd_tiles > 0) + (L.bwd_tiles > 0);
     return LSA_OK;
@@ -840,6 +1032,40 @@ void launch_block(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t kb, doubl
     }
     if (L.max_m > kNB) {  // columns outside the block exist (in the larger nodes)
         const int32_t active = active_at(kb);
+        hipLaunchKernelGGL((nd_gj_stage_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, kb,
+                           (T*)f->d_ybuf);
+        const int32_t tiles = (L.max_m + kGT - 1) / kGT;
+        hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, tiles), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb, (const T*)f->d_ybuf);
+    }
+}
+
+// one block of kNB columns of every pivot block of the level, pivot rows chosen by tournament
+template <typename T>
+void launch_block_tp(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t kb, double tiny2) {
+    hipStream_t st = ctx->stream;
+    const int32_t* lv = f->d_lvl_nodes + L.node_begin;
+    T* front = (T*)f->d_front;
+    const int32_t active = (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), kb, std::greater<int32_t>()) - L.sorted_m.begin());
+    if (active == 0) return;
+    int32_t sets = (L.max_m + kTR - 1) / kTR;
+    hipLaunchKernelGGL((nd_tp_round_kernel<T, true, false>), dim3(active, sets), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, f->d_rowq, kb, 0,
+                       (const int32_t*)nullptr, f->d_cand[0], (T*)nullptr, f->d_flag, tiny2);
+    int src = 0;
+    for (int32_t round = 0;; ++round) {
+        const int32_t groups = (sets + kTA - 1) / kTA;
+        if (groups == 1) {
+            hipLaunchKernelGGL((nd_tp_round_kernel<T, false, true>), dim3(active, 1), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, f->d_rowq, kb,
+                               round, (const int32_t*)f->d_cand[src], (int32_t*)nullptr, (T*)f->d_dinv, f->d_flag, tiny2);
+            break;
+        }
+        hipLaunchKernelGGL((nd_tp_round_kernel<T, false, false>), dim3(active, groups), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, f->d_rowq,
+                           kb, round, (const int32_t*)f->d_cand[src], f->d_cand[src ^ 1], (T*)nullptr, f->d_flag, tiny2);
+        src ^= 1;
+        sets = groups;
+    }
+    hipLaunchKernelGGL((nd_tp_colblock_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb,
+                       (const T*)f->d_dinv);
+    if (L.max_m > kNB) {
         hipLaunchKernelGGL((nd_gj_stage_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, kb,
                            (T*)f->d_ybuf);
         const int32_t tiles = (L.max_m + kGT - 1) / kGT;
@@ -882,7 +1108,8 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
         for (const TileList& e : L.ext)
             if (e.count > 0) hipLaunchKernelGGL((nd_extend_add_kernel<T>), dim3(e.count), dim3(256), 0, st, tl + 2 * e.off, f->d_nodes, f->d_cmap, front);
         for (int32_t kb = 0; kb < L.max_m; kb += kNB) {
-            if (L.max_m <= 64) launch_block<T, 64, 1, 8>(ctx, f, L, kb, tiny2);
+            if (L.max_m >= f->tp_min) launch_block_tp<T>(ctx, f, L, kb, tiny2);
+            else if (L.max_m <= 64) launch_block<T, 64, 1, 8>(ctx, f, L, kb, tiny2);
             else if (L.max_m <= 128) launch_block<T, 128, 1, 8>(ctx, f, L, kb, tiny2);
             else if (L.max_m <= 256) launch_block<T, 256, 1, 8>(ctx, f, L, kb, tiny2);
             else if (L.max_m <= 512) launch_block<T, 512, 1, 8>(ctx, f, L, kb, tiny2);

@@ -62,6 +62,7 @@ struct NdLevel {
     std::vector<int32_t> sorted_m;          // own sizes of the level's nodes (descending)
     TileList unperm, gemm[3], copyback;
     int32_t fwd_tiles = 0, bwd_tiles = 0;  // grid.y of the sweep kernels: tiles of the tallest node (0 = nothing to do)
+    int32_t sweep_rows = 32;               // rows per sweep tile: 32, or 8 on levels with few tiles
     std::vector<TileList> ext;  // one per child rank
     int64_t scratch = 0;
 };
@@ -642,9 +643,9 @@ __global__ __launch_bounds__(256) void nd_copyback_kernel(const int32_t* __restr
     }
 }
 
-template <typename VT>
-__device__ __forceinline__ VT sub16_sum(VT v) {
-    for (int o = 8; o > 0; o >>= 1) {
+template <int LANES = 16, typename VT>
+__device__ __forceinline__ VT sub16_sum(VT v) {  // sum over the LANES lanes of a sub-wave
+    for (int o = LANES / 2; o > 0; o >>= 1) {
         if constexpr (sizeof(VT) == 16) {
             v.re += __shfl_xor(v.re, o);
             v.im += __shfl_xor(v.im, o);
@@ -657,27 +658,53 @@ __device__ __forceinline__ VT sub16_sum(VT v) {
 
 // acc0 += Fa[0:cn] . vs, acc1 += Fb[0:cn] . vs over the 16 lanes of a sub-wave; eight row loads in flight per lane (the
 // sweeps are chains of short kernels: what they wait for is memory latency, not bandwidth)
-template <typename MT, typename VT>
+template <int LPR = 16, typename MT, typename VT>
 __device__ __forceinline__ void two_row_dot(const MT* __restrict__ Fa, const MT* __restrict__ Fb, const VT* vs, int32_t cn, int sl, VT& acc0,
                                             VT& acc1) {
     int32_t k = sl;
-    for (; k + 48 < cn; k += 64) {
-        const MT a0 = Fa[k], a1 = Fa[k + 16], a2 = Fa[k + 32], a3 = Fa[k + 48];
-        const MT b0 = Fb[k], b1 = Fb[k + 16], b2 = Fb[k + 32], b3 = Fb[k + 48];
+    for (; k + 3 * LPR < cn; k += 4 * LPR) {
+        const MT a0 = Fa[k], a1 = Fa[k + LPR], a2 = Fa[k + 2 * LPR], a3 = Fa[k + 3 * LPR];
+        const MT b0 = Fb[k], b1 = Fb[k + LPR], b2 = Fb[k + 2 * LPR], b3 = Fb[k + 3 * LPR];
         fma_acc(acc0, a0, vs[k]);
         fma_acc(acc1, b0, vs[k]);
-        fma_acc(acc0, a1, vs[k + 16]);
-        fma_acc(acc1, b1, vs[k + 16]);
-        fma_acc(acc0, a2, vs[k + 32]);
-        fma_acc(acc1, b2, vs[k + 32]);
-        fma_acc(acc0, a3, vs[k + 48]);
-        fma_acc(acc1, b3, vs[k + 48]);
+        fma_acc(acc0, a1, vs[k + LPR]);
+        fma_acc(acc1, b1, vs[k + LPR]);
+        fma_acc(acc0, a2, vs[k + 2 * LPR]);
+        fma_acc(acc1, b2, vs[k + 2 * LPR]);
+        fma_acc(acc0, a3, vs[k + 3 * LPR]);
+        fma_acc(acc1, b3, vs[k + 3 * LPR]);
     }
-    for (; k < cn; k += 16) {
+    for (; k < cn; k += LPR) {
         const MT a0 = Fa[k], b0 = Fb[k];
         fma_acc(acc0, a0, vs[k]);
         fma_acc(acc1, b0, vs[k]);
     }
+}
+
+// the first 4 * LPR columns of a row pair, loaded before the vector they multiply is ready (the sweeps are chains of
+// dependent loads: node record -> gather table -> update vectors -> front rows; the rows depend only on the first)
+template <int LPR, typename MT>
+__device__ __forceinline__ void row_pair_prefetch(const MT* __restrict__ Fa, const MT* __restrict__ Fb, int32_t cn, int sl, MT (&pa)[4], MT (&pb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int32_t k = sl + q * LPR;
+        pa[q] = k < cn ? Fa[k] : scalar_traits<MT>::zero();
+        pb[q] = k < cn ? Fb[k] : scalar_traits<MT>::zero();
+    }
+}
+
+template <int LPR, typename MT, typename VT>
+__device__ __forceinline__ void two_row_dot_prefetched(const MT* __restrict__ Fa, const MT* __restrict__ Fb, const VT* vs, int32_t cn, int sl, VT& acc0,
+                                                       VT& acc1, const MT (&pa)[4], const MT (&pb)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int32_t k = sl + q * LPR;
+        if (k < cn) {
+            fma_acc(acc0, pa[q], vs[k]);
+            fma_acc(acc1, pb[q], vs[k]);
+        }
+    }
+    if (cn > 4 * LPR) two_row_dot<LPR>(Fa + 4 * LPR, Fb + 4 * LPR, vs + 4 * LPR, cn - 4 * LPR, sl, acc0, acc1);
 }
 
 // sum of the children's update-vector entries that land on front position j (fixed order: child rank)
@@ -701,73 +728,87 @@ __device__ __forceinline__ VT gather_updates(const int32_t* __restrict__ ge, int
     return v;
 }
 
-// upward sweep, one tree level: workgroup (x = node of the level, y = tile of kRT rows of its [F11; F21] block column)
-template <typename MT, typename VT>
+// upward sweep, one tree level: workgroup (x = node of the level, y = tile of 512 / LPR rows of its [F11; F21] block column);
+// LPR lanes run along a pair of rows: 16 (32 rows per workgroup) where the level has many tiles, 64 (8 rows) near the top
+// of the tree, where a few tall fronts must still be spread over the whole chip
+template <typename MT, typename VT, int LPR>
 __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ front,
                                                      const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
                                                      const VT* __restrict__ rhs, VT* __restrict__ x, VT* __restrict__ ubuf) {
     __shared__ VT vs[kCH];
     const NdNodeDev nd = lnodes[blockIdx.x];
-    const int32_t r0 = (int32_t)blockIdx.y * kRT;
+    const int32_t r0 = (int32_t)blockIdx.y * (512 / LPR);
     const int32_t m = nd.m, f = nd.f;
     if (r0 >= f) return;
     const int32_t* ix = idx + nd.idx_off;
     const int32_t* ge = gell + nd.ge_off;
     const MT* F = front + nd.front_off;
-    const int tid = threadIdx.x, sw = tid >> 4, sl = tid & 15;
-    const int32_t ra = r0 + sw, rb = r0 + sw + 16;
+    const int tid = threadIdx.x, sw = tid / LPR, sl = tid % LPR;
+    const int32_t ra = r0 + sw, rb = r0 + sw + 256 / LPR;
     const MT* Fa = F + (size_t)min(ra, f - 1) * f;
     const MT* Fb = F + (size_t)min(rb, f - 1) * f;
     VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
+    // everything that depends only on the node record is requested first: the head of the two rows, and what the children
+    // add to the update entries these rows produce
+    MT pa[4], pb[4];
+    row_pair_prefetch<LPR>(Fa, Fb, min(kCH, m), sl, pa, pb);
+    VT ua = scalar_traits<VT>::zero(), ub = scalar_traits<VT>::zero();
+    int32_t oa = -1, ob = -1;
+    if (sl == 0) {
+        if (ra < m) oa = ix[ra];
+        else if (ra < f) ua = gather_updates(ge, nd.nchild, f, ra, ubuf, ua);
+        if (rb < m) ob = ix[rb];
+        else if (rb < f) ub = gather_updates(ge, nd.nchild, f, rb, ubuf, ub);
+    }
     for (int32_t c0 = 0; c0 < m; c0 += kCH) {
         const int32_t cn = min(kCH, m - c0);
         for (int32_t j = tid; j < cn; j += 256) vs[j] = gather_updates(ge, nd.nchild, f, c0 + j, ubuf, rhs[ix[c0 + j]]);
         __syncthreads();
-        two_row_dot(Fa + c0, Fb + c0, vs, cn, sl, acc0, acc1);
+        if (c0 == 0) two_row_dot_prefetched<LPR>(Fa, Fb, vs, cn, sl, acc0, acc1, pa, pb);
+        else two_row_dot<LPR>(Fa + c0, Fb + c0, vs, cn, sl, acc0, acc1);
         __syncthreads();
     }
-    acc0 = sub16_sum(acc0);
-    acc1 = sub16_sum(acc1);
+    acc0 = sub16_sum<LPR>(acc0);
+    acc1 = sub16_sum<LPR>(acc1);
     if (sl == 0) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int32_t r = h ? rb : ra;
-            const VT a = h ? acc1 : acc0;
-            if (r >= f) continue;
-            if (r < m) x[ix[r]] = a;
-            else ubuf[nd.u_off + (r - m)] = gather_updates(ge, nd.nchild, f, r, ubuf, a);
-        }
+        if (ra < m) x[oa] = acc0;
+        else if (ra < f) ubuf[nd.u_off + (ra - m)] = s_add(ua, acc0);
+        if (rb < m) x[ob] = acc1;
+        else if (rb < f) ubuf[nd.u_off + (rb - m)] = s_add(ub, acc1);
     }
 }
 
 // downward sweep, one tree level: x[own] -= F12 x[boundary]
-template <typename MT, typename VT>
+template <typename MT, typename VT, int LPR>
 __global__ __launch_bounds__(256) void nd_bwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ front,
                                                      const int32_t* __restrict__ idx, VT* __restrict__ x) {
     __shared__ VT vs[kCH];
     const NdNodeDev nd = lnodes[blockIdx.x];
-    const int32_t r0 = (int32_t)blockIdx.y * kRT;
+    const int32_t r0 = (int32_t)blockIdx.y * (512 / LPR);
     const int32_t m = nd.m, f = nd.f, b = f - m;
     if (r0 >= m || b == 0) return;
     const int32_t* ix = idx + nd.idx_off;
     const MT* F = front + nd.front_off + m;
-    const int tid = threadIdx.x, sw = tid >> 4, sl = tid & 15;
-    const int32_t ra = r0 + sw, rb = r0 + sw + 16;
+    const int tid = threadIdx.x, sw = tid / LPR, sl = tid % LPR;
+    const int32_t ra = r0 + sw, rb = r0 + sw + 256 / LPR;
     const MT* Fa = F + (size_t)min(ra, m - 1) * f;
     const MT* Fb = F + (size_t)min(rb, m - 1) * f;
     // the rows' own entries are needed only at the end: issue their loads before the sweep over the boundary
     const int32_t ia = ix[min(ra, m - 1)], ib = ix[min(rb, m - 1)];
     const VT xa = x[ia], xb = x[ib];
     VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
+    MT pa[4], pb[4];
+    row_pair_prefetch<LPR>(Fa, Fb, min(kCH, b), sl, pa, pb);
     for (int32_t c0 = 0; c0 < b; c0 += kCH) {
         const int32_t cn = min(kCH, b - c0);
         for (int32_t j = tid; j < cn; j += 256) vs[j] = x[ix[m + c0 + j]];
         __syncthreads();
-        two_row_dot(Fa + c0, Fb + c0, vs, cn, sl, acc0, acc1);
+        if (c0 == 0) two_row_dot_prefetched<LPR>(Fa, Fb, vs, cn, sl, acc0, acc1, pa, pb);
+        else two_row_dot<LPR>(Fa + c0, Fb + c0, vs, cn, sl, acc0, acc1);
         __syncthreads();
     }
-    acc0 = sub16_sum(acc0);
-    acc1 = sub16_sum(acc1);
+    acc0 = sub16_sum<LPR>(acc0);
+    acc1 = sub16_sum<LPR>(acc1);
     if (sl == 0) {
         if (ra < m) x[ia] = s_sub(xa, acc0);
         if (rb < m) x[ib] = s_sub(xb, acc1);
@@ -954,13 +995,20 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
                     for (int32_t tn = 0; tn * kGT < N; ++tn) push(L.gemm[kind], t, (tm << 16) | tn);
             }
         }
+        {
+            // the sweeps wait for memory: a level whose fronts make fewer 32-row tiles than a few per CU gets 8-row tiles
+            int64_t tiles32 = 0;
+            for (int32_t q = 0; q < L.node_count; ++q) tiles32 += (S.f[(size_t)S.lvl_nodes[(size_t)L.node_begin + q]] + kRT - 1) / kRT;
+            static const int64_t few = getenv("LSA_ND_SWEEP_FEW") ? atoll(getenv("LSA_ND_SWEEP_FEW")) : 4 * (int64_t)ctx->num_cu;
+            L.sweep_rows = tiles32 <= few ? 8 : kRT;
+        }
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            L.fwd_tiles = std::max(L.fwd_tiles, (S.f[(size_t)t] + kRT - 1) / kRT);
+            L.fwd_tiles = std::max(L.fwd_tiles, (S.f[(size_t)t] + L.sweep_rows - 1) / L.sweep_rows);
             L.max_f = std::max(L.max_f, S.f[(size_t)t]);
-            if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.m[(size_t)t] + kRT - 1) / kRT);
+            if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.m[(size_t)t] + L.sweep_rows - 1) / L.sweep_rows);
         }
-        if (L.fwd_tiles > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a front of more than %d rows is not supported", 65535 * kRT);
+        if (L.fwd_tiles > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a front of more than %d rows is not supported", 65535 * 8);
         begin_list(L.copyback);
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
@@ -1180,14 +1228,23 @@ int nd_apply(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
         if ((int32_t)li == S.phase_b_level && S.nranks > 1 && S.xu_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, f->d_ubuf, (size_t)S.xu_slot * sizeof(VT)));
         if (li == f->levels.size()) break;
         const NdLevel& L = f->levels[li];
-        if (L.fwd_tiles > 0)
-            hipLaunchKernelGGL((nd_fwd_kernel<MT, VT>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,
-                               f->d_gell, b, x, (VT*)f->d_ubuf);
+        if (L.fwd_tiles > 0) {
+            if (L.sweep_rows == 8)
+                hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 64>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,
+                                   f->d_gell, b, x, (VT*)f->d_ubuf);
+            else
+                hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 16>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,
+                                   f->d_gell, b, x, (VT*)f->d_ubuf);
+        }
     }
     for (size_t l = f->levels.size(); l-- > 0;) {
         const NdLevel& L = f->levels[l];
-        if (L.bwd_tiles > 0)
-            hipLaunchKernelGGL((nd_bwd_kernel<MT, VT>), dim3(L.node_count, L.bwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx, x);
+        if (L.bwd_tiles > 0) {
+            if (L.sweep_rows == 8)
+                hipLaunchKernelGGL((nd_bwd_kernel<MT, VT, 64>), dim3(L.node_count, L.bwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx, x);
+            else
+                hipLaunchKernelGGL((nd_bwd_kernel<MT, VT, 16>), dim3(L.node_count, L.bwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx, x);
+        }
     }
     LSA_HIP_CHECK(ctx, hipGetLastError());
     return LSA_OK;

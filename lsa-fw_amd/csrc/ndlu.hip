@@ -105,15 +105,33 @@ __global__ __launch_bounds__(256) void nd_extend_add_kernel(const int32_t* __res
     }
 }
 
-// max of a 64-bit key over the wavefront (butterfly through LDS-free shuffles)
+// max of a 64-bit key over the wavefront, returned to every lane: DPP steps inside each row of 16 lanes (a ds_bpermute
+// butterfly costs ~100 cycles per step, and the pivot searches are chains of them), then the four row maxima through SGPRs
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_mov_key(unsigned long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v & 0xFFFFFFFFull), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, false);
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+}
 __device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)(v & 0xFFFFFFFFull), o);
-        const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), o);
-        const unsigned long long ov = ((unsigned long long)hi << 32) | lo;
-        v = ov > v ? ov : v;
+    unsigned long long o;
+    o = dpp_mov_key<0xB1>(v);  // quad_perm [1,0,3,2]
+    v = o > v ? o : v;
+    o = dpp_mov_key<0x4E>(v);  // quad_perm [2,3,0,1]
+    v = o > v ? o : v;
+    o = dpp_mov_key<0x141>(v);  // row_half_mirror
+    v = o > v ? o : v;
+    o = dpp_mov_key<0x140>(v);  // row_mirror: every lane of a row now holds the row's max
+    v = o > v ? o : v;
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xFFFFFFFFull), 16 * row);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), 16 * row);
+        const unsigned long long r = ((unsigned long long)hi << 32) | lo;
+        best = r > best ? r : best;
     }
-    return v;
+    return best;
 }
 
 __device__ __forceinline__ unsigned long long pivot_key(double mag2, int32_t row) {
@@ -363,11 +381,18 @@ __global__ __launch_bounds__(256) void nd_gj_gemm_kernel(const int32_t* __restri
 // set is left; the last workgroup inverts the 32 x 32 pivot tile.  The block's columns then are one small product per row
 // (nd_tp_colblock_kernel), and the staged rank-32 product above does the rest: 5-7 launches per 32 columns, all of them
 // wide.  The pivot rows reach ipiv / rowq as with the panel launches, so everything downstream is unchanged.
-constexpr int kTR = 256;  // rows per workgroup in the first round
-constexpr int kTA = 4;    // candidate sets per workgroup in the later rounds
+constexpr int kTA = 8;  // candidate sets per workgroup in the later rounds (8 x 32 rows, thread per row)
 
-__host__ __device__ inline int32_t tp_sets(int32_t m, int32_t round) {  // candidate sets of a pivot block before merge round `round`
-    int32_t n = (m + kTR - 1) / kTR;
+// rows per workgroup in the first round: thread per row, or two rows per thread where 64 more registers are to be had
+template <typename T>
+struct tp_first {
+    static constexpr int RPT = sizeof(T) == 16 ? 1 : 2;
+    static constexpr int rows = 256 * RPT;
+};
+constexpr int kTRmin = 256;  // smallest first-round chunk: sizes the candidate buffers
+
+__host__ __device__ inline int32_t tp_sets(int32_t m, int32_t first_rows, int32_t round) {  // candidate sets of a pivot block before merge round `round`
+    int32_t n = (m + first_rows - 1) / first_rows;
     for (int32_t r = 0; r < round; ++r) n = (n + kTA - 1) / kTA;
     return n;
 }
@@ -377,6 +402,7 @@ __global__ __launch_bounds__(256) void nd_tp_round_kernel(const int32_t* __restr
                                                           const T* __restrict__ front, int32_t* __restrict__ ipiv, int32_t* __restrict__ rowq, int32_t kb,
                                                           int32_t round, const int32_t* __restrict__ cand_in, int32_t* __restrict__ cand_out,
                                                           T* __restrict__ dinv, int32_t* __restrict__ flag, double tiny2) {
+    constexpr int RPT = FIRST ? tp_first<T>::RPT : 1;
     __shared__ unsigned long long skey[2];
     __shared__ T prow_s[2][kNB];
     __shared__ int32_t sel_s[kNB];
@@ -387,50 +413,78 @@ __global__ __launch_bounds__(256) void nd_tp_round_kernel(const int32_t* __restr
     const int32_t w = min(kNB, m - kb);
     if (w <= 0) return;
     const int32_t g = (int32_t)blockIdx.y;  // output set
-    const int32_t nin = FIRST ? (m + kTR - 1) / kTR : tp_sets(m, round);
+    const int32_t nin = tp_sets(m, tp_first<T>::rows, FIRST ? 0 : round);
     if (FIRST ? g >= nin : g * kTA >= nin) return;
     const T* a = front + nd.front_off;
     const int32_t* rq = rowq + nd.piv_off;
-    const int64_t coff = ((int64_t)(nd.piv_off / kTR) + t) * kNB;
+    const int64_t coff = ((int64_t)(nd.piv_off / kTRmin) + t) * kNB;
     const int tid = threadIdx.x, lane = tid & 63;
-    int32_t row = -1;
+    // (two plain arrays, not v[RPT][kNB]: the two-dimensional form ends up in scratch memory)
+    int32_t row0 = -1, row1 = -1;
+    T v0[kNB], v1[kNB];
     if (FIRST) {
-        const int32_t i = g * kTR + tid;
-        if (i < m && rq[i] < 0) row = i;
+        const int32_t i0 = g * tp_first<T>::rows + tid, i1 = i0 + 256;
+        if (i0 < m && rq[i0] < 0) row0 = i0;
+        if (RPT == 2 && i1 < m && rq[i1] < 0) row1 = i1;
     } else {
         const int32_t s = g * kTA + (tid >> 5);
-        if ((tid >> 5) < kTA && s < nin) row = cand_in[coff + (int64_t)s * kNB + (tid & 31)];
+        if (s < nin) row0 = cand_in[coff + (int64_t)s * kNB + (tid & 31)];
     }
-    T v[kNB];
 #pragma unroll
-    for (int c = 0; c < kNB; ++c) v[c] = (row >= 0 && c < w) ? a[(size_t)row * ld + kb + c] : scalar_traits<T>::zero();
+    for (int c = 0; c < kNB; ++c) {
+        v0[c] = (row0 >= 0 && c < w) ? a[(size_t)row0 * ld + kb + c] : scalar_traits<T>::zero();
+        if constexpr (RPT == 2) v1[c] = (row1 >= 0 && c < w) ? a[(size_t)row1 * ld + kb + c] : scalar_traits<T>::zero();
+    }
+    bool alive0 = row0 >= 0, alive1 = RPT == 2 && row1 >= 0;
     if (tid < 2) skey[tid] = 0ull;
     if (tid < kNB) sel_s[tid] = -1;
-    bool alive = row >= 0;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < kNB; ++j) {  // (no early exit: the loop must unroll for v[] to stay in registers; w is uniform)
-        unsigned long long key = (alive && j < w) ? pivot_key(s_abs2(v[j]), tid) : 0ull;
+    for (int j = 0; j < kNB; ++j) {  // (no early exit: the loop must unroll for the rows to stay in registers; w is uniform)
+        unsigned long long key = (alive0 && j < w) ? pivot_key(s_abs2(v0[j]), tid) : 0ull;
+        if constexpr (RPT == 2) {
+            const unsigned long long k1 = (alive1 && j < w) ? pivot_key(s_abs2(v1[j]), 256 + tid) : 0ull;
+            key = k1 > key ? k1 : key;
+        }
         key = wave_max_key(key);
         if (lane == 0 && key) atomicMax(&skey[j & 1], key);
         __syncthreads();
         key = skey[j & 1];
         if (tid == 0) skey[(j + 1) & 1] = 0ull;
-        const bool mine = key != 0ull && tid == 65535 - (int32_t)(key & 0xFFFFull);
-        if (mine) {
+        const int32_t win = 65535 - (int32_t)(key & 0xFFFFull);  // (256 *) second row + tid of the winning row
+        if (key != 0ull && win == tid) {
 #pragma unroll
-            for (int c = 0; c < kNB; ++c) prow_s[j & 1][c] = v[c];
-            sel_s[j] = row;
-            alive = false;
+            for (int c = 0; c < kNB; ++c) prow_s[j & 1][c] = v0[c];
+            sel_s[j] = row0;
+            alive0 = false;
+        }
+        if constexpr (RPT == 2) {
+            if (key != 0ull && win == 256 + tid) {
+#pragma unroll
+                for (int c = 0; c < kNB; ++c) prow_s[j & 1][c] = v1[c];
+                sel_s[j] = row1;
+                alive1 = false;
+            }
         }
         __syncthreads();
-        if (key != 0ull && alive) {
+        if (key != 0ull) {
             const T pv = prow_s[j & 1][j];
             if (s_abs2(pv) > 0.0) {
-                const T nf = s_sub(scalar_traits<T>::zero(), s_mul(v[j], s_inv(pv)));
+                const T pinv = s_inv(pv);
+                if (alive0) {
+                    const T nf = s_sub(scalar_traits<T>::zero(), s_mul(v0[j], pinv));
 #pragma unroll
-                for (int c = 0; c < kNB; ++c)
-                    if (c > j) fma_acc(v[c], nf, prow_s[j & 1][c]);
+                    for (int c = 0; c < kNB; ++c)
+                        if (c > j) fma_acc(v0[c], nf, prow_s[j & 1][c]);
+                }
+                if constexpr (RPT == 2) {
+                    if (alive1) {
+                        const T nf = s_sub(scalar_traits<T>::zero(), s_mul(v1[j], pinv));
+#pragma unroll
+                        for (int c = 0; c < kNB; ++c)
+                            if (c > j) fma_acc(v1[c], nf, prow_s[j & 1][c]);
+                    }
+                }
             }
         }
     }
@@ -920,6 +974,10 @@ int upload(lsa_ctx* ctx, const std::vector<U>& h, U** d) {
 int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     const NdSymbolic& S = f->S;
     const int32_t nt = S.nt;
+    {
+        const char* e = getenv("LSA_ND_TP_MIN");
+        f->tp_min = e && *e ? std::max(1, atoi(e)) : 384;
+    }
     std::vector<NdNodeDev> nodes((size_t)nt);
     std::vector<int32_t> tiles;
     f->levels.assign((size_t)S.nlevels, NdLevel());
@@ -1014,7 +1072,9 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
             for (int32_t r0 = 0; r0 < S.f[(size_t)t]; r0 += 16) push(L.copyback, t, r0);
         }
-        if (L.max_m > 16384) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a pivot block of %d rows exceeds the 16 384 the panel kernels hold in registers", L.max_m);
+        if (L.max_m > 16384 && L.max_m < f->tp_min)  // (the tournament path has no such limit)
+            return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a pivot block of %d rows exceeds the 16 384 the panel kernels hold in registers (LSA_ND_TP_MIN = %d)",
+                                 L.max_m, f->tp_min);
     }
     LSA_CHECK(upload(ctx, nodes, &f->d_nodes));
     {
@@ -1043,13 +1103,11 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ybuf, nn * kNB * es));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ysm, (size_t)std::max(nt, 1) * 8 * kNB * es));
     {
-        const char* e = getenv("LSA_ND_TP_MIN");
-        f->tp_min = e && *e ? std::max(1, atoi(e)) : 384;
         int32_t widest = 0;  // nodes of the most populous level that eliminates by tournament
         for (const NdLevel& L : f->levels)
             if (L.max_m >= f->tp_min) widest = std::max(widest, L.node_count);
         if (widest > 0) {
-            const size_t cand = ((size_t)S.n / kTR + (size_t)nt + 1) * kNB * sizeof(int32_t);
+            const size_t cand = ((size_t)S.n / kTRmin + (size_t)nt + 1) * kNB * sizeof(int32_t);
             LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[0], cand));
             LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[1], cand));
             LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_dinv, (size_t)widest * kNB * kNB * es));
@@ -1095,7 +1153,7 @@ void launch_block_tp(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t kb, do
     T* front = (T*)f->d_front;
     const int32_t active = (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), kb, std::greater<int32_t>()) - L.sorted_m.begin());
     if (active == 0) return;
-    int32_t sets = (L.max_m + kTR - 1) / kTR;
+    int32_t sets = (L.max_m + tp_first<T>::rows - 1) / tp_first<T>::rows;
     hipLaunchKernelGGL((nd_tp_round_kernel<T, true, false>), dim3(active, sets), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, f->d_rowq, kb, 0,
                        (const int32_t*)nullptr, f->d_cand[0], (T*)nullptr, f->d_flag, tiny2);
     int src = 0;

@@ -193,3 +193,37 @@ def test_eigensolver_lu_variants_agree(hip_ctx):
         assert s.solver.stats["gmres_iters"] <= 2 * s.solver.stats["op_applies"]  # direct solves, at most polished
         s.solver.release()
     assert np.max(np.abs(lam["nd"] - lam["band"]) / np.abs(lam["band"])) < 1e-10
+
+
+@pytest.mark.parametrize("case,sigma,leaf,tp_min", [("S5k", SIGMA, 0, 32), ("S5k", 0.05, 200, 32), ("S30k", SIGMA, 0, 64), ("S30k", SIGMA, 600, 100),
+                                                    ("C9k", -5.0, 0, 32), ("C20k", -5.0 + 0.5j, 0, 200)])
+def test_ndlu_tournament_pivoting(hip_ctx, monkeypatch, case, sigma, leaf, tp_min):
+    """Tall pivot blocks choose the 32 pivot rows of a column block by a tournament (local eliminations over 256 / 512
+    rows, 8-way merges, the winners' tile inverted in LDS; ``LSA_ND_TP_MIN`` = the block height from which a level does so,
+    384 by default).  Forced onto small and mid-size fronts here -- one to three tournament rounds, partial last blocks,
+    real and complex factors, 2D and 3D patterns, the transposed sweeps -- the answers agree with SuperLU like those of the
+    panel elimination, and zero diagonals (pressure rows) are pivoted around."""
+    import lsa_hip
+    from oracle import fem
+
+    monkeypatch.setenv("LSA_ND_TP_MIN", str(tp_min))
+    monkeypatch.setenv("LSA_ND_NO_CACHE", "1")
+    if case.startswith("C"):
+        es = fem.cube_case(case)
+        C = sp.csr_matrix((es.A.data - sigma * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+    else:
+        es, C = _shifted(case, sigma)
+    f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, C), leaf)
+    rng = np.random.default_rng(11)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    x = _solve(hip_ctx, f, b)
+    assert np.linalg.norm(C @ x - b) <= 1e-12 * np.linalg.norm(b)
+    xref = spla.splu(sp.csc_matrix(C.astype(np.complex128))).solve(b)
+    assert np.linalg.norm(x - xref) <= 1e-10 * np.linalg.norm(xref)
+    assert np.array_equal(_solve(hip_ctx, f, b), x)
+    dx = lsa_hip.DeviceVector(hip_ctx, es.n, np.complex128)
+    f.solve_adjoint(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
+    xa = dx.numpy()
+    assert np.linalg.norm(C.conj().T @ xa - b) <= 1e-12 * np.linalg.norm(b)
+    f.refactor(lsa_hip.CsrMatrix.from_scipy(hip_ctx, C))  # same values: the second elimination reproduces the first bit for bit
+    assert np.array_equal(_solve(hip_ctx, f, b), x)

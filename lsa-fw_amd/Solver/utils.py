@@ -738,8 +738,14 @@ class iEpsSolver:
         return self.get_eigenvalue(idx), self.get_eigenvector(idx)
 
     def get_all_eigenpairs_up_to(self, num: int) -> Iterator[tuple[float | complex, iComplexPETScVector]]:
-        for i in range(min(self.get_num_converged(), num)):
-            yield self.get_eigenpair(i)
+        # The norms and scalings of the vectors run on ONE host BLAS thread, for the duration of this call only: a threaded
+        # BLAS call leaves its worker pool spinning, and the launch-bound factorisation of the caller's NEXT solve then
+        # takes 50 ms longer (tools/micro/after_eigensolve.py: 74 -> 125 ms per solve at 30 k unknowns on a 256-core host).
+        from lsa_hip.krylov_schur import _single_threaded_blas
+
+        with _single_threaded_blas():
+            pairs = [self.get_eigenpair(i) for i in range(min(self.get_num_converged(), num))]
+        yield from pairs
 
     def get_eigenvector_array(self, idx: int) -> np.ndarray:
         """Complex ndarray of eigenvector ``idx`` (convenience; not in the reference)."""

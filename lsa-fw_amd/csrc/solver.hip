@@ -105,7 +105,8 @@ int spmv_global(lsa_ctx* ctx, const lsa_mat* A, int dtype, const void* x, void* 
     if (adjoint) return k_spmv_transpose(ctx, A, 1, dtype, x, y);  // y = A^H x (one rank only: checked when the mode is set)
     const size_t es = esize(dtype);
     LSA_CHECK(k_spmv(ctx, A, dtype, x, (char*)y + (size_t)A->row0 * es));
-    if (ctx->nranks > 1) LSA_CHECK(k_allgather_inplace(ctx, y, (size_t)(A->ncols / ctx->nranks) * es));
+    // (a whole square matrix was multiplied on every rank: nothing to exchange)
+    if (ctx->nranks > 1 && A->n != A->ncols) LSA_CHECK(k_allgather_inplace(ctx, y, (size_t)(A->ncols / ctx->nranks) * es));
     return LSA_OK;
 }
 
@@ -526,7 +527,16 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
     if (mode == 0 || mode == 2) {
         op->Kfac = C;
         op->Kmul = M;
-        if (tree) {  // SpMV on this rank's rows of the whole matrices
+        // Subtree-parallel layout: every rank holds the whole matrices.  A product over this rank's rows only must be
+        // completed by an all-gather of the result (16 B per unknown over xGMI); the whole product costs 20 B per stored
+        // entry from HBM.  With the ~30 entries per row of the 2D pattern the replicated product is the cheaper one at any
+        // size (and bit-identical on every rank); with the ~100 of the 3D pattern the sharded one is.
+        bool shard_rows = false;
+        if (tree) {
+            const char* e = getenv("LSA_DIST_SPMV");  // "shard" / "replicate": override (measurement)
+            shard_rows = (e && *e) ? (e[0] == 's') : (C->nnz > 60 * (int64_t)C->n);
+        }
+        if (tree && shard_rows) {  // SpMV on this rank's rows of the whole matrices
             op->view_fac = mat_row_view(C, tree->row0, tree->row1);
             op->Kfac = op->view_fac;
             if (M) {
@@ -542,7 +552,7 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
                 lsa_op_destroy(op);
                 return rc;
             }
-            if (tree) {
+            if (tree && shard_rows) {
                 if (op->view_mul) lsa_mat_destroy(op->view_mul);
                 op->view_mul = mat_row_view(op->owned_mul, tree->row0, tree->row1);
                 op->Kmul = op->view_mul;

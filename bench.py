@@ -69,6 +69,12 @@ def log(msg: str) -> None:
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+if os.environ.get("LSA_BENCH_STACKS"):  # development: python stacks of every thread to stderr every N seconds (finding a hang)
+    import faulthandler
+
+    faulthandler.dump_traceback_later(float(os.environ["LSA_BENCH_STACKS"]), repeat=True, file=sys.stderr)
+
+
 def build_solver(es, sigma, args, device, pc, layout="single"):
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
@@ -583,7 +589,11 @@ def main() -> None:
                 }
             except Exception as exc:  # noqa: BLE001  (the headline value must survive a failure of this leg)
                 out["roofline"] = {"error": f"{type(exc).__name__}: {exc}"}
-        if not args.no_cpu_baseline:
+        if world > 1:
+            # the CPU baseline is a leg of the N = 1 run (same S30k workload as its GPU line); the sharded run's workload
+            # takes the oracle many minutes and would hold the other ranks in the closing barrier
+            out["cpu_baseline"] = None
+        elif not args.no_cpu_baseline:
             try:
                 base, lam_cpu = cpu_baseline(es, sigma, args)
                 out["cpu_baseline"] = base

@@ -305,6 +305,10 @@ typedef int (*lsa_host_allgather_fn)(void *host_buf, int64_t bytes_per_rank, voi
 int lsa_comm_init_host(lsa_ctx *ctx, int nranks, int rank, lsa_host_allgather_fn fn, void *user);
 /* all-gathers issued on this context and the bytes this rank received through them */
 int lsa_comm_stats(const lsa_ctx *ctx, int64_t *calls, int64_t *bytes_received);
+/* The RCCL plumbing exercised with ONE rank (what a one-GPU box can run): open the library, unique id, a communicator of
+ * one rank on the context's device, one in-place ncclAllGather of `bytes` bytes on the context's stream, compare, destroy.
+ * Leaves the context's own communicator untouched.  LSA_OK, or LSA_ERR_COMM with the failing step in lsa_last_error. */
+int lsa_comm_selftest(lsa_ctx *ctx, int64_t bytes);
 /* Row-block shard of a global CSR: this rank owns rows [row0, row1); x and y of lsa_spmv stay global-length
  * and replicated, each rank computes its rows and the blocks are exchanged with ncclAllGather.
  * Padded block layout: the global index space is nranks equal blocks of B_pad = n_global / nranks slots, rank r owns

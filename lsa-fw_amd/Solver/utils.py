@@ -792,13 +792,18 @@ def _dist_comm_init(ctx, world: int, rank: int) -> None:
     if dist.get_backend() == "nccl" and os.environ.get("LSA_COMM_TRANSPORT", "rccl") != "host":
         # RCCL is opened by the library itself (dlopen); if that fails on ANY rank, every rank falls back to the host
         # transport together (a collective decision: ranks on different transports would dead-lock)
+        # (1) every rank checks that it can open RCCL at all -- asking for a unique id does that -- and the ranks agree on
+        # the answer BEFORE anyone enters ncclCommInitRank, which would wait for ever for a rank that never calls it
         ok = 1
         try:
-            uid = ctx.unique_id() if rank == 0 else None
+            uid = ctx.unique_id()
         except Exception as exc:  # noqa: BLE001
-            logger.warning("RCCL unavailable on rank 0 (%s)", exc)
+            logger.warning("RCCL unavailable on rank %d (%s)", rank, exc)
             uid, ok = None, 0
-        uid = _dist_broadcast_bytes(uid)
+        probe = torch.tensor([ok], dtype=torch.int32, device="cuda")
+        dist.all_reduce(probe, op=dist.ReduceOp.MIN)
+        ok = int(probe.item())
+        uid = _dist_broadcast_bytes(uid if (rank == 0 and ok) else None)  # (2) rank 0's id for everybody
         if uid is not None and ok:
             try:
                 ctx.comm_init(world, rank, uid)

@@ -158,6 +158,40 @@ int lsa_comm_init_host(lsa_ctx* ctx, int nranks, int rank, lsa_host_allgather_fn
     return LSA_OK;
 }
 
+int lsa_comm_selftest(lsa_ctx* ctx, int64_t bytes) {
+    if (!ctx || bytes < 1 || bytes > (1 << 28)) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_comm_selftest: bad argument");
+    Rccl& r = rccl();
+    if (!r.handle) return lsa_set_error(ctx, LSA_ERR_COMM, "RCCL unavailable: %s", r.why.c_str());
+    LSA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    nccl_uid uid;
+    int rc = r.get_uid(&uid);
+    if (rc != 0) return lsa_set_error(ctx, LSA_ERR_COMM, "ncclGetUniqueId failed: %s", r.err_string ? r.err_string(rc) : "?");
+    nccl_comm comm = nullptr;
+    rc = r.init_rank(&comm, 1, uid, 0);
+    if (rc != 0) return lsa_set_error(ctx, LSA_ERR_COMM, "ncclCommInitRank (one rank) failed: %s", r.err_string ? r.err_string(rc) : "?");
+    std::vector<unsigned char> h((size_t)bytes), back((size_t)bytes, 0);
+    for (int64_t i = 0; i < bytes; ++i) h[(size_t)i] = (unsigned char)(i * 131 + 7);
+    void* d = nullptr;
+    int out = LSA_OK;
+    if (hipMalloc(&d, (size_t)bytes) != hipSuccess) {
+        r.comm_destroy(comm);
+        return lsa_set_error(ctx, LSA_ERR_OOM, "lsa_comm_selftest: out of device memory");
+    }
+    if (hipMemcpyAsync(d, h.data(), (size_t)bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) out = LSA_ERR_HIP;
+    if (out == LSA_OK) {
+        rc = r.all_gather(d, d, (size_t)bytes, kNcclChar, comm, ctx->stream);  // in place: block 0 of one
+        if (rc != 0) out = lsa_set_error(ctx, LSA_ERR_COMM, "ncclAllGather failed: %s", r.err_string ? r.err_string(rc) : "?");
+    }
+    if (out == LSA_OK && (hipMemcpyAsync(back.data(), d, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                          hipStreamSynchronize(ctx->stream) != hipSuccess))
+        out = lsa_set_error(ctx, LSA_ERR_HIP, "lsa_comm_selftest: copy back failed");
+    if (out == LSA_OK && back != h) out = lsa_set_error(ctx, LSA_ERR_COMM, "lsa_comm_selftest: the gathered block differs from what was sent");
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    r.comm_destroy(comm);
+    return out;
+}
+
 int lsa_comm_stats(const lsa_ctx* ctx, int64_t* calls, int64_t* bytes_received) {
     if (!ctx) return LSA_ERR_ARG;
     if (calls) *calls = ctx->comm_calls;

@@ -149,6 +149,7 @@ SIGNATURES = {
     "lsa_comm_init": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P]),
     "lsa_comm_init_host": (ctypes.c_int, [_P, ctypes.c_int, ctypes.c_int, _P, _P]),
     "lsa_comm_stats": (ctypes.c_int, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    "lsa_comm_selftest": (ctypes.c_int, [_P, _I64]),
     "lsa_csr_upload_shard": (ctypes.c_int, [_P, _I32, _I32, _I32, _I64, _P, _P, _P, ctypes.c_int, _PP]),
 }
 
@@ -280,6 +281,10 @@ class Context:
 
         self._host_cb = _HOST_GATHER_FN(_cb)  # keep the trampoline alive as long as the context
         self.check(self._lib.lsa_comm_init_host(self.handle, nranks, rank, ctypes.cast(self._host_cb, ctypes.c_void_p), None))
+
+    def comm_selftest(self, nbytes: int = 1 << 20) -> None:
+        """RCCL with one rank on this device: open, unique id, communicator, one in-place all-gather, destroy (raises on failure)."""
+        self.check(self._lib.lsa_comm_selftest(self.handle, int(nbytes)))
 
     def comm_stats(self) -> dict:
         calls, nbytes = _I64(0), _I64(0)

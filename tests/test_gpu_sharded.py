@@ -128,3 +128,54 @@ def test_sharded_solve_with_several_ranks_on_one_gpu(tmp_path, world, pc, case):
         assert int(out[0]["gmres"]) == 0 and per_apply * int(out[0]["applies"]) <= int(out[0]["gathers"]) <= per_apply * int(out[0]["applies"]) + 8
     else:  # block-Jacobi over > 1 rank: the inner solves iterate
         assert int(out[0]["gmres"]) > int(out[0]["applies"]) and int(out[0]["gathers"]) > 2 * int(out[0]["applies"])
+
+
+def test_rccl_plumbing_with_one_rank(hip_ctx):
+    """What a one-GPU box can run of the RCCL path: dlopen, ncclGetUniqueId, ncclCommInitRank (one rank) on the library's
+    device, one in-place ncclAllGather on the library's stream, destroy -- the call sequence and signatures the sharded
+    layouts use with more ranks (`lsa_comm_selftest`)."""
+    hip_ctx.comm_selftest(1 << 20)
+    hip_ctx.comm_selftest(4097)
+    uid = hip_ctx.unique_id()
+    assert len(uid) == 128 and any(uid)
+
+
+def _nccl_world_of_one(_index: int, port: int, out: str) -> None:
+    import os
+    import sys
+    from pathlib import Path
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    root = Path(__file__).resolve().parents[1]
+    sys.path[:0] = [str(root), str(root / "lsa-fw_amd")]
+    import torch
+    import torch.distributed as dist
+
+    import lsa_hip
+    from Solver.utils import _dist_comm_init
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    t = torch.ones(4, device="cuda")
+    dist.all_reduce(t)  # PyTorch's own RCCL is loaded and has a communicator on this device
+    ctx = lsa_hip.Context(0)
+    ctx.comm_selftest(1 << 16)  # the library's RCCL (the copy already in the process) beside it
+    _dist_comm_init(ctx, 1, 0)  # the bootstrap the sharded layouts run: probe, agreement, id broadcast, init
+    Path(out).write_text("ok")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_beside_the_nccl_backend_of_torch(tmp_path):
+    """bench.py --gpus N runs under torch.distributed's nccl backend: the library's communicator then lives beside
+    PyTorch's in one process.  One rank, in a child process (a process group per test process would outlive the test)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = tmp_path / "done"
+    mp.spawn(_nccl_world_of_one, args=(port, str(out)), nprocs=1, join=True)
+    assert out.read_text() == "ok"

@@ -448,14 +448,39 @@ def main() -> None:
     es = fem.cylinder_case(args.case)
     sigma = SWEEP_SIGMAS[(2 + rank) % len(SWEEP_SIGMAS)] if args.sweep else SWEEP_SIGMAS[2]
     log(f"rank {rank}/{world}: {args.case} n={es.n} nnz={es.A.nnz} sigma={sigma} layout={layout}")
-    solver = build_solver(es, sigma, args, device, args.pc, "sharded" if sharded else "single")
-    solver.solver.prepare()  # ordering + upload: (A, M) -- this rank's rows when sharded -- now resident in HBM
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    layout_note = None
+    solver = None
+    if sharded:
+        # The sharded layout has more moving parts than anything else here (forest cut, RCCL bootstrap, exchange regions): if
+        # setting it up or the first solve fails on ANY rank, every rank falls back to independent replicas and the line says
+        # so -- a bench line with a note instead of no line.  (The ranks agree through the launcher's process group.)
+        ok, why = 1, ""
+        try:
+            solver = build_solver(es, sigma, args, device, args.pc, "sharded")
+            solver.solver.prepare()
+            solver.solve()
+        except Exception as exc:  # noqa: BLE001
+            ok, why = 0, f"{type(exc).__name__}: {exc}"
+            log(f"rank {rank}: sharded layout failed: {why}")
+        flag = torch.tensor([ok], dtype=torch.int32, device=reduce_device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            layout_note = "sharded layout failed on at least one rank (" + (why or "another rank") + "): independent replicas of the same problem instead"
+            if solver is not None:
+                try:
+                    solver.solver.release()
+                except Exception:  # noqa: BLE001
+                    pass
+            solver, sharded, layout = None, False, "replicas"
+    if solver is None:
+        solver = build_solver(es, sigma, args, device, args.pc, "single")
+        solver.solver.prepare()  # ordering + upload: (A, M) now resident in HBM
     for _ in range(args.warmup):
         solver.solve()
     barrier()
@@ -554,6 +579,7 @@ def main() -> None:
                 "gmres_iters_per_apply": (stats.get("gmres_iters", 0) / max(stats.get("op_applies", 1), 1)) if sharded else None,
                 "allgather_calls_per_solve": stats.get("allgather_calls") if sharded else None,
                 "allgather_bytes_received_per_rank_per_solve": stats.get("allgather_bytes_received") if sharded else None,
+                "layout_note": layout_note,
                 "replicas": replicas,
                 "speedup_over_one_gpu_same_workload": (total_pairs / elapsed) / (replicas["eigenpairs_per_s"] / world)
                 if (sharded and replicas and "eigenpairs_per_s" in replicas) else None,

@@ -62,7 +62,7 @@ struct NdLevel {
     std::vector<int32_t> sorted_m;          // own sizes of the level's nodes (descending)
     TileList unperm, gemm[3], copyback;
     int32_t fwd_tiles = 0, bwd_tiles = 0;  // grid.y of the sweep kernels: tiles of the tallest node (0 = nothing to do)
-    int32_t sweep_rows = 32;               // rows per sweep tile: 32, or 8 on levels with few tiles
+    int32_t sweep_rows = 32;               // rows per upward-sweep tile: 32; 8 on levels with few tiles (both sweeps); 128 on thin levels
     std::vector<TileList> ext;  // one per child rank
     int64_t scratch = 0;
 };
@@ -313,19 +313,25 @@ __global__ __launch_bounds__(256) void nd_gj_stage_kernel(const int32_t* __restr
 
 // the columns outside the finished block: A[i, c] = (i is a pivot row of the block ? 0 : A[i, c]) + sum_j Wb[i, j] Yb[j, c]
 // grid: (node, 64-row tile, 64-column tile); 4 x 4 per thread; the whole K = nb <= 32 extent in one pass through LDS
+// Column windows (tournament path with look-ahead): `only` non-empty = update just the columns [only_lo, only_hi) (the next
+// block's, so that its pivot search can start while the rest is updated); `skip` = leave [skip_lo, skip_hi) alone (done
+// already).  ztile0 = first 64-column tile of the grid.
 template <typename T>
 __global__ __launch_bounds__(256) void nd_gj_gemm_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
                                                          T* __restrict__ front, const int32_t* __restrict__ rowq, int32_t kb,
-                                                         const T* __restrict__ ybuf) {
+                                                         const T* __restrict__ ybuf, int32_t only_lo, int32_t only_hi, int32_t skip_lo,
+                                                         int32_t skip_hi, int32_t ztile0) {
     __shared__ T Ws[kNB][kGT + 1];
     __shared__ T Ys[kNB][kGT + 1];
     const int32_t t = lvl_nodes[blockIdx.x];
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, ld = nd.f;
     const int32_t nb = min(kNB, m - kb);
-    const int32_t row0 = (int32_t)blockIdx.y * kGT, col0 = (int32_t)blockIdx.z * kGT;
+    const int32_t row0 = (int32_t)blockIdx.y * kGT, col0 = ((int32_t)blockIdx.z + ztile0) * kGT;
     if (nb <= 0 || row0 >= m || col0 >= m) return;
     if (col0 >= kb && col0 + kGT <= kb + nb) return;  // tile inside the block
+    if (only_hi > only_lo && (col0 >= only_hi || col0 + kGT <= only_lo)) return;
+    if (col0 >= skip_lo && col0 + kGT <= skip_hi) return;
     T* a = front + nd.front_off;
     const T* yb = ybuf + (size_t)kNB * nd.piv_off;
     const int32_t* rq = rowq + nd.piv_off;
@@ -366,6 +372,7 @@ __global__ __launch_bounds__(256) void nd_gj_gemm_kernel(const int32_t* __restri
         for (int j = 0; j < 4; ++j) {
             const int32_t gc = col0 + tx + 16 * j;
             if (gc >= m || (gc >= kb && gc < kb + nb)) continue;
+            if ((gc >= skip_lo && gc < skip_hi) || (only_hi > only_lo && (gc < only_lo || gc >= only_hi))) continue;
             T* cptr = a + (size_t)gr * ld + gc;
             *cptr = is_piv ? acc[i][j] : s_add(*cptr, acc[i][j]);
         }
@@ -947,6 +954,8 @@ struct lsa_ndlu {
     int32_t *d_cand[2] = {nullptr, nullptr};  // tournament pivoting: candidate rows, two buffers used in turn
     void* d_dinv = nullptr;                    // ... the inverted pivot tile of every node of the level being eliminated
     int32_t tp_min = 1 << 30;                  // levels whose tallest pivot block has at least this many rows use it
+    hipStream_t side = nullptr;                // ... the next block's tournament runs here, under the current block's update
+    hipEvent_t ev_panel = nullptr, ev_pivots = nullptr;
     double seconds_analyse = 0.0, seconds_numeric = 0.0;
     int32_t solve_launches = 0;
 };
@@ -959,6 +968,9 @@ void nd_free(lsa_ndlu* f) {
                     (void*)f->d_lvl_nodes, (void*)f->d_asm_dst, (void*)f->d_asm_src, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_xflag, (void*)f->d_maxabs,
                     f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp, f->d_ybuf, f->d_ysm, (void*)f->d_cand[0], (void*)f->d_cand[1], f->d_dinv})
         if (p) (void)hipFree(p);
+    if (f->ev_panel) (void)hipEventDestroy(f->ev_panel);
+    if (f->ev_pivots) (void)hipEventDestroy(f->ev_pivots);
+    if (f->side) (void)hipStreamDestroy(f->side);
     delete f;
 }
 
@@ -1058,13 +1070,17 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
             int64_t tiles32 = 0;
             for (int32_t q = 0; q < L.node_count; ++q) tiles32 += (S.f[(size_t)S.lvl_nodes[(size_t)L.node_begin + q]] + kRT - 1) / kRT;
             static const int64_t few = getenv("LSA_ND_SWEEP_FEW") ? atoll(getenv("LSA_ND_SWEEP_FEW")) : 4 * (int64_t)ctx->num_cu;
-            L.sweep_rows = tiles32 <= few ? 8 : kRT;
+            // thin separators (pivot blocks of a few dozen unknowns under fronts of a few hundred rows): the upward sweep reads
+            // f short rows per node; four lanes per row pair and 128 rows per workgroup gather the node's vector 1/4 as often
+            static const int32_t thin = getenv("LSA_ND_SWEEP_THIN") ? atoi(getenv("LSA_ND_SWEEP_THIN")) : 64;
+            L.sweep_rows = tiles32 <= few ? 8 : (L.max_m <= thin && l > 0) ? 128 : kRT;
         }
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
             L.fwd_tiles = std::max(L.fwd_tiles, (S.f[(size_t)t] + L.sweep_rows - 1) / L.sweep_rows);
             L.max_f = std::max(L.max_f, S.f[(size_t)t]);
-            if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.m[(size_t)t] + L.sweep_rows - 1) / L.sweep_rows);
+            const int32_t bwd_rows = L.sweep_rows == 8 ? 8 : kRT;  // (the downward sweep of a thin level has few, long rows: 32-row tiles)
+            if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.m[(size_t)t] + bwd_rows - 1) / bwd_rows);
         }
         if (L.fwd_tiles > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a front of more than %d rows is not supported", 65535 * 8);
         begin_list(L.copyback);
@@ -1111,6 +1127,16 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
             LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[0], cand));
             LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[1], cand));
             LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_dinv, (size_t)widest * kNB * kNB * es));
+            const char* la = getenv("LSA_ND_LOOKAHEAD");
+            if (!(la && *la && atoi(la) == 0)) {
+                // highest priority: the tournament's few workgroups must not queue behind the thousands of the product they
+                // run under
+                int lo_pri = 0, hi_pri = 0;
+                LSA_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+                LSA_HIP_CHECK(ctx, hipStreamCreateWithPriority(&f->side, hipStreamNonBlocking, hi_pri));
+                LSA_HIP_CHECK(ctx, hipEventCreateWithFlags(&f->ev_panel, hipEventDisableTiming));
+                LSA_HIP_CHECK(ctx, hipEventCreateWithFlags(&f->ev_pivots, hipEventDisableTiming));
+            }
         }
     }
     f->solve_launches = 0;
@@ -1141,42 +1167,82 @@ void launch_block(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t kb, doubl
         hipLaunchKernelGGL((nd_gj_stage_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, kb,
                            (T*)f->d_ybuf);
         const int32_t tiles = (L.max_m + kGT - 1) / kGT;
-        hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, tiles), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb, (const T*)f->d_ybuf);
+        hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, tiles), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb, (const T*)f->d_ybuf, 0, 0,
+                           0, 0, 0);
     }
 }
 
-// one block of kNB columns of every pivot block of the level, pivot rows chosen by tournament
+// the tournament for the block of columns starting at kb, on stream `st`: leaves D^-1 per node in d_dinv and the pivot
+// rows in ipiv / rowq
 template <typename T>
-void launch_block_tp(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t kb, double tiny2) {
-    hipStream_t st = ctx->stream;
+void launch_tournament(lsa_ndlu* f, const NdLevel& L, int32_t kb, double tiny2, hipStream_t st) {
     const int32_t* lv = f->d_lvl_nodes + L.node_begin;
-    T* front = (T*)f->d_front;
+    const T* front = (const T*)f->d_front;
     const int32_t active = (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), kb, std::greater<int32_t>()) - L.sorted_m.begin());
     if (active == 0) return;
     int32_t sets = (L.max_m + tp_first<T>::rows - 1) / tp_first<T>::rows;
-    hipLaunchKernelGGL((nd_tp_round_kernel<T, true, false>), dim3(active, sets), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, f->d_rowq, kb, 0,
+    hipLaunchKernelGGL((nd_tp_round_kernel<T, true, false>), dim3(active, sets), dim3(256), 0, st, lv, f->d_nodes, front, f->d_ipiv, f->d_rowq, kb, 0,
                        (const int32_t*)nullptr, f->d_cand[0], (T*)nullptr, f->d_flag, tiny2);
     int src = 0;
     for (int32_t round = 0;; ++round) {
         const int32_t groups = (sets + kTA - 1) / kTA;
         if (groups == 1) {
-            hipLaunchKernelGGL((nd_tp_round_kernel<T, false, true>), dim3(active, 1), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, f->d_rowq, kb,
-                               round, (const int32_t*)f->d_cand[src], (int32_t*)nullptr, (T*)f->d_dinv, f->d_flag, tiny2);
+            hipLaunchKernelGGL((nd_tp_round_kernel<T, false, true>), dim3(active, 1), dim3(256), 0, st, lv, f->d_nodes, front, f->d_ipiv, f->d_rowq, kb, round,
+                               (const int32_t*)f->d_cand[src], (int32_t*)nullptr, (T*)f->d_dinv, f->d_flag, tiny2);
             break;
         }
-        hipLaunchKernelGGL((nd_tp_round_kernel<T, false, false>), dim3(active, groups), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, f->d_rowq,
-                           kb, round, (const int32_t*)f->d_cand[src], f->d_cand[src ^ 1], (T*)nullptr, f->d_flag, tiny2);
+        hipLaunchKernelGGL((nd_tp_round_kernel<T, false, false>), dim3(active, groups), dim3(256), 0, st, lv, f->d_nodes, front, f->d_ipiv, f->d_rowq, kb, round,
+                           (const int32_t*)f->d_cand[src], f->d_cand[src ^ 1], (T*)nullptr, f->d_flag, tiny2);
         src ^= 1;
         sets = groups;
     }
-    hipLaunchKernelGGL((nd_tp_colblock_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb,
-                       (const T*)f->d_dinv);
-    if (L.max_m > kNB) {
-        hipLaunchKernelGGL((nd_gj_stage_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, kb,
-                           (T*)f->d_ybuf);
-        const int32_t tiles = (L.max_m + kGT - 1) / kGT;
-        hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, tiles), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb, (const T*)f->d_ybuf);
+}
+
+// Gauss-Jordan of all pivot blocks of a level by tournament pivoting, with look-ahead: once block k's own columns are done
+// the next block's 32 columns are updated first, and its tournament (a chain of single-workgroup launches) runs on a
+// second stream underneath the rank-32 product that updates everything else.
+template <typename T>
+int launch_level_tp(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, double tiny2) {
+    hipStream_t st = ctx->stream, side = f->side;
+    const int32_t* lv = f->d_lvl_nodes + L.node_begin;
+    T* front = (T*)f->d_front;
+    auto active_at = [&](int32_t k) {
+        return (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), k, std::greater<int32_t>()) - L.sorted_m.begin());
+    };
+    // (two cross-stream hand-offs per block cost ~15 us: worth it only where the product they hide behind is long.
+    // Measured: C300k 472 -> 438 ms, C160k 186 -> 183 ms; S500k, tallest pivot block 838 rows, 56 -> 59 ms without this limit)
+    static const int32_t ahead_min = getenv("LSA_ND_LOOKAHEAD_MIN") ? atoi(getenv("LSA_ND_LOOKAHEAD_MIN")) : 1024;
+    const bool ahead = side != nullptr && L.max_m >= std::max(ahead_min, 2 * kNB + 1);
+    launch_tournament<T>(f, L, 0, tiny2, st);
+    for (int32_t kb = 0; kb < L.max_m; kb += kNB) {
+        const int32_t active = active_at(kb);
+        if (active == 0) break;
+        hipLaunchKernelGGL((nd_tp_colblock_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb,
+                           (const T*)f->d_dinv);
+        const int32_t next = kb + kNB;
+        const bool has_next = next < L.max_m && active_at(next) > 0;
+        if (L.max_m > kNB) {
+            hipLaunchKernelGGL((nd_gj_stage_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, kb,
+                               (T*)f->d_ybuf);
+            const int32_t tiles = (L.max_m + kGT - 1) / kGT;
+            if (has_next && ahead) {
+                hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, 1), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb, (const T*)f->d_ybuf,
+                                   next, next + kNB, 0, 0, next / kGT);
+                LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_panel, st));
+                LSA_HIP_CHECK(ctx, hipStreamWaitEvent(side, f->ev_panel, 0));
+                launch_tournament<T>(f, L, next, tiny2, side);
+                LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_pivots, side));
+                hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, tiles), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb,
+                                   (const T*)f->d_ybuf, 0, 0, next, next + kNB, 0);
+                LSA_HIP_CHECK(ctx, hipStreamWaitEvent(st, f->ev_pivots, 0));
+                continue;
+            }
+            hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, tiles), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb, (const T*)f->d_ybuf,
+                               0, 0, 0, 0, 0);
+        }
+        if (has_next) launch_tournament<T>(f, L, next, tiny2, st);
     }
+    return LSA_OK;
 }
 
 template <typename T>
@@ -1213,9 +1279,9 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
             LSA_CHECK(k_allgather_inplace(ctx, f->d_front, (size_t)S.xfront_slot * sizeof(T)));
         for (const TileList& e : L.ext)
             if (e.count > 0) hipLaunchKernelGGL((nd_extend_add_kernel<T>), dim3(e.count), dim3(256), 0, st, tl + 2 * e.off, f->d_nodes, f->d_cmap, front);
-        for (int32_t kb = 0; kb < L.max_m; kb += kNB) {
-            if (L.max_m >= f->tp_min) launch_block_tp<T>(ctx, f, L, kb, tiny2);
-            else if (L.max_m <= 64) launch_block<T, 64, 1, 8>(ctx, f, L, kb, tiny2);
+        if (L.max_m >= f->tp_min) LSA_CHECK(launch_level_tp<T>(ctx, f, L, tiny2));
+        for (int32_t kb = 0; kb < L.max_m && L.max_m < f->tp_min; kb += kNB) {
+            if (L.max_m <= 64) launch_block<T, 64, 1, 8>(ctx, f, L, kb, tiny2);
             else if (L.max_m <= 128) launch_block<T, 128, 1, 8>(ctx, f, L, kb, tiny2);
             else if (L.max_m <= 256) launch_block<T, 256, 1, 8>(ctx, f, L, kb, tiny2);
             else if (L.max_m <= 512) launch_block<T, 512, 1, 8>(ctx, f, L, kb, tiny2);
@@ -1289,6 +1355,9 @@ int nd_apply(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
         if (L.fwd_tiles > 0) {
             if (L.sweep_rows == 8)
                 hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 64>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,
+                                   f->d_gell, b, x, (VT*)f->d_ubuf);
+            else if (L.sweep_rows == 128)
+                hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 4>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,
                                    f->d_gell, b, x, (VT*)f->d_ubuf);
             else
                 hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 16>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,

@@ -31,8 +31,26 @@ Rccl& rccl() {
     if (r.handle || !r.why.empty()) return r;
     const char* env = getenv("LSA_RCCL_PATH");
     if (env && *env) r.handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
-    // an RCCL the process has loaded already (PyTorch's, when the launcher runs the nccl backend) is used as it is: one
-    // runtime per process, a second communicator inside it; otherwise ROCm's own copy is opened
+    // RCCL must sit on the HIP / HSA runtime this library is bound to.  A process can hold two ROCm trees (PyTorch wheels
+    // bundle their own next to /opt/rocm): the RCCL of the other tree finds an HSA runtime nobody initialised ("no
+    // ROCm-capable device is detected" in ncclCommInitRank).  So: the librccl next to the libamdhip64 that resolved hipStreamSynchronize
+    // for us -- PyTorch's when the launcher imported torch first (bench.py: one runtime per process, a second communicator
+    // inside it), ROCm's otherwise --
+    if (!r.handle) {
+        Dl_info info;
+        if (dladdr((void*)&hipStreamSynchronize, &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char* leaf : {"librccl.so.1", "librccl.so"}) {
+                    if (r.handle) break;
+                    r.handle = dlopen((dir + leaf).c_str(), RTLD_NOW | RTLD_LOCAL);
+                }
+            }
+        }
+    }
+    // ... then whatever RCCL the process has loaded already, then ROCm's own copy
     const char* loaded[] = {"librccl.so", "librccl.so.1"};
     for (const char* c : loaded)
         if (!r.handle) r.handle = dlopen(c, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
@@ -135,6 +153,7 @@ int lsa_comm_init(lsa_ctx* ctx, int nranks, int rank, const void* id128) {
     Rccl& r = rccl();
     if (!r.handle) return lsa_set_error(ctx, LSA_ERR_COMM, "RCCL unavailable: %s", r.why.c_str());
     LSA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    (void)hipGetLastError();  // RCCL reads the runtime's sticky last-error state: a handled failure of earlier work must not fail its setup
     nccl_uid uid;
     memcpy(&uid, id128, sizeof uid);
     nccl_comm comm = nullptr;
@@ -163,6 +182,8 @@ int lsa_comm_selftest(lsa_ctx* ctx, int64_t bytes) {
     Rccl& r = rccl();
     if (!r.handle) return lsa_set_error(ctx, LSA_ERR_COMM, "RCCL unavailable: %s", r.why.c_str());
     LSA_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipGetLastError();  // (see lsa_comm_init)
     nccl_uid uid;
     int rc = r.get_uid(&uid);
     if (rc != 0) return lsa_set_error(ctx, LSA_ERR_COMM, "ncclGetUniqueId failed: %s", r.err_string ? r.err_string(rc) : "?");

@@ -273,10 +273,14 @@ int lsa_krylov_extend(lsa_ctx *ctx, lsa_krylov *k, int32_t j0, int32_t j1, void 
 /* Krylov-Schur truncation: V[:, 0:knew] = V[:, 0:m] Q (Q is m x knew column-major complex on the host)
  * and V[:, knew] = V[:, m]. */
 int lsa_krylov_restart(lsa_ctx *ctx, lsa_krylov *k, int32_t m, int32_t knew, const void *Q, int32_t ldq);
-/* X = V[:, 0:m] Y, Y m x nvec on the host; X (n x nvec column-major complex) is written to the host,
- * each column normalised to unit 2-norm when normalise != 0 (SLEPc convention, Solver/utils.py:309). */
+/* X = V[:, 0:m] Y, Y m x nvec on the host; X (n x nvec column-major complex) is written to the host.  normalise: 0 = as they
+ * are; bit 0 = each column scaled to unit 2-norm (SLEPc convention, Solver/utils.py:309); bit 1 = and rotated to a canonical
+ * phase (its entry of largest magnitude real and positive: a real eigenvector comes out real, the test the reference's real
+ * build makes at Solver/utils.py:280-291), with the 2-norms of the columns' imaginary parts kept for lsa_krylov_imag_norms. */
 int lsa_krylov_ritz_vectors(lsa_ctx *ctx, lsa_krylov *k, int32_t m, int32_t nvec, const void *Y, int32_t ldy,
                             int normalise, void *X);
+/* 2-norms of the imaginary parts of the columns of the last lsa_krylov_ritz_vectors call with normalise bit 1 (nvec <= its nvec) */
+int lsa_krylov_imag_norms(const lsa_krylov *k, int32_t nvec, double *out);
 /* residual check of Solver/eigen2.py:48-56 on the device:
  * res[i] = ||A x_i - lam_i M x_i|| / (||A x_i|| + |lam_i| ||M x_i|| + 1e-16), X on the host (n x nvec). */
 int lsa_eig_residuals(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, int32_t nvec, const void *lam, const void *X,

@@ -334,6 +334,7 @@ class iEpsSolver:
         self._project_out = None if project_out is None else np.unique(np.asarray(project_out, dtype=np.int64))
         self._eigenvalues = np.zeros(0, dtype=np.complex128)
         self._eigenvectors = np.zeros((0, 0), dtype=np.complex128)
+        self._imag_norms = None
         self._residual_estimates = np.zeros(0)
         self._stats: dict = {}
         self._restarts = 0
@@ -576,6 +577,7 @@ class iEpsSolver:
                 back = lambda th: th + sigma  # noqa: E731
             theta_key = lambda th: lam_key(back(np.asarray(th, dtype=np.complex128)))  # noqa: E731
             res = krylov_schur(basis, nev, self._tol, self._max_it, theta_key, rng_seed=self._seed)
+            imag_norms = getattr(basis, "imag_norms", None)  # set when the device already put the vectors into canonical phase
             theta = res.theta
             lam = back(np.asarray(theta, dtype=np.complex128))
             if part is None:
@@ -608,6 +610,7 @@ class iEpsSolver:
         self._eigenvalues = lam[order]
         # column access (one eigenvector) must be contiguous; the Krylov-Schur driver already returns the wanted pairs first
         self._eigenvectors = X if (np.array_equal(order, np.arange(len(order))) and X.flags.f_contiguous) else np.asfortranarray(X[:, order])
+        self._imag_norms = imag_norms[order] if (imag_norms is not None and len(imag_norms) == len(order)) else None
         self._residual_estimates = res.residuals[order]
         self._restarts = res.restarts
 
@@ -688,6 +691,7 @@ class iEpsSolver:
         order = np.argsort(found_lam)
         self._eigenvalues = np.array(found_lam, dtype=np.complex128)[order]
         self._eigenvectors = np.asfortranarray(np.column_stack([found_vec[i] for i in order])) if found_lam else np.zeros((n, 0), dtype=np.complex128)
+        self._imag_norms = None  # (the merged vectors are not the last solve's: phases are fixed on the host when they are handed out)
         self._residual_estimates = np.zeros(len(found_lam))
         self._restarts = restarts
         self._stats = stats_total
@@ -725,6 +729,13 @@ class iEpsSolver:
         """Eigenvector ``idx`` with unit 2-norm; the imaginary part is dropped when its norm is <= 1e-6, as the
         reference's real build does (``Solver/utils.py:280-291``)."""
         v = self._eigenvectors[:, idx]
+        imag_norms = getattr(self, "_imag_norms", None)
+        if imag_norms is not None:  # unit norm and canonical phase were applied on the device (lsa_krylov_ritz_vectors)
+            if imag_norms[idx] <= 1e-6:
+                vr = v.real
+                return iComplexPETScVector(iPETScVector._adopt(vr / np.linalg.norm(vr)))
+            v = v.copy()
+            return iComplexPETScVector(iPETScVector._adopt(v.real), iPETScVector._adopt(v.imag))
         # fix the arbitrary complex phase so that a real eigenvector comes out real
         k = int(np.argmax(np.abs(v)))
         v = v * (np.abs(v[k]) / v[k]) if v[k] != 0 else v.copy()

@@ -210,6 +210,148 @@ __global__ void hess_column_kernel(int cnt, const T* __restrict__ h1, const T* _
     if (threadIdx.x == 0) s_from(hout[cnt], sqrt(nrm2[0]), 0.0);
 }
 
+// ---- Ritz vectors: unit norm and a canonical phase for all columns in two launches --------------------------------------------
+// per (block, column): sum |x|^2 over the block's rows and the entry of largest magnitude (lowest row among equals)
+__global__ __launch_bounds__(kThreads) void col_stats_kernel(int64_t n, const cplx* __restrict__ X, int64_t ldx, double* __restrict__ nrm_part,
+                                                             double* __restrict__ mag_part, long long* __restrict__ idx_part) {
+    __shared__ double ssum[4];
+    __shared__ double smag[kThreads];
+    __shared__ long long sidx[kThreads];
+    const cplx* x = X + (size_t)blockIdx.y * (size_t)ldx;
+    double s = 0.0, best = -1.0;
+    long long bi = -1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const double a = s_abs2(x[i]);
+        s += a;
+        if (a > best) {
+            best = a;
+            bi = i;
+        }
+    }
+    const double tot = block_sum<double>(s, ssum);
+    smag[threadIdx.x] = best;
+    sidx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double m2 = smag[threadIdx.x + o];
+            const long long i2 = sidx[threadIdx.x + o];
+            if (m2 > smag[threadIdx.x] || (m2 == smag[threadIdx.x] && i2 >= 0 && (sidx[threadIdx.x] < 0 || i2 < sidx[threadIdx.x]))) {
+                smag[threadIdx.x] = m2;
+                sidx[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const size_t at = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        nrm_part[at] = tot;
+        mag_part[at] = smag[0];
+        idx_part[at] = sidx[0];
+    }
+}
+
+// every block combines its column's partials in the same fixed order, then scales its rows:  x <- x * conj(x_k) / |x_k|
+// (/ ||x|| when `unit`), x_k the entry of largest magnitude;  imag_part[(column, block)] = sum Im(x)^2 afterwards
+__global__ __launch_bounds__(kThreads) void col_phase_kernel(int64_t n, cplx* __restrict__ X, int64_t ldx, const double* __restrict__ nrm_part,
+                                                             const double* __restrict__ mag_part, const long long* __restrict__ idx_part, int unit,
+                                                             double* __restrict__ imag_part) {
+    __shared__ double ssum[4];
+    __shared__ double smag[kThreads];
+    __shared__ long long sidx[kThreads];
+    cplx* x = X + (size_t)blockIdx.y * (size_t)ldx;
+    const int nb = gridDim.x;
+    const size_t base = (size_t)blockIdx.y * nb;
+    double s = 0.0, best = -1.0;
+    long long bi = -1;
+    for (int q = threadIdx.x; q < nb; q += kThreads) {
+        s += nrm_part[base + q];
+        const double m2 = mag_part[base + q];
+        const long long i2 = idx_part[base + q];
+        if (m2 > best || (m2 == best && i2 >= 0 && (bi < 0 || i2 < bi))) {
+            best = m2;
+            bi = i2;
+        }
+    }
+    const double tot = block_sum<double>(s, ssum);
+    smag[threadIdx.x] = best;
+    sidx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = kThreads / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            const double m2 = smag[threadIdx.x + o];
+            const long long i2 = sidx[threadIdx.x + o];
+            if (m2 > smag[threadIdx.x] || (m2 == smag[threadIdx.x] && i2 >= 0 && (sidx[threadIdx.x] < 0 || i2 < sidx[threadIdx.x]))) {
+                smag[threadIdx.x] = m2;
+                sidx[threadIdx.x] = i2;
+            }
+        }
+        __syncthreads();
+    }
+    const long long k = sidx[0];
+    cplx f{1.0, 0.0};
+    if (k >= 0 && smag[0] > 0.0) {
+        const cplx xk = x[k];
+        const double inv = 1.0 / sqrt(smag[0]);
+        f = cplx{xk.re * inv, -xk.im * inv};
+    }
+    if (unit && tot > 0.0) {
+        const double inv = 1.0 / sqrt(tot);
+        f.re *= inv;
+        f.im *= inv;
+    }
+    __syncthreads();  // (every thread has read x[k] before any block-mate overwrites it; other blocks: x[k] is rewritten only by
+                      //  the block that owns row k, and a value read after that rewrite would differ -- so row k is scaled LAST, below)
+    double im2 = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (i == k) continue;
+        const cplx v = s_mul(x[i], f);
+        x[i] = v;
+        im2 += v.im * v.im;
+    }
+    const double it = block_sum<double>(im2, ssum);
+    if (threadIdx.x == 0) imag_part[base + blockIdx.x] = it;
+}
+
+// the pivot entries themselves (skipped above so that every block reads the original value), and the column sums of Im^2
+__global__ __launch_bounds__(64) void col_phase_finish_kernel(cplx* __restrict__ X, int64_t ldx, int nb, const double* __restrict__ nrm_part,
+                                                              const double* __restrict__ mag_part, const long long* __restrict__ idx_part, int unit,
+                                                              const double* __restrict__ imag_part, double* __restrict__ imag2) {
+    const size_t base = (size_t)blockIdx.x * nb;
+    double s = 0.0, im = 0.0, best = -1.0;
+    long long bi = -1;
+    for (int q = threadIdx.x; q < nb; q += 64) {
+        s += nrm_part[base + q];
+        im += imag_part[base + q];
+        const double m2 = mag_part[base + q];
+        const long long i2 = idx_part[base + q];
+        if (m2 > best || (m2 == best && i2 >= 0 && (bi < 0 || i2 < bi))) {
+            best = m2;
+            bi = i2;
+        }
+    }
+    s = wave_sum<double>(s);
+    im = wave_sum<double>(im);
+    for (int o = 32; o > 0; o >>= 1) {
+        const double m2 = __shfl_xor(best, o);
+        const long long i2 = __shfl_xor(bi, o);
+        if (m2 > best || (m2 == best && i2 >= 0 && (bi < 0 || i2 < bi))) {
+            best = m2;
+            bi = i2;
+        }
+    }
+    if (threadIdx.x == 0) {
+        if (bi >= 0 && best > 0.0) {
+            double mag = sqrt(best);
+            if (unit && s > 0.0) mag /= sqrt(s);
+            X[(size_t)blockIdx.x * (size_t)ldx + (size_t)bi] = cplx{mag, 0.0};  // x_k conj(x_k) / |x_k| (/ ||x||): real, positive
+        }
+        imag2[blockIdx.x] = im;
+    }
+}
+
 // Out[i, k0+t] = sum_c V[i, c] Q[c, k0+t], t < kOutTile
 constexpr int kOutTile = 4;
 template <typename T>
@@ -318,6 +460,25 @@ int k_multi_axpy(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64
     });
     if (nrm2_dev) hipLaunchKernelGGL(nrm2_finish_kernel, dim3(1), dim3(64), 0, ctx->stream, blocks, partial, nrm2_dev);
     return check_launch(ctx, "multi_axpy");
+}
+
+// columns of X (n x ncols, complex, column-major): canonical phase (largest entry real positive), unit 2-norm when `unit`;
+// imag2_dev[c] = sum_i Im(X[i, c])^2 afterwards.  Three launches for all columns.
+int k_columns_canonical(lsa_ctx* ctx, int64_t n, int ncols, void* X, int64_t ldx, int unit, double* imag2_dev) {
+    if (ncols <= 0 || n <= 0) return LSA_OK;
+    const int nb = stream_blocks(ctx, n);
+    const size_t per = (size_t)ncols * nb;
+    LSA_CHECK(lsa_ensure_scratch(ctx, per * (3 * sizeof(double) + sizeof(long long)), 0));
+    double* nrm = (double*)ctx->dscratch;
+    double* mag = nrm + per;
+    double* imp = mag + per;
+    long long* idx = (long long*)(imp + per);
+    hipLaunchKernelGGL(col_stats_kernel, dim3(nb, ncols), dim3(kThreads), 0, ctx->stream, n, (const cplx*)X, ldx, nrm, mag, idx);
+    hipLaunchKernelGGL(col_phase_kernel, dim3(nb, ncols), dim3(kThreads), 0, ctx->stream, n, (cplx*)X, ldx, (const double*)nrm, (const double*)mag,
+                       (const long long*)idx, unit, imp);
+    hipLaunchKernelGGL(col_phase_finish_kernel, dim3(ncols), dim3(64), 0, ctx->stream, (cplx*)X, ldx, nb, (const double*)nrm, (const double*)mag,
+                       (const long long*)idx, unit, (const double*)imp, imag2_dev);
+    return check_launch(ctx, "columns_canonical");
 }
 
 int k_nrm2(lsa_ctx* ctx, int dtype, int64_t n, const void* x, double* nrm2_dev) {

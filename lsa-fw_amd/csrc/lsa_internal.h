@@ -192,6 +192,8 @@ int k_multi_dot(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_
 // w -= V h, and nrm2_dev[0] = ||w||^2 afterwards when nrm2_dev != null
 int k_multi_axpy(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, const void* h_dev, void* w,
                  double* nrm2_dev);
+// columns of X: canonical phase (largest entry real positive), unit norm when `unit`; imag2_dev[c] = sum Im(X[:, c])^2
+int k_columns_canonical(lsa_ctx* ctx, int64_t n, int ncols, void* X, int64_t ldx, int unit, double* imag2_dev);
 // nrm2_dev[0] = ||x||^2
 int k_nrm2(lsa_ctx* ctx, int dtype, int64_t n, const void* x, double* nrm2_dev);
 int k_mask(lsa_ctx* ctx, int dtype, int64_t n, const double* keep_dev, void* y);

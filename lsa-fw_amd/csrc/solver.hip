@@ -422,6 +422,8 @@ struct lsa_krylov {
     std::vector<zc> hcol;
     // pipelined Arnoldi steps (exact inner solves): Hessenberg columns and the b - C x checks of a batch of steps stay on
     // the device until the batch is read back with one synchronisation
+    double* imag2 = nullptr;         // device: sum Im^2 of the columns of the last canonical Ritz vectors
+    std::vector<double> imag_norms;  // ... their square roots on the host (lsa_krylov_imag_norms)
     void* Hdev = nullptr;      // batch x (ncv + 2) complex
     double* checks = nullptr;  // batch x 2: ||b - C x||^2, ||b||^2
     int32_t batch = 0;
@@ -775,7 +777,7 @@ void lsa_krylov_destroy(lsa_krylov* k) {
     if (!k) return;
     if (k->ctx && k->ctx->stream) (void)hipStreamSynchronize(k->ctx->stream);
     if (k->row_perm) (void)hipFree(k->row_perm);
-    for (void* p : {k->V, k->V2, k->w, k->qdev, k->Hdev, (void*)k->checks})
+    for (void* p : {k->V, k->V2, k->w, k->qdev, k->Hdev, (void*)k->checks, (void*)k->imag2})
         if (p) (void)hipFree(p);
     k->ow.release();
     delete k;
@@ -984,7 +986,14 @@ int lsa_krylov_ritz_vectors(lsa_ctx* ctx, lsa_krylov* k, int32_t m, int32_t nvec
         for (int32_t r = 0; r < m; ++r) p[(size_t)c * m + r] = Yh[(size_t)c * ldy + r];
     LSA_HIP_CHECK(ctx, hipMemcpyAsync(k->qdev, p, (size_t)m * nvec * 16, hipMemcpyHostToDevice, ctx->stream));
     LSA_CHECK(k_basis_gemm(ctx, LSA_C128, k->n, m, nvec, k->V, k->n, k->qdev, m, k->V2, k->n));
-    if (normalise) {
+    k->imag_norms.clear();
+    if (normalise & 2) {
+        // unit norm and canonical phase of all columns in three launches; the norms of the imaginary parts come back with them
+        if (!k->imag2) LSA_HIP_ALLOC(ctx, hipMalloc((void**)&k->imag2, (size_t)(k->ncv + 2) * sizeof(double)));
+        LSA_CHECK(k_columns_canonical(ctx, k->n, nvec, k->V2, k->n, normalise & 1, k->imag2));
+        k->imag_norms.assign((size_t)nvec, 0.0);
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync(k->imag_norms.data(), k->imag2, (size_t)nvec * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    } else if (normalise) {
         for (int32_t c = 0; c < nvec; ++c) {
             void* col = (char*)k->V2 + (size_t)c * vb;
             LSA_CHECK(k_nrm2(ctx, LSA_C128, k->n, col, k->ow.nrm2));
@@ -1004,6 +1013,13 @@ int lsa_krylov_ritz_vectors(lsa_ctx* ctx, lsa_krylov* k, int32_t m, int32_t nvec
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_krylov_ritz_vectors: download failed: %s", hipGetErrorString(e));
+    for (double& v : k->imag_norms) v = std::sqrt(v);
+    return LSA_OK;
+}
+
+int lsa_krylov_imag_norms(const lsa_krylov* k, int32_t nvec, double* out) {
+    if (!k || !out || nvec < 0 || (size_t)nvec > k->imag_norms.size()) return LSA_ERR_ARG;
+    for (int32_t c = 0; c < nvec; ++c) out[c] = k->imag_norms[(size_t)c];
     return LSA_OK;
 }
 

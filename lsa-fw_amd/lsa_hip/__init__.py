@@ -140,6 +140,7 @@ SIGNATURES = {
     "lsa_krylov_extend": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32, ctypes.POINTER(_I32)]),
     "lsa_krylov_restart": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32]),
     "lsa_krylov_ritz_vectors": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32, ctypes.c_int, _P]),
+    "lsa_krylov_imag_norms": (ctypes.c_int, [_P, _I32, _P]),
     "lsa_eig_residuals": (ctypes.c_int, [_P, _P, _P, _I32, _P, _P, _P]),
     "lsa_mm_open": (ctypes.c_int, [ctypes.c_char_p, _PP, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_int)]),
     "lsa_mm_read_csr": (ctypes.c_int, [_P, _P, _P, _P]),
@@ -736,12 +737,18 @@ class KrylovBasis:
         Q = np.asfortranarray(Q, dtype=np.complex128)
         self.ctx.check(self.ctx._lib.lsa_krylov_restart(self.ctx.handle, self.handle, int(m), Q.shape[1], _ptr(Q), Q.shape[0]))
 
-    def ritz_vectors(self, m: int, Y: np.ndarray, normalise: bool = True) -> np.ndarray:
+    def ritz_vectors(self, m: int, Y: np.ndarray, normalise: bool = True, canonical_phase: bool = True) -> np.ndarray:
+        """``X = V[:, :m] Y`` on the host; unit columns when ``normalise``; with ``canonical_phase`` also rotated so that the
+        entry of largest magnitude is real and positive, and ``self.imag_norms`` = the 2-norms of the imaginary parts."""
         Y = np.asfortranarray(Y, dtype=np.complex128)
         X = np.empty((self.n, Y.shape[1]), dtype=np.complex128, order="F")
-        self.ctx.check(
-            self.ctx._lib.lsa_krylov_ritz_vectors(self.ctx.handle, self.handle, int(m), Y.shape[1], _ptr(Y), Y.shape[0], int(normalise), _ptr(X))
-        )
+        mode = (1 if normalise else 0) | (2 if (normalise and canonical_phase) else 0)
+        self.ctx.check(self.ctx._lib.lsa_krylov_ritz_vectors(self.ctx.handle, self.handle, int(m), Y.shape[1], _ptr(Y), Y.shape[0], mode, _ptr(X)))
+        self.imag_norms = None
+        if mode & 2:
+            out = np.zeros(Y.shape[1], dtype=np.float64)
+            if self.ctx._lib.lsa_krylov_imag_norms(self.handle, Y.shape[1], _ptr(out)) == 0:
+                self.imag_norms = out
         return X
 
     def __del__(self):

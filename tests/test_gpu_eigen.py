@@ -490,3 +490,36 @@ def test_batched_arnoldi_steps_equal_one_step_at_a_time(hip_ctx, monkeypatch, ba
         got[b] = (kb.extend(0, 12, H), H.copy(), op.stats()["op_applies"])
     assert got[1][0] == got[batch][0] == 2  # three vectors span the subspace: the third step breaks down
     assert np.array_equal(got[1][1][:, :3], got[batch][1][:, :3]) and got[1][2] == got[batch][2] == 3
+
+
+def test_ritz_vectors_leave_the_device_normalised_and_in_canonical_phase(hip_ctx):
+    """``lsa_krylov_ritz_vectors`` with normalise = 3: unit 2-norm, the entry of largest magnitude real and positive, and
+    the norms of the imaginary parts reported -- all columns in three launches; what ``get_eigenvector`` used to do on the
+    host for every vector (``Solver/utils.py:280-291`` of the reference: the real build keeps the real part of a vector
+    whose imaginary part is below 1e-6)."""
+    import lsa_hip
+    from oracle import fem
+
+    es = fem.cylinder_case("S2k")
+    dA = lsa_hip.CsrMatrix.from_scipy(hip_ctx, es.A)
+    dM = lsa_hip.CsrMatrix.from_scipy(hip_ctx, es.M)
+    op = lsa_hip.ShiftInvertOperator(hip_ctx, dA, dM, fem.SIGMA_RE50, pc_type=2)
+    kb = lsa_hip.KrylovBasis(hip_ctx, op, 12)
+    kb.inject(0, np.random.default_rng(1).standard_normal(es.n) + 0j)
+    H = np.zeros((13, 12), dtype=np.complex128, order="F")
+    assert kb.extend(0, 12, H) == -1
+    rng = np.random.default_rng(2)
+    Y = rng.standard_normal((12, 5)) + 1j * rng.standard_normal((12, 5))
+    raw = kb.ritz_vectors(12, Y, normalise=False)
+    X = kb.ritz_vectors(12, Y, normalise=True)
+    assert kb.imag_norms is not None and kb.imag_norms.shape == (5,)
+    for c in range(5):
+        x, r = X[:, c], raw[:, c]
+        k = int(np.argmax(np.abs(r)))
+        assert abs(np.linalg.norm(x) - 1.0) <= 1e-14
+        assert x[k].imag == 0.0 and x[k].real > 0.0 and abs(x[k]) == np.abs(x).max()
+        ref = r * (np.conj(r[k]) / abs(r[k])) / np.linalg.norm(r)
+        assert np.linalg.norm(x - ref) <= 1e-13
+        assert abs(kb.imag_norms[c] - np.linalg.norm(x.imag)) <= 1e-13
+    plain = kb.ritz_vectors(12, Y, normalise=True, canonical_phase=False)
+    assert kb.imag_norms is None and np.allclose(np.abs(plain), np.abs(X), atol=1e-14)

@@ -598,8 +598,10 @@ class iEpsSolver:
                 logger.warning("The exact LU did not fit the device memory: the inner solves ran ILU(%d)-preconditioned GMRES instead.",
                                prep["levels"])
             if self._stats.get("backward_accepted"):
-                logger.info("%d inner solves were accepted on their backward error (the shift lies next to an eigenvalue).", self._stats["backward_accepted"])
-            if self._stats.get("stagnated_solves") or self._stats.get("max_rel_res", 0.0) > 10.0 * ksp_rtol:
+                logger.info("%d inner solves were accepted on their backward error (the shift lies next to eigenvalues: A - sigma M is "
+                            "ill-conditioned); worst true relative residual %.2e. A direct solver does no better; check residuals().",
+                            self._stats["backward_accepted"], self._stats.get("max_rel_res", 0.0))
+            if self._stats.get("stagnated_solves") or (self._stats.get("max_rel_res", 0.0) > 10.0 * ksp_rtol and not self._stats.get("backward_accepted")):
                 logger.warning("Inner solves stagnated above the requested tolerance: worst true relative residual %.2e (ksp_rtol %.1e, %d "
                                "solves accepted at the rounding floor). Eigenpairs are those of an inexactly applied operator; check "
                                "residuals().", self._stats.get("max_rel_res", 0.0), ksp_rtol, self._stats.get("stagnated_solves", 0))

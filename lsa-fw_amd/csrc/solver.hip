@@ -208,6 +208,7 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, PcRef pc, int dtype, const void* b
                 if (st) {
                     ++st->backward_accepted;
                     st->last_rel_res = beta0 / bnorm;
+                    st->max_rel_res = std::max(st->max_rel_res, beta0 / bnorm);  // (reported as it is: the Python layer warns above 10 rtol)
                 }
                 if (iters_out) *iters_out = 0;
                 if (relres_out) *relres_out = beta0 / bnorm;

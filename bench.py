@@ -427,10 +427,15 @@ def main() -> None:
         dev = int(os.environ.get("LSA_BENCH_DEVICE", local_rank))
         backend = os.environ.get("LSA_BENCH_BACKEND", "nccl")
         torch.cuda.set_device(dev)
+        # Five minutes per collective: the longest legitimate wait here is rank 0's roofline legs before the closing barrier
+        # (seconds).  A rank that fails on its own while the others sit in a collective then ends the job instead of
+        # leaving it to the backend's default of 10-30 minutes.
+        from datetime import timedelta
+
         if backend == "nccl":
-            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", dev))
+            dist_mod.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=timedelta(seconds=300))
         else:
-            dist_mod.init_process_group(backend)
+            dist_mod.init_process_group(backend, timeout=timedelta(seconds=300))
         dist = dist_mod
         reduce_device = "cuda" if backend == "nccl" else "cpu"
     device = int(os.environ.get("LSA_BENCH_DEVICE", local_rank)) if world > 1 else 0
@@ -458,10 +463,14 @@ def main() -> None:
     solver = None
     if sharded:
         # The sharded layout has more moving parts than anything else here (forest cut, RCCL bootstrap, exchange regions): if
-        # setting it up or the first solve fails on ANY rank, every rank falls back to independent replicas and the line says
-        # so -- a bench line with a note instead of no line.  (The ranks agree through the launcher's process group.)
+        # setting it up or the first solve fails on EVERY rank (a deterministic failure), the ranks fall back to independent
+        # replicas and the line says so -- a bench line with a note instead of no line.  (The ranks agree through the
+        # launcher's process group; a failure on SOME ranks only leaves the others inside the setup's own collectives and
+        # ends with the process group's time-out, as it would without this.)
         ok, why = 1, ""
         try:
+            if os.environ.get("LSA_BENCH_FAIL_SHARDED") in (str(rank), "all"):  # development: rehearse the fall-back below
+                raise RuntimeError("forced failure of the sharded setup (LSA_BENCH_FAIL_SHARDED)")
             solver = build_solver(es, sigma, args, device, args.pc, "sharded")
             solver.solver.prepare()
             solver.solve()

@@ -579,6 +579,7 @@ def main() -> None:
                 "pc": args.pc,
                 "other_pc": other,
                 "layout": "single GPU" if world == 1 else "sharded" if sharded else "replicas: one shift of the Re sweep per rank" if args.sweep
+                          else f"replicas: every rank solves the same {args.case} problem (fall-back from the sharded layout)" if layout_note
                           else "replicas of the N = 1 workload",
                 "parallelism": None if world == 1 else (
                     (f"one problem over {world} ranks: rows of A, M, C sharded (SpMV + all-gather), Krylov bases replicated, "

@@ -87,6 +87,7 @@ void lsa_ctx_destroy(lsa_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     lsa_blu_drop_cache(ctx);
     lsa_ndlu_drop_cache(ctx);
+    lsa_krylov_drop_cache(ctx);
     comm_release(ctx);  // before the stream the communicator is bound to goes away
     if (ctx->dscratch) (void)hipFree(ctx->dscratch);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);

@@ -106,9 +106,11 @@ struct lsa_ctx {
     // a shift sweep refactorises the same pattern once per sigma (.examples/eigenvalues.py:97-108)
     struct lsa_blu* blu_cache = nullptr;
     struct lsa_ndlu* nd_cache = nullptr;  // the same for the nested-dissection LU (analysis + tables + buffers)
+    struct lsa_krylov* krylov_cache = nullptr;  // the last destroyed Krylov workspace (two bases, work vectors), reused by the next of the same shape
 };
 extern "C" void lsa_blu_drop_cache(lsa_ctx* ctx);   // blocklu.hip (internal; not part of include/lsa_hip.h)
 extern "C" void lsa_ndlu_drop_cache(lsa_ctx* ctx);  // ndlu.hip
+extern "C" void lsa_krylov_drop_cache(lsa_ctx* ctx);  // solver.hip
 
 struct lsa_vec {
     lsa_ctx* ctx;

@@ -147,7 +147,8 @@ struct GmresWork {
         restart = restart_;
         dtype = dtype_;
         const size_t vb = (size_t)std::max<int64_t>(n, 1) * esize(dtype);
-        LSA_HIP_CHECK(ctx, hipMalloc(&V, vb * (size_t)(restart + 1)));
+        // (the basis itself is allocated when an iteration actually starts: behind an exact LU solve that is the exception,
+        //  and 41 vectors are 330 MB at 500 k unknowns, per operator, i.e. per solve)
         LSA_HIP_CHECK(ctx, hipMalloc(&w, vb));
         LSA_HIP_CHECK(ctx, hipMalloc(&z, vb));
         // shards write only their own rows: the padding rows of the block layout must read as zero
@@ -161,6 +162,12 @@ struct GmresWork {
         g.assign(restart + 2, zc(0));
         y.assign(restart + 1, zc(0));
         hcol.assign(restart + 2, zc(0));
+        return LSA_OK;
+    }
+    int ensure_basis(lsa_ctx* ctx) {
+        if (V) return LSA_OK;
+        const size_t vb = (size_t)std::max<int64_t>(n, 1) * esize(dtype);
+        LSA_HIP_ALLOC(ctx, hipMalloc(&V, vb * (size_t)(restart + 1)));
         return LSA_OK;
     }
     void release() {
@@ -267,6 +274,7 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, PcRef pc, int dtype, const void* b
             break;
         }
         if (verified_cycles > 0) last_verified = relres;
+        LSA_CHECK(W.ensure_basis(ctx));
         LSA_CHECK(k_scale_by_inv_norm(ctx, dtype, n, W.w, W.ow.nrm2, col(0)));
         std::fill(W.g.begin(), W.g.end(), zc(0));
         W.g[0] = zc(beta, 0);
@@ -424,12 +432,20 @@ struct lsa_krylov {
     // pipelined Arnoldi steps (exact inner solves): Hessenberg columns and the b - C x checks of a batch of steps stay on
     // the device until the batch is read back with one synchronisation
     double* imag2 = nullptr;         // device: sum Im^2 of the columns of the last canonical Ritz vectors
+    void* xtmp = nullptr;            // device: the Ritz vectors in the caller's row order (ncv + 1 columns), allocated on first use
     std::vector<double> imag_norms;  // ... their square roots on the host (lsa_krylov_imag_norms)
     void* Hdev = nullptr;      // batch x (ncv + 2) complex
     double* checks = nullptr;  // batch x 2: ||b - C x||^2, ||b||^2
     int32_t batch = 0;
     bool pipeline = false;
 };
+
+static void krylov_free(lsa_krylov* k) {
+    for (void* p : {k->V, k->V2, k->w, k->qdev, k->Hdev, (void*)k->checks, (void*)k->imag2, k->xtmp, (void*)k->row_perm})
+        if (p) (void)hipFree(p);
+    k->ow.release();
+    delete k;
+}
 
 extern "C" {
 
@@ -743,13 +759,30 @@ int lsa_op_stats(const lsa_op* op, lsa_stats* out) {
 // ---- Krylov basis ------------------------------------------------------------------------------------------------
 int lsa_krylov_create(lsa_ctx* ctx, lsa_op* op, int32_t ncv, lsa_krylov** out) {
     if (!ctx || !op || !out || ncv < 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_create: bad argument");
+    const size_t vb = (size_t)std::max<int64_t>(op->n, 1) * 16;
+    const char* be = getenv("LSA_KRYLOV_BATCH");
+    const int32_t batch = be && *be ? std::max(0, std::min(atoi(be), 256)) : 16;
+    if (lsa_krylov* c = ctx->krylov_cache) {
+        // A shift sweep (and every repeated solve) builds one Krylov workspace per solve: two bases of ncv + 1 vectors
+        // (80 MB at 30 k unknowns, 1.3 GB at 500 k).  The last one destroyed is kept and handed out again when the shape
+        // matches, instead of being freed and allocated anew (LSA_KRYLOV_NO_CACHE switches this off).
+        ctx->krylov_cache = nullptr;
+        if (c->n == op->n && c->ncv == ncv && c->batch == batch) {
+            c->op = op;
+            c->pipeline = batch > 1;
+            c->imag_norms.clear();
+            (void)hipMemsetAsync(c->w, 0, vb, ctx->stream);
+            *out = c;
+            return LSA_OK;
+        }
+        krylov_free(c);
+    }
     lsa_krylov* k = new lsa_krylov();
     k->ctx = ctx;
     k->op = op;
     k->n = op->n;
     k->ncv = ncv;
     k->V = k->V2 = k->w = k->qdev = nullptr;
-    const size_t vb = (size_t)std::max<int64_t>(k->n, 1) * 16;
     bool ok = hipMalloc(&k->V, vb * (size_t)(ncv + 1)) == hipSuccess && hipMalloc(&k->V2, vb * (size_t)(ncv + 1)) == hipSuccess &&
               hipMalloc(&k->w, vb) == hipSuccess && hipMalloc(&k->qdev, (size_t)(ncv + 1) * (size_t)(ncv + 1) * 16) == hipSuccess;
     if (!ok || k->ow.alloc(ctx, ncv + 1, LSA_C128) != LSA_OK) {
@@ -760,8 +793,7 @@ int lsa_krylov_create(lsa_ctx* ctx, lsa_op* op, int32_t ncv, lsa_krylov** out) {
     k->hcol.assign((size_t)ncv + 2, zc(0));
     // Arnoldi steps are queued in batches when the inner solve is one exact LU solve and the exchange (if any) is
     // stream-ordered (RCCL): LSA_KRYLOV_BATCH steps per read-back (default 16; 0 or 1 = one step at a time)
-    const char* be = getenv("LSA_KRYLOV_BATCH");
-    k->batch = be && *be ? std::max(0, std::min(atoi(be), 256)) : 16;
+    k->batch = batch;
     if (k->batch > 1) {
         if (hipMalloc(&k->Hdev, (size_t)k->batch * (size_t)(ncv + 2) * 16) != hipSuccess ||
             hipMalloc((void**)&k->checks, (size_t)k->batch * 2 * sizeof(double)) != hipSuccess) {
@@ -776,12 +808,24 @@ int lsa_krylov_create(lsa_ctx* ctx, lsa_op* op, int32_t ncv, lsa_krylov** out) {
 
 void lsa_krylov_destroy(lsa_krylov* k) {
     if (!k) return;
-    if (k->ctx && k->ctx->stream) (void)hipStreamSynchronize(k->ctx->stream);
+    lsa_ctx* ctx = k->ctx;
+    if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (k->row_perm) (void)hipFree(k->row_perm);
-    for (void* p : {k->V, k->V2, k->w, k->qdev, k->Hdev, (void*)k->checks, (void*)k->imag2})
-        if (p) (void)hipFree(p);
-    k->ow.release();
-    delete k;
+    k->row_perm = nullptr;
+    k->op = nullptr;
+    if (ctx && k->V && k->V2 && k->w && k->qdev && k->ow.h1 && !getenv("LSA_KRYLOV_NO_CACHE")) {  // (a half-built workspace is not worth keeping)
+        if (ctx->krylov_cache) krylov_free(ctx->krylov_cache);
+        ctx->krylov_cache = k;
+        return;
+    }
+    krylov_free(k);
+}
+
+void lsa_krylov_drop_cache(lsa_ctx* ctx) {
+    if (ctx && ctx->krylov_cache) {
+        krylov_free(ctx->krylov_cache);
+        ctx->krylov_cache = nullptr;
+    }
 }
 
 int lsa_krylov_set_row_permutation(lsa_ctx* ctx, lsa_krylov* k, const int32_t* perm) {
@@ -980,7 +1024,7 @@ int lsa_krylov_ritz_vectors(lsa_ctx* ctx, lsa_krylov* k, int32_t m, int32_t nvec
     if (m < 1 || m > k->ncv + 1 || nvec < 0 || nvec > k->ncv + 1 || ldy < m) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_ritz_vectors: bad sizes");
     if (nvec == 0) return LSA_OK;
     const size_t vb = (size_t)k->n * 16;
-    LSA_CHECK(lsa_ensure_scratch(ctx, 0, (size_t)m * nvec * 16));
+    LSA_CHECK(lsa_ensure_scratch(ctx, 0, (size_t)m * nvec * 16 + (size_t)nvec * sizeof(double)));
     const cplx* Yh = (const cplx*)Y;
     cplx* p = (cplx*)ctx->pinned;
     for (int32_t c = 0; c < nvec; ++c)
@@ -993,7 +1037,8 @@ int lsa_krylov_ritz_vectors(lsa_ctx* ctx, lsa_krylov* k, int32_t m, int32_t nvec
         if (!k->imag2) LSA_HIP_ALLOC(ctx, hipMalloc((void**)&k->imag2, (size_t)(k->ncv + 2) * sizeof(double)));
         LSA_CHECK(k_columns_canonical(ctx, k->n, nvec, k->V2, k->n, normalise & 1, k->imag2));
         k->imag_norms.assign((size_t)nvec, 0.0);
-        LSA_HIP_CHECK(ctx, hipMemcpyAsync(k->imag_norms.data(), k->imag2, (size_t)nvec * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        // (into the pinned scratch, behind the packed Y: an asynchronous copy to pageable memory is staged by the runtime)
+        LSA_HIP_CHECK(ctx, hipMemcpyAsync((char*)ctx->pinned + (size_t)m * nvec * 16, k->imag2, (size_t)nvec * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     } else if (normalise) {
         for (int32_t c = 0; c < nvec; ++c) {
             void* col = (char*)k->V2 + (size_t)c * vb;
@@ -1005,16 +1050,16 @@ int lsa_krylov_ritz_vectors(lsa_ctx* ctx, lsa_krylov* k, int32_t m, int32_t nvec
     const void* src = k->V2;
     void* tmp = nullptr;
     if (k->row_perm) {  // rows back into the caller's numbering on the device (a fancy-indexed scatter of n x nvec on the host costs more than the solve's Schur forms)
-        LSA_HIP_ALLOC(ctx, hipMalloc(&tmp, vb * (size_t)nvec));
+        if (!k->xtmp) LSA_HIP_ALLOC(ctx, hipMalloc(&k->xtmp, vb * (size_t)(k->ncv + 1)));
+        tmp = k->xtmp;
         const int blocks = (int)std::min<int64_t>((k->n + 255) / 256, (int64_t)ctx->num_cu * 16);
         hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks, nvec), dim3(256), 0, ctx->stream, k->n, k->row_perm, (const cplx*)k->V2, (cplx*)tmp);
         src = tmp;
     }
     hipError_t e = hipMemcpyAsync(X, src, vb * (size_t)nvec, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (tmp) (void)hipFree(tmp);
     if (e != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_krylov_ritz_vectors: download failed: %s", hipGetErrorString(e));
-    for (double& v : k->imag_norms) v = std::sqrt(v);
+    for (size_t c = 0; c < k->imag_norms.size(); ++c) k->imag_norms[c] = std::sqrt(((const double*)((const char*)ctx->pinned + (size_t)m * nvec * 16))[c]);
     return LSA_OK;
 }
 

@@ -403,6 +403,15 @@ class iEpsSolver:
         return (id(self._A), id(self._M), self._st_type, self._target, self._pc_type, self._ilu_levels, self._ordering, self._device,
                 self._layout, self._lu, self._adjoint)  # (the antishift only changes the multiplied matrix, built per solve)
 
+    def _only_the_target_moved(self, prev: dict, sig: tuple) -> bool:
+        old = prev["sig"]
+        if old[:3] + old[4:] != sig[:3] + sig[4:] or not prev["sinvert"] or prev["part"] is not None or prev["forest"] is not None:
+            return False
+        if self._target is None or old[3] is None:
+            return False
+        # real <-> complex factors are different scalar types on the device (lsa_ndlu_prepare)
+        return (complex(old[3]).imag != 0.0) == (complex(self._target).imag != 0.0)
+
     def prepare(self) -> None:
         """Host-side analysis + upload: shared pattern, fill-reducing / pivot-safe ordering, CSR -> HBM.
 
@@ -412,7 +421,14 @@ class iEpsSolver:
 
         if self._A is None:
             raise ValueError("Operators are not set.")
-        if getattr(self, "_prepared", None) is not None and self._prepared["sig"] == self._signature():
+        prev, sig = getattr(self, "_prepared", None), self._signature()
+        if prev is not None and prev["sig"] == sig:
+            return
+        if prev is not None and self._only_the_target_moved(prev, sig):
+            # A shift sweep on one pair (A, M) -- the interval solve behind iEpsWhich.ALL, a user scanning targets: everything
+            # prepared depends on the PATTERN of A - sigma M and on whether its factors are real or complex, not on the shift.
+            # The context (with its cached analysis and buffers), the uploaded matrices and the ordering stay.
+            prev["sigma"], prev["sig"] = self._target, sig
             return
         self.release()
         A = self._A.as_scipy_array()

@@ -109,3 +109,37 @@ def test_refined_meshes_residuals_and_start_vector_independence(case):
     # the target agree to 1e-8, all twenty to 1e-7.
     d = np.array([np.min(np.abs(lams[1] - r)) / abs(r) for r in lams[0]])
     assert d[:10].max() <= 1e-8 and d.max() <= 1e-7
+
+
+def test_moving_the_target_keeps_what_was_prepared():
+    """A new target on the same (A, M) re-uses the context, the uploaded matrices, the ordering and the cached analysis
+    (only the pattern of A - sigma M and the scalar type of its factors matter to them); the answers are those of a solver
+    built at the new target from scratch.  Real <-> complex shifts change the factors' type and prepare anew."""
+    from oracle import fem
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    es = fem.cylinder_case("S5k")
+
+    def make(target):
+        s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=6, atol=1e-10, ncv=40), check_hermitian=False)
+        s.solver.set_st_type(iSTType.SINVERT)
+        s.solver.set_st_pc_type(PreconditionerType.LU)
+        s.solver.set_target(target)
+        return s
+
+    s1 = make(fem.SIGMA_RE50)
+    s1.solve()
+    ctx = s1.solver._prepared["ctx"]
+    sigma2 = fem.SIGMA_RE50 + (0.03 - 0.02j)
+    s1.solver.set_target(sigma2)
+    moved = s1.solve()
+    assert s1.solver._prepared["ctx"] is ctx and s1.solver.stats["analysis_reused"] == 1
+    fresh = make(sigma2).solve()
+    assert len(moved) == len(fresh) == 6
+    for (l1, v1), (l2, v2) in zip(moved, fresh):
+        assert l1 == l2 and np.array_equal(v1.as_array(), v2.as_array())
+    assert s1.solver.residuals().max() <= 1e-8
+    s1.solver.set_target(0.05)  # a real shift: float64 factors, a different preparation
+    real = s1.solve()
+    assert s1.solver._prepared["ctx"] is not ctx and len(real) == 6 and s1.solver.residuals().max() <= 1e-8

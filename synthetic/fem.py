@@ -506,7 +506,7 @@ def assemble_linearized_ns_3d(mesh: CubeMesh, re: float = 10.0, *, baseflow=duct
     return EigenSystem(A, M, np.flatnonzero(mask).astype(np.int32), dofs_p.astype(np.int32), ddofs.astype(np.int32), mesh, node_offset)
 
 
-CUBE_CASES = {"C2k": 4, "C9k": 7, "C20k": 9, "C40k": 11, "C80k": 14, "C160k": 18, "C300k": 22, "C640k": 29, "C1M": 34, "C5M": 58}
+CUBE_CASES = {"C2k": 4, "C9k": 7, "C20k": 9, "C40k": 11, "C80k": 14, "C160k": 18, "C300k": 22, "C640k": 29, "C1M": 34, "C2M": 43, "C5M": 58}
 SIGMA_CUBE = -5.0  # shift of the 3D case: next to the least stable physical modes of the Re = 10 duct (-5.99, -6.00, -6.8, ...) and
 # away from the spurious lambda = 1 of the identity Dirichlet rows; real, so the factors are float64
 

@@ -14,19 +14,25 @@ reported under config.other_pc so both numbers are always on the line.
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-N > 1, default `--layout sharded` (the layout BASELINE.json's north_star names): ONE problem, its rows cut into N blocks,
-one rank per GPU.  Each rank holds its rows of A, M, C = A - sigma M and the exact LU of its diagonal block; the Krylov
-bases are replicated; every SpMV and every preconditioner apply ends with one in-place all-gather (RCCL over xGMI);
-the inner solve is GMRES preconditioned by the block-Jacobi LU.  Total work is fixed as N grows ("strong"); `value`
-counts the pairs of that one problem.  The line carries the inner iterations per apply and the all-gather traffic.
-`--layout replicas` (reported as config.replicas in the sharded line too): every rank solves the N = 1 workload on its
+N > 1, default `--layout sharded` (the layout BASELINE.json's north_star names; BASELINE config 3): ONE problem -- the
+500 k-unknown cylinder pair -- solved by all ranks together, one rank per GPU.  The nested-dissection forest of
+C = A - sigma M is cut over the ranks: every rank factors its subtrees, the subtree roots' fronts are exchanged by one
+in-place all-gather (RCCL over xGMI) and the small top of the forest is factored redundantly; the Krylov bases are
+replicated; an operator apply is the exact solve of the one-GPU path (no inner iteration) with two all-gathers (the
+subtree roots' update vectors, the solution blocks) on the 2D pattern.  Total work is fixed as N grows ("strong"); `value`
+counts the pairs of that one problem; the line carries the exchanges per solve and, as `config.replicas`, the rate of
+N independent solves of the same problem (its one-GPU reference).  If the sharded set-up fails on every rank the ranks fall
+back to those replicas and say so (`config.layout_note`).  `--layout replicas`: every rank solves the N = 1 workload on its
 own, no data-path collective ("weak"); `--sweep` gives each rank its own shift of the reference's Re-sweep table
-(.examples/eigenvalues.py:37-49) instead.  Rehearsal on one GPU: LSA_BENCH_DEVICE=0 LSA_BENCH_BACKEND=gloo (all ranks on
-device 0, host-staged all-gather through gloo).
+(.examples/eigenvalues.py:37-49) instead.  Rehearsal on one GPU: tools/rehearse_two_ranks.sh (LSA_BENCH_DEVICE=0
+LSA_BENCH_BACKEND=gloo: all ranks on device 0, host-staged all-gather through gloo).
+
+Set-up (untimed): assembly, prepare() (ordering, upload, pattern analysis) and the process's first two solves (one-time costs
+of kernel loading and of the runtime); then W warm-up steps, then K timed steps between barriers.
 
 Rank 0 prints ONE JSON line.  `roofline` is measured on the SpMV kernel (the kernel the metric names) on SROOF, a
 ~1.5e8-nnz CSR with the cylinder-flow row pattern that does not fit the 256 MB Infinity Cache; `cpu_baseline` is the
-oracle (scipy ARPACK + SuperLU, the algorithm Solver/eigen2.py states) on the same S30k problem on the host cores.
+oracle (scipy ARPACK + SuperLU, the algorithm Solver/eigen2.py states) on the same S30k problem on the host cores (N = 1 only).
 """
 
 from __future__ import annotations

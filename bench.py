@@ -598,10 +598,12 @@ def main() -> None:
                           else f"replicas: every rank solves the same {args.case} problem (fall-back from the sharded layout)" if layout_note
                           else "replicas of the N = 1 workload",
                 "parallelism": None if world == 1 else (
-                    (f"one problem over {world} ranks: rows of A, M, C sharded (SpMV + all-gather), Krylov bases replicated, "
+                    (f"one problem over {world} ranks, Krylov bases replicated, "
                      + ("subtree-parallel exact LU (own subtrees of the nested-dissection forest, all-gather of the subtree roots' update "
-                        "vectors, replicated top, all-gather of the solution)" if args.pc == "lu"
-                        else "block-Jacobi ILU(k) + GMRES, all-gather after every SpMV and preconditioner apply")) if sharded else f"{world} independent solves"),
+                        "vectors, replicated top, all-gather of the solution); the sparse products replicated on the 2D pattern, "
+                        "on the rank's rows + all-gather on the 3D one" if args.pc == "lu"
+                        else "rows of A, M, C sharded, block-Jacobi ILU(k) + GMRES, all-gather after every SpMV and preconditioner apply")) if sharded
+                    else f"{world} independent solves"),
                 "gmres_iters_per_apply": (stats.get("gmres_iters", 0) / max(stats.get("op_applies", 1), 1)) if sharded else None,
                 "allgather_calls_per_solve": stats.get("allgather_calls") if sharded else None,
                 "allgather_bytes_received_per_rank_per_solve": stats.get("allgather_bytes_received") if sharded else None,

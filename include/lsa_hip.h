@@ -329,9 +329,11 @@ int lsa_op_create_sharded(lsa_ctx *ctx, const lsa_mat *A_rows, const lsa_mat *M_
                           const lsa_mat *M_diag, const double sigma[2], int mode, const lsa_op_options *opts, lsa_op **out);
 
 /* Shift-invert operator of the subtree-parallel layout: every rank holds the WHOLE matrices A, M in the padded block layout
- * (n_pad x n_pad, empty padding rows) and the forest of lsa_ndlu_create_tree; it multiplies with its rows [row0, row1) (then
- * all-gather) and solves with the subtree-parallel exact LU (own subtrees, one small all-gather, replicated top, all-gather
- * of the solution): three collectives per operator apply and no inner iteration.  mode 0 or 2, opts->pc_type 2. */
+ * (n_pad x n_pad, empty padding rows) and the forest of lsa_ndlu_create_tree, and solves with the subtree-parallel exact LU
+ * (own subtrees, one small all-gather, replicated top, all-gather of the solution): no inner iteration.  The sparse products
+ * run on the whole matrix on every rank when the pattern has at most 60 entries per row (cheaper than an exchange: two
+ * collectives per operator apply), on the rank's rows [row0, row1) followed by an all-gather otherwise (four).  mode 0 or
+ * 2, opts->pc_type 2. */
 int lsa_op_create_dist(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, int32_t row0, int32_t row1, int32_t ntree, const int32_t *first,
                        const int32_t *size, const int32_t *parent, const int32_t *owner, const double sigma[2], int mode,
                        const lsa_op_options *opts, lsa_op **out);

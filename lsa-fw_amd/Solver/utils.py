@@ -463,7 +463,8 @@ class iEpsSolver:
         if self._layout == "sharded" and world > 1 and pc_code == 2 and sinvert:
             # Subtree-parallel exact LU (the LU-class setting of the reference, sharded): the nested-dissection forest is cut
             # over the ranks, a rank's unknowns are one row block of the padded layout, every rank holds the whole (A, M)
-            # -- it multiplies with its rows and factors its subtrees plus the replicated top of the forest.
+            # -- it factors its subtrees plus the replicated top of the forest; the sparse products run replicated (2D patterns)
+            # or on its rows (3D patterns), see lsa_op_create_dist.
             from lsa_hip import sharding
 
             rank = _dist_rank_world()[0]

@@ -154,6 +154,12 @@ typedef struct lsa_ndlu lsa_ndlu;      /* factorisation resident in HBM      */
  * is numerically zero (the pressure rows of a saddle-point matrix): they are eliminated after all their neighbours, which
  * keeps every pivot block non-singular.  The handle is returned on failure too (for lsa_nd_sym_error). */
 int lsa_nd_analyse(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t leaf_size, const int8_t *constraint, lsa_nd_sym **out);
+/* Ordering only: the dissection's elimination order and forest, without the index tables.  lsa_nd_sym_export then fills
+ * perm, node_start, parent and level (front_size = own size, idx untouched).  A caller that permutes its matrices by perm
+ * and hands the forest back (first = node_start[t], size = node_start[t + 1] - node_start[t]: lsa_ndlu_prepare_tree) runs the
+ * whole iteration in the elimination order: a node's own unknowns are contiguous in every vector, and the sweeps of the
+ * factorisation address them without index lists. */
+int lsa_nd_order(int32_t n, const int32_t *rowptr, const int32_t *col, int32_t leaf_size, const int8_t *constraint, lsa_nd_sym **out);
 /* The same analysis for a tree the caller provides, optionally localised for one rank of a subtree-parallel
  * factorisation.  Node t owns the matrix indices [first[t], first[t] + size[t]) (nodes in any order in which parent[] can be
  * looked up; -1 = root); owner[t] (NULL on one rank) = the rank whose subtree the node belongs to, -1 = the replicated top
@@ -192,6 +198,10 @@ int lsa_ndlu_create(lsa_ctx *ctx, const lsa_mat *C, int32_t leaf_size, lsa_ndlu 
  * the pattern-only work out of a timed solve (the Python layer calls it from prepare()).  constraint: as for
  * lsa_nd_analyse (NULL: none). */
 int lsa_ndlu_prepare(lsa_ctx *ctx, const lsa_mat *P, int dtype, int32_t leaf_size, const int8_t *constraint);
+/* The same with the caller's forest (arguments as for lsa_nd_analyse_tree on one rank; normally the forest of lsa_nd_order on
+ * the matrix permuted by its perm). */
+int lsa_ndlu_prepare_tree(lsa_ctx *ctx, const lsa_mat *P, int dtype, int32_t ntree, const int32_t *first, const int32_t *size,
+                          const int32_t *parent);
 /* Subtree-parallel form (one process per GPU, after lsa_comm_init*): every rank holds the whole matrix C and calls this with
  * the same forest (arguments as for lsa_nd_analyse_tree; the context's rank selects the localisation).  A rank factors
  * the subtrees it owns; the subtree roots' fronts are exchanged by one in-place all-gather; the top of the forest
@@ -210,8 +220,9 @@ int lsa_ndlu_solve(lsa_ctx *ctx, lsa_ndlu *f, const lsa_vec *b, lsa_vec *x);
  * factorisation and no transposed matrix. */
 int lsa_ndlu_solve_adjoint(lsa_ctx *ctx, lsa_ndlu *f, int conj, const lsa_vec *b, lsa_vec *x);
 int lsa_ndlu_solve_time(lsa_ctx *ctx, lsa_ndlu *f, const lsa_vec *b, lsa_vec *x, int iters, double *avg_ms);
-/* apply_bytes: algorithmic bytes of one solve (every factor scalar once + the vectors); apply_launches: dependent
- * launches of one solve (two per tree level) */
+/* front_entries: scalars of the device buffers (packed factors + the working fronts of one chunk + the update arena);
+ * apply_bytes: algorithmic bytes of one solve (every factor scalar once + the vectors); apply_launches: dependent
+ * launches of one solve (two per tree level, less one: the roots have no downward step) */
 int lsa_ndlu_info(const lsa_ndlu *f, int32_t *ntree, int32_t *nlevels, int32_t *max_front, int64_t *factor_entries,
                   int64_t *front_entries, int64_t *apply_bytes, int32_t *apply_launches, double *seconds_analyse,
                   double *seconds_numeric);
@@ -285,6 +296,69 @@ int lsa_krylov_imag_norms(const lsa_krylov *k, int32_t nvec, double *out);
  * res[i] = ||A x_i - lam_i M x_i|| / (||A x_i|| + |lam_i| ||M x_i|| + 1e-16), X on the host (n x nvec). */
 int lsa_eig_residuals(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, int32_t nvec, const void *lam, const void *X,
                       double *res);
+
+/* ---- the whole eigen-solve behind one call: SLEPc.EPS.solve() (Solver/utils.py:268-270) ------------------------------------------
+ * Krylov-Schur outer iteration (SLEPc's default EPS: expand to ncv vectors, Schur form of the projected matrix with the wanted
+ * Ritz values first, residual estimates |b^H y|, relative convergence test EPS_CONV_REL, restart with nconv + (m - nconv)/2
+ * vectors) with the dense ncv x ncv algebra done by the library itself on the host (in-tree complex QR algorithm: no LAPACK
+ * is needed by a consumer of this header).  lsa_hip/krylov_schur.py is the same loop in Python over LAPACK, kept as the test
+ * double and for `which` policies that need callbacks. */
+typedef enum {  /* EPSWhich on the eigenvalues lambda of the pencil (iEpsWhich, Solver/utils.py:152-187) */
+    LSA_WHICH_LARGEST_MAGNITUDE = 1,
+    LSA_WHICH_LARGEST_REAL = 3,
+    LSA_WHICH_SMALLEST_REAL = 4,
+    LSA_WHICH_LARGEST_IMAGINARY = 5,
+    LSA_WHICH_SMALLEST_IMAGINARY = 6,
+    LSA_WHICH_TARGET_MAGNITUDE = 7,
+    LSA_WHICH_TARGET_REAL = 8,
+    LSA_WHICH_TARGET_IMAGINARY = 9
+} lsa_which;
+typedef struct {
+    int32_t nev;            /* eigenpairs wanted                                                                       */
+    int32_t max_restarts;   /* EPS max_it                                                                              */
+    double tol;             /* relative tolerance on the residual estimate of a Ritz pair                             */
+    int32_t which;          /* lsa_which                                                                               */
+    int32_t transform;      /* how a Ritz value theta of the operator maps to lambda: 0 = sigma + 1/theta (shift-invert),
+                               1 = theta + sigma (shift), 2 = (sigma theta + nu) / (theta - 1) (Cayley)               */
+    double sigma[2];        /* the operator's shift                                                                    */
+    double antishift[2];    /* nu of the Cayley transform                                                              */
+    double target[2];       /* target of the TARGET_* policies                                                         */
+    uint64_t seed;          /* of the start vector (when v0 is NULL) and of the fresh directions after a breakdown     */
+    double keep_fraction;   /* share of the unconverged part of the basis kept at a restart (0.5)                      */
+} lsa_ks_options;
+typedef struct {
+    int32_t nconv;          /* converged pairs (may exceed nev, like EPS.getConverged())                               */
+    int32_t nout;           /* pairs written: min(nconv, max_out)                                                      */
+    int32_t restarts;
+    int32_t pad;
+    int64_t op_applies;
+    double next_unconverged; /* relative residual estimate of the first pair that missed the tolerance                 */
+} lsa_ks_result;
+/* n and ncv of a basis */
+int lsa_krylov_shape(const lsa_krylov *k, int64_t *n, int32_t *ncv);
+/* rows of a matrix handle (local rows of a shard) */
+int64_t lsa_mat_rows(const lsa_mat *m);
+/* The outer iteration on an existing basis (any operator: shift-invert, shift, Cayley, projected, adjoint, sharded).
+ * v0: host start vector (n complex) or NULL (random from opts->seed); mask: NULL or n 0/1 doubles applied to every injected
+ * vector (projected operators, padding of the sharded layout).  Outputs, wanted first: theta_out / lambda_out[max_out]
+ * (complex), X_out (n x max_out complex column-major, unit 2-norm, canonical phase; NULL: no vectors), est_out[max_out]
+ * relative residual estimates.  Returns LSA_OK also when fewer than nev pairs converged in max_restarts (see result). */
+int lsa_krylov_solve(lsa_ctx *ctx, lsa_krylov *k, const lsa_ks_options *opts, const void *v0, const double *mask, int32_t max_out,
+                     void *theta_out, void *lambda_out, void *X_out, double *est_out, lsa_ks_result *result);
+/* Eigenpairs of A x = lambda M x nearest sigma in ONE call: builds and factors A - sigma M (lsa_op_create, mode 0), allocates
+ * the basis, iterates, writes the pairs and releases everything.  ncv <= 0: max(2 nev, nev + 15) (SLEPc's default).  row_perm:
+ * NULL, or perm[i] = the caller's index of row i (the matrices were uploaded in a permuted order, e.g. that of lsa_nd_order):
+ * the vectors come back in the caller's numbering.  stats: NULL or the operator's counters. */
+int lsa_eigs_sinvert(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, const double sigma[2], int32_t nev, int32_t ncv, double tol,
+                     int32_t max_restarts, const lsa_op_options *opts, const void *v0, const int32_t *row_perm, int32_t max_out,
+                     void *lambda_out, void *X_out, double *est_out, lsa_ks_result *result, lsa_stats *stats);
+/* The dense kernels of that iteration, for tests (host only; complex column-major):
+ *   lsa_dense_schur: A = Q T Q^H, T (upper triangular) over A, Q written; LSA_ERR_DIVERGED if the QR algorithm stalls
+ *   lsa_dense_schur_reorder: the diagonal entries with select[k] != 0 move to the leading block (orders kept), T and Q updated
+ *   lsa_dense_tri_eigenvectors: right eigenvectors of the upper triangular T, unit 2-norm columns of S */
+int lsa_dense_schur(int32_t n, void *A, int32_t lda, void *Q, int32_t ldq);
+int lsa_dense_schur_reorder(int32_t n, void *T, int32_t ldt, void *Q, int32_t ldq, const int32_t *select, int32_t *nselected);
+int lsa_dense_tri_eigenvectors(int32_t n, const void *T, int32_t ldt, void *S, int32_t lds);
 
 /* ---- MatrixMarket reader (host only): the A.mtx / M.mtx stage boundary --------------------------------------------
  * Stands in for scipy.io.mmread + the per-entry setValue loop of iPETScMatrix.from_path / from_matrix

@@ -451,7 +451,22 @@ class iEpsSolver:
             K = _combine(A, M, sigma) if M is not None else A  # the matrix that gets factorised
         else:
             K = M
-        if self._ordering == "rcm" and n > 8 and pc_code >= 1 and K is not None:
+        nd_tree = None
+        if pc_code == 2 and K is not None and n > 8 and self._ordering != "natural" and not (self._layout == "sharded" and _dist_rank_world()[1] > 1):
+            # Exact nested-dissection LU: the whole iteration runs in ITS elimination order (a tree node's own unknowns are
+            # contiguous in every vector: the sweeps address them without index lists); the forest goes back to the library
+            # with the permuted pattern.  Zero-diagonal (pressure) unknowns as constraints, eliminated after their
+            # neighbours, on 3D-like patterns (> 60 entries per row), where a leaf subdomain can hold more pressure
+            # unknowns than its interior supports; costs 20 % more factor entries in 2D, where it has not been needed (and
+            # the library re-analyses by itself if it ever is).
+            Kc = sp.csr_matrix(K)
+            zero_diag = None
+            if Kc.nnz > 60 * n:
+                zd = Kc.diagonal() == 0
+                zero_diag = zd if zd.any() else None
+            nd_tree = lsa_hip.nd_order(Kc, 0, constraint=zero_diag)
+            perm = nd_tree["perm"]
+        elif self._ordering == "rcm" and n > 8 and pc_code >= 1 and K is not None:
             perm = pivot_safe_rcm(sp.csr_matrix(K))
         else:
             perm = np.arange(n)
@@ -499,19 +514,19 @@ class iEpsSolver:
             dA = lsa_hip.CsrMatrix.from_scipy(ctx, Ap)
             dM = None if Mp is None else lsa_hip.CsrMatrix.from_scipy(ctx, Mp)
         if pc_code == 2 and K is not None and forest is None:
-            # pattern-only phase of the nested-dissection LU (ordering, elimination forest, index tables, buffers)
-            # the scalar type the library will give C = A - sigma M (lsa_op_create): complex only for a complex shift or
-            # complex operators (K above is complex whenever the target was stored as a Python complex)
+            # pattern-only phase of the nested-dissection LU (elimination forest, index tables, memory plan, buffers) for the
+            # scalar type the library will give C = A - sigma M (lsa_op_create): complex only for a complex shift or complex
+            # operators (K above is complex whenever the target was stored as a Python complex)
             cplx_factors = A.dtype.kind == "c" or (M is not None and M.dtype.kind == "c") or (sinvert and complex(sigma).imag != 0.0)
             fac = dAd if dAd is not None else dA
-            # Zero-diagonal (pressure) unknowns as constraints, eliminated after their neighbours: needed on 3D Taylor-Hood
-            # patterns, where a leaf subdomain can hold more pressure unknowns than its interior supports; costs 20 % more
-            # factor entries in 2D, where it has not been needed (and the library re-analyses by itself if it ever is).
-            zero_diag = None
-            if part is None and fac.nnz > 60 * fac.shape[0]:
-                zd = sp.csr_matrix(K).diagonal()[perm] == 0
-                zero_diag = zd if zd.any() else None
-            fac.prepare_lu(cplx_factors, constraint=zero_diag)
+            if nd_tree is not None and dAd is None:
+                fac.prepare_lu_tree(cplx_factors, nd_tree["first"], nd_tree["size"], nd_tree["parent"])
+            else:  # a rank's diagonal block (block-Jacobi layout), or no ordering asked for: the library dissects by itself
+                zero_diag = None
+                if part is None and fac.nnz > 60 * fac.shape[0]:
+                    zd = sp.csr_matrix(K).diagonal()[perm] == 0
+                    zero_diag = zd if zd.any() else None
+                fac.prepare_lu(cplx_factors, constraint=zero_diag)
         self._prepared = {"sig": self._signature(), "ctx": ctx, "dA": dA, "dM": dM, "dAd": dAd, "dMd": dMd, "part": part, "perm": perm,
                           "forest": forest,
                           "n": n, "sinvert": sinvert, "cayley": self._st_type is iSTType.CAYLEY, "sigma": sigma, "pc_code": pc_code,
@@ -593,7 +608,18 @@ class iEpsSolver:
             else:
                 back = lambda th: th + sigma  # noqa: E731
             theta_key = lambda th: lam_key(back(np.asarray(th, dtype=np.complex128)))  # noqa: E731
-            res = krylov_schur(basis, nev, self._tol, self._max_it, theta_key, rng_seed=self._seed)
+            import os
+
+            if os.environ.get("LSA_KS_DRIVER", "native") == "python":
+                # the same outer iteration in Python over LAPACK (lsa_hip/krylov_schur.py): test double of the library's loop
+                res = krylov_schur(basis, nev, self._tol, self._max_it, theta_key, rng_seed=self._seed)
+            else:
+                # one library call: Krylov-Schur with the library's own dense algebra (lsa_krylov_solve).  The start vector is
+                # drawn here so that both drivers begin from the same one.
+                rng = np.random.default_rng(self._seed)
+                v0 = rng.standard_normal(basis.n) + 1j * rng.standard_normal(basis.n)
+                res = basis.solve(nev, self._tol, self._max_it, which.value, 2 if cayley else 0 if sinvert else 1, sigma, antishift=nu,
+                                  target=self._target, v0=v0, seed=self._seed)
             imag_norms = getattr(basis, "imag_norms", None)  # set when the device already put the vectors into canonical phase
             theta = res.theta
             lam = back(np.asarray(theta, dtype=np.complex128))

@@ -210,6 +210,141 @@ __global__ void hess_column_kernel(int cnt, const T* __restrict__ h1, const T* _
     if (threadIdx.x == 0) s_from(hout[cnt], sqrt(nrm2[0]), 0.0);
 }
 
+// ---- CGS2 of one Arnoldi step in five launches (basis small enough for at most kFuseChunks row chunks) ----------------------
+// The two-stage reductions keep their fixed order, but the small second stages ride in the prologue of the kernel that
+// consumes them instead of being launches of their own (a dependent launch costs 4-6 us on this part, and an Arnoldi step of
+// the 30 k-unknown case is a chain of ~35 of them):
+//   cgs_dot     partial dots of w against V[:, 0:j], chunk-major; the workgroups of the first column tile also sum the
+//               residual check of the inner solve (|b - z|^2, |b|^2 over their rows)
+//   cgs_axpy    every workgroup sums the partials in chunk order (two threads per column), then w -= V h; workgroup 0 leaves h
+//               (and the check's two sums) in global memory; the second pass also leaves per-workgroup sums of |w|^2
+//   cgs_scale   every workgroup sums those, v_next = w / ||w||; workgroup 0 writes the Hessenberg column h1 + h2, ||w||
+constexpr int kFuseChunks = 64;
+constexpr int kFuseCols = 128;  // two threads per column in the prologue of cgs_axpy
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void cgs_dot_kernel(int64_t n, int j, int64_t rows_per_block, const T* __restrict__ V, int64_t ldv,
+                                                           const T* __restrict__ w, T* __restrict__ part, int ldp,
+                                                           const T* __restrict__ chk_b, const T* __restrict__ chk_z, double* __restrict__ chk_part) {
+    __shared__ T smem[4];
+    __shared__ double dsm[4];
+    const int chunk = blockIdx.x;
+    const int c0 = blockIdx.y * kColTile;
+    const int64_t r0 = (int64_t)chunk * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
+    T acc[kColTile];
+#pragma unroll
+    for (int c = 0; c < kColTile; ++c) acc[c] = scalar_traits<T>::zero();
+    const int nc = (j - c0 < kColTile) ? (j - c0) : kColTile;
+    if (nc == kColTile) {
+        for (int64_t i = r0 + threadIdx.x; i < r1; i += kThreads) {
+            const T wv = w[i];
+#pragma unroll
+            for (int c = 0; c < kColTile; ++c) fma_conj_acc(acc[c], V[i + (int64_t)(c0 + c) * ldv], wv);
+        }
+    } else {
+        for (int64_t i = r0 + threadIdx.x; i < r1; i += kThreads) {
+            const T wv = w[i];
+#pragma unroll
+            for (int c = 0; c < kColTile; ++c)
+                if (c < nc) fma_conj_acc(acc[c], V[i + (int64_t)(c0 + c) * ldv], wv);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < kColTile; ++c) {
+        T s = block_sum<T>(acc[c], smem);
+        if (threadIdx.x == 0 && c < nc) part[(int64_t)chunk * ldp + c0 + c] = s;
+    }
+    if (chk_part && blockIdx.y == 0) {
+        double rw = 0.0, rb = 0.0;
+        for (int64_t i = r0 + threadIdx.x; i < r1; i += kThreads) {
+            const T bi = chk_b[i];
+            rw += s_abs2(s_sub(bi, chk_z[i]));
+            rb += s_abs2(bi);
+        }
+        const double sw = block_sum<double>(rw, dsm);
+        __syncthreads();
+        const double sb = block_sum<double>(rb, dsm);
+        if (threadIdx.x == 0) {
+            chk_part[2 * chunk] = sw;
+            chk_part[2 * chunk + 1] = sb;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void cgs_axpy_kernel(int64_t n, int j, const T* __restrict__ V, int64_t ldv, const T* __restrict__ part,
+                                                            int nchunks, int ldp, T* __restrict__ w, T* __restrict__ h_out,
+                                                            double* __restrict__ nrm_part, const double* __restrict__ chk_part,
+                                                            double* __restrict__ chk_out) {
+    __shared__ double smem[4];
+    __shared__ T hs[kFuseCols];
+    {
+        // h[c] = sum over the chunks, in chunk order inside each of two interleaved halves, then half 0 + half 1
+        const int c = threadIdx.x >> 1, half = threadIdx.x & 1;
+        T acc = scalar_traits<T>::zero();
+        if (c < j)
+            for (int k = half; k < nchunks; k += 2) acc = s_add(acc, part[(int64_t)k * ldp + c]);
+        T other;
+        if constexpr (sizeof(T) == 16) other = cplx{__shfl_xor(acc.re, 1), __shfl_xor(acc.im, 1)};
+        else other = __shfl_xor(acc, 1);
+        const T h = half == 0 ? s_add(acc, other) : s_add(other, acc);
+        if (half == 0 && c < j) {
+            hs[c] = h;
+            if (blockIdx.x == 0) h_out[c] = h;
+        }
+        if (chk_out && blockIdx.x == 0 && threadIdx.x < 2) {
+            double a = 0.0;
+            for (int k = 0; k < nchunks; ++k) a += chk_part[2 * k + threadIdx.x];
+            chk_out[threadIdx.x] = a;
+        }
+    }
+    __syncthreads();
+    double nrm = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        T acc = scalar_traits<T>::zero();
+        int c = 0;
+        for (; c + 4 <= j; c += 4) {
+            const T v0 = V[i + (int64_t)c * ldv], v1 = V[i + (int64_t)(c + 1) * ldv];
+            const T v2 = V[i + (int64_t)(c + 2) * ldv], v3 = V[i + (int64_t)(c + 3) * ldv];
+            fma_acc(acc, hs[c], v0);
+            fma_acc(acc, hs[c + 1], v1);
+            fma_acc(acc, hs[c + 2], v2);
+            fma_acc(acc, hs[c + 3], v3);
+        }
+        for (; c < j; ++c) fma_acc(acc, hs[c], V[i + (int64_t)c * ldv]);
+        const T r = s_sub(w[i], acc);
+        w[i] = r;
+        nrm += s_abs2(r);
+    }
+    if (nrm_part) {
+        double s = block_sum<double>(nrm, smem);
+        if (threadIdx.x == 0) nrm_part[blockIdx.x] = s;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void cgs_scale_kernel(int64_t n, const T* __restrict__ x, const double* __restrict__ nrm_part, int nparts,
+                                                             T* __restrict__ y, int j, const T* __restrict__ h1, const T* __restrict__ h2,
+                                                             T* __restrict__ hout) {
+    __shared__ double smem[4];
+    __shared__ double tot_s;
+    double a = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += kThreads) a += nrm_part[k];
+    const double t = block_sum<double>(a, smem);
+    if (threadIdx.x == 0) tot_s = t;
+    __syncthreads();
+    const double tot = tot_s;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < j; c += kThreads) hout[c] = s_add(h1[c], h2[c]);
+        if (threadIdx.x == 0) s_from(hout[j], sqrt(tot), 0.0);
+    }
+    const double s = 1.0 / sqrt(tot);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = s_mul(s, x[i]);
+}
+
 // ---- Ritz vectors: unit norm and a canonical phase for all columns in two launches --------------------------------------------
 // per (block, column): sum |x|^2 over the block's rows and the entry of largest magnitude (lowest row among equals)
 __global__ __launch_bounds__(kThreads) void col_stats_kernel(int64_t n, const cplx* __restrict__ X, int64_t ldx, double* __restrict__ nrm_part,
@@ -545,4 +680,49 @@ int k_basis_gemm(lsa_ctx* ctx, int dtype, int64_t n, int m, int k, const void* V
                            (const T*)V, ldv, (const T*)Q, ldq, (T*)Out, ldo);
     });
     return check_launch(ctx, "basis_gemm");
+}
+
+// CGS2 of w against V[:, 0:j] and v_next = w / ||w|| in five launches (see cgs_dot_kernel), with the inner solve's residual
+// check (chk_b, chk_z -> chk_out[2] = |b - z|^2, |b|^2; all three null: none) folded in.  `work` holds at least
+// k_cgs2_fused_work_bytes(ctx, n, j) bytes.  Returns 1 when the shape is outside what the fused form handles (nothing was
+// launched: the caller takes the kernel-per-stage path), LSA_OK or a negative status otherwise.
+size_t k_cgs2_fused_work_bytes(lsa_ctx* ctx, int64_t n, int jmax) {
+    return (size_t)16 * (size_t)(2 * kFuseChunks * kFuseCols + 2 * kFuseCols) + sizeof(double) * (size_t)(2 * kFuseChunks + stream_blocks(ctx, n) + 8) + (size_t)jmax * 0;
+}
+
+int k_cgs2_fused(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, void* w, void* vnext, void* hcol_dev, void* work,
+                 const void* chk_b, const void* chk_z, double* chk_out) {
+    if (j <= 0 || j > kFuseCols || n <= 0) return 1;
+    int64_t rpb = (n + kFuseChunks - 1) / kFuseChunks;
+    rpb = ((rpb + kThreads - 1) / kThreads) * kThreads;
+    if (rpb < 512) rpb = 512;
+    if (rpb > 2048) return 1;  // long vectors: the second stages are noise there, and wider grids stream better
+    const int nchunks = (int)((n + rpb - 1) / rpb);
+    const int blocks = stream_blocks(ctx, n);
+    const size_t esz = dtype == LSA_C128 ? 16 : 8;
+    char* p = (char*)work;
+    void* part1 = p;
+    p += esz * (size_t)kFuseChunks * kFuseCols;
+    void* part2 = p;
+    p += esz * (size_t)kFuseChunks * kFuseCols;
+    void* h1 = p;
+    p += esz * kFuseCols;
+    void* h2 = p;
+    p += esz * kFuseCols;
+    double* chk_part = (double*)p;
+    double* nrm_part = chk_part + 2 * kFuseChunks;
+    const dim3 dgrid(nchunks, (j + kColTile - 1) / kColTile);
+    DISPATCH_T(dtype, {
+        hipLaunchKernelGGL((cgs_dot_kernel<T>), dgrid, dim3(kThreads), 0, ctx->stream, n, j, rpb, (const T*)V, ldv, (const T*)w, (T*)part1, kFuseCols,
+                           (const T*)chk_b, (const T*)chk_z, chk_out ? chk_part : (double*)nullptr);
+        hipLaunchKernelGGL((cgs_axpy_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, j, (const T*)V, ldv, (const T*)part1, nchunks, kFuseCols,
+                           (T*)w, (T*)h1, (double*)nullptr, (const double*)chk_part, chk_out);
+        hipLaunchKernelGGL((cgs_dot_kernel<T>), dgrid, dim3(kThreads), 0, ctx->stream, n, j, rpb, (const T*)V, ldv, (const T*)w, (T*)part2, kFuseCols,
+                           (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+        hipLaunchKernelGGL((cgs_axpy_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, j, (const T*)V, ldv, (const T*)part2, nchunks, kFuseCols,
+                           (T*)w, (T*)h2, nrm_part, (const double*)nullptr, (double*)nullptr);
+        hipLaunchKernelGGL((cgs_scale_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, (const T*)w, (const double*)nrm_part, blocks, (T*)vnext,
+                           j, (const T*)h1, (const T*)h2, (T*)hcol_dev);
+    });
+    return check_launch(ctx, "cgs2_fused");
 }

@@ -116,6 +116,36 @@ int k_allgather_inplace(lsa_ctx* ctx, void* vec, size_t bytes_per_rank) {
     return LSA_OK;
 }
 
+// The ranks of a sharded layout agree on a status before any of them enters a data collective or returns from a collective
+// set-up: every rank passes what it has (LSA_OK or its own failure) and gets back its own failure, or else the status of the
+// first rank that failed.  A rank that failed locally -- out of device memory for buffers whose size differs from rank to
+// rank, a limit of the kernels, non-finite input -- thus never leaves the others waiting in an exchange that has no time-out.
+// One 16-byte all-gather through the context's scratch (allocated with the context: nothing can fail before the exchange).
+int k_agree_status(lsa_ctx* ctx, int rc) {
+    if (ctx->nranks <= 1) return rc;
+    const size_t slot = 4 * sizeof(int32_t);
+    if (ctx->dscratch_bytes < slot * (size_t)ctx->nranks || ctx->pinned_bytes < slot * (size_t)ctx->nranks)
+        return rc != LSA_OK ? rc : lsa_set_error(ctx, LSA_ERR_ARG, "k_agree_status: context scratch too small for %d ranks", ctx->nranks);
+    int32_t* h = (int32_t*)ctx->pinned;
+    char* d = (char*)ctx->dscratch;
+    h[0] = rc;
+    h[1] = h[2] = h[3] = 0;
+    bool ok = hipMemcpyAsync(d + slot * (size_t)ctx->rank, h, slot, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+              hipStreamSynchronize(ctx->stream) == hipSuccess;
+    const std::string mine = ctx->err;
+    const int xrc = k_allgather_inplace(ctx, d, slot);  // (entered even after a local copy failure: the others are in it)
+    ok = ok && xrc == LSA_OK && hipMemcpyAsync(h, d, slot * (size_t)ctx->nranks, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+         hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (rc != LSA_OK) {
+        ctx->err = mine;
+        return rc;
+    }
+    if (!ok) return lsa_set_error(ctx, xrc != LSA_OK ? xrc : LSA_ERR_HIP, "k_agree_status: the status exchange failed");
+    for (int r = 0; r < ctx->nranks; ++r)
+        if (h[4 * r] != LSA_OK) return lsa_set_error(ctx, h[4 * r], "rank %d failed with status %d before a collective step; every rank gives up with it", r, h[4 * r]);
+    return LSA_OK;
+}
+
 void comm_release(lsa_ctx* ctx) {
     if (ctx->comm) {
         Rccl& r = rccl();

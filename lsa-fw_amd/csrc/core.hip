@@ -213,6 +213,8 @@ int lsa_csr_upload_shard(lsa_ctx* ctx, int32_t n_global, int32_t row0, int32_t r
     return csr_upload_impl(ctx, row1 - row0, n_global, row0, nnz_local, rowptr_local, col, val, dtype, out);
 }
 
+int64_t lsa_mat_rows(const lsa_mat* m) { return m ? (int64_t)m->n : 0; }
+
 void lsa_mat_destroy(lsa_mat* m) {
     if (!m) return;
     if (m->ctx && m->ctx->stream) (void)hipStreamSynchronize(m->ctx->stream);

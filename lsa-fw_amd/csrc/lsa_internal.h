@@ -150,6 +150,7 @@ int lsa_set_error(lsa_ctx* ctx, int code, const char* fmt, ...);
 // rows [r0, r1) of a square matrix as a shard (n = r1 - r0, row0 = r0): borrows every array, must not outlive `full`
 lsa_mat* mat_row_view(const lsa_mat* full, int32_t r0, int32_t r1);
 void comm_release(lsa_ctx* ctx);  // comm.hip
+int k_agree_status(lsa_ctx* ctx, int rc);  // comm.hip: collective agreement on a status (returns rc on one rank)
 int lsa_ensure_scratch(lsa_ctx* ctx, size_t dbytes, size_t hbytes);
 
 #define LSA_HIP_CHECK(ctx, expr)                                                                         \
@@ -204,6 +205,11 @@ int k_residual_norms(lsa_ctx* ctx, int dtype, int64_t n, const void* b, const vo
 int k_scale_by_inv_norm(lsa_ctx* ctx, int dtype, int64_t n, const void* x, const double* nrm2_dev, void* y);
 // hsum[c] += hadd[c] (c < j) and hsum[j] = sqrt(nrm2[0])  -- assembles one Hessenberg column on the device
 int k_hess_column(lsa_ctx* ctx, int dtype, int j, const void* h1, const void* h2, const double* nrm2_dev, void* hout);
+// CGS2 + normalisation of one Arnoldi step in five launches, the inner solve's residual check folded in (blas.hip); returns 1
+// (nothing launched) for shapes it does not handle
+size_t k_cgs2_fused_work_bytes(lsa_ctx* ctx, int64_t n, int jmax);
+int k_cgs2_fused(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, void* w, void* vnext, void* hcol_dev, void* work,
+                 const void* chk_b, const void* chk_z, double* chk_out);
 // Out[:, 0:k] = V[:, 0:m] Q   (Q m x k column-major on the device, ldq)
 int k_basis_gemm(lsa_ctx* ctx, int dtype, int64_t n, int m, int k, const void* V, int64_t ldv, const void* Q, int ldq,
                  void* Out, int64_t ldo);

@@ -14,6 +14,7 @@ struct NdSymbolic {
     uint64_t pattern_hash = 0;
     uint64_t constraint_hash = 0;  // 0: no constraint unknowns were given; else a hash of the flagged set
     int32_t leaf_size = 0;
+    bool order_only = false;       // lsa_nd_order: only perm, node_start, parent, level are filled
     uint64_t tree_hash = 0;        // 0: the tree came from the library's own dissection; else a hash of the caller's tree
     int32_t nt = 0;       // tree nodes this rank keeps (all of them on one rank)
     int32_t nlevels = 0;  // work levels (entries of lvl_ptr - 1)
@@ -59,5 +60,5 @@ int nd_analyse_tree(int32_t n, const int32_t* rp, const int32_t* ci, int32_t nt,
                     const int32_t* owner, int rank, int nranks, NdSymbolic* out, char* err, int errlen);
 // constraint: null, or n flags marking the unknowns with a numerically zero diagonal (eliminated after their neighbours)
 int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, const int8_t* constraint, NdSymbolic* out, char* err,
-               int errlen);
+               int errlen, bool order_only = false);
 uint64_t nd_pattern_hash(int32_t n, const int32_t* rp, const int32_t* ci);

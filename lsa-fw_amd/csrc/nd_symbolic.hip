@@ -97,6 +97,11 @@ void dissect(const Graph& g, int32_t leaf, std::vector<std::vector<int32_t>>& ow
         stack.push_back(std::move(all));
     }
     std::vector<int32_t> order, order2, cnt;
+    // The smaller part must hold at least `balance` percent of the region.  Among the candidates the smallest separator wins,
+    // so a loose bound buys small separators with a lopsided, deeper forest -- and every level of the forest is one dependent
+    // launch per sweep of every solve.  Planar meshes: 40 (30 k unknowns: 10 levels instead of 12 for 4 % more factor
+    // entries; 120 k: 13 instead of 16); 3D meshes, whose solves stream gigabytes per level: 30.  LSA_ND_BALANCE overrides.
+    const int64_t balance = getenv("LSA_ND_BALANCE") ? std::max(1, std::min(49, atoi(getenv("LSA_ND_BALANCE")))) : (g.ptr[(size_t)n] > 60 * (int64_t)n ? 30 : 40);
     auto emit = [&](std::vector<int32_t>&& verts, int32_t par) {
         own.push_back(std::move(verts));
         parent.push_back(par);
@@ -182,7 +187,7 @@ void dissect(const Graph& g, int32_t leaf, std::vector<std::vector<int32_t>>& ow
                 fb_gap = gap;
                 fallback = k;
             }
-            if (std::min(below, above) * 10 >= total * 3 && (best < 0 || cnt[(size_t)k] < best_cnt)) {
+            if (std::min(below, above) * 100 >= total * balance && (best < 0 || cnt[(size_t)k] < best_cnt)) {
                 best = k;
                 best_cnt = cnt[(size_t)k];
             }
@@ -305,6 +310,17 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
     }
     for (int32_t t = 0; t < nt; ++t)
         if (gparent[(size_t)t] >= 0) glevel[(size_t)gparent[(size_t)t]] = std::max(glevel[(size_t)gparent[(size_t)t]], glevel[(size_t)t] + 1);
+    if (S.order_only) {  // lsa_nd_order: the elimination order and the forest are all the caller wants
+        S.nt = nt;
+        S.nlevels = 0;
+        for (int32_t t = 0; t < nt; ++t) S.nlevels = std::max(S.nlevels, glevel[(size_t)t] + 1);
+        S.node_start = gstart;
+        S.parent = gparent;
+        S.level = glevel;
+        S.m = gm;
+        S.f = gm;
+        return LSA_OK;
+    }
     // boundary (struct) of every node in elimination positions
     std::vector<std::vector<int32_t>> bnd((size_t)nt);
     {
@@ -566,13 +582,14 @@ int check_pattern(int32_t n, const int32_t* rp, const int32_t* ci, const Fail& f
 }  // namespace
 
 int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, const int8_t* constraint, NdSymbolic* out, char* err,
-               int errlen) {
+               int errlen, bool order_only) {
     const Fail fail{err, errlen};
     if (!out) return fail(LSA_ERR_ARG, "nd_analyse: bad argument");
     if (int rc = check_pattern(n, rp, ci, fail)) return rc;
     if (leaf_size <= 0) leaf_size = 128;
     NdSymbolic& S = *out;
     S = NdSymbolic();
+    S.order_only = order_only;
     S.n = n;
     S.nnz = n > 0 ? rp[n] : 0;
     S.leaf_size = leaf_size;
@@ -756,6 +773,22 @@ int lsa_nd_analyse(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t
     }
     h->err = buf;
     *out = h;  // returned on failure too, so that the message can be read; release with lsa_nd_sym_destroy
+    return rc;
+}
+
+int lsa_nd_order(int32_t n, const int32_t* rowptr, const int32_t* col, int32_t leaf_size, const int8_t* constraint, lsa_nd_sym** out) {
+    if (!out) return LSA_ERR_ARG;
+    lsa_nd_sym* h = new lsa_nd_sym();
+    char buf[256] = {0};
+    int rc;
+    try {
+        rc = nd_analyse(n, rowptr, col, leaf_size, constraint, &h->S, buf, (int)sizeof buf, true);
+    } catch (const std::bad_alloc&) {
+        rc = LSA_ERR_ARG;
+        snprintf(buf, sizeof buf, "nd_order: out of host memory");
+    }
+    h->err = buf;
+    *out = h;
     return rc;
 }
 

@@ -1,17 +1,24 @@
 // Nested-dissection multifrontal LU on the device: the exact factorisation behind PreconditionerType.LU, the setting of
 // the reference's cylinder runs for the ST's KSP (.examples/eigenvalues.py:100; Sensitivity/__init__.py:182,260).
 //
-// Layout (analysis: nd_symbolic.hip).  Every tree node t keeps its dense front F_t (f x f, row-major, f = m + b) resident
-// in HBM; after the factorisation it holds
-//     F11 <- F11^-1           (m x m, explicit inverse: Gauss-Jordan, pivot search over the whole column of the block)
-//     F21 <- -F21 F11^-1      (b x m)
-//     F12 <-  F11^-1 F12      (m x b)
-//     F22 <-  F22 - F21 F11^-1 F12   (the update matrix the parent added to its own front)
+// Layout (analysis: nd_symbolic.hip).  Tree node t owns m unknowns and has a boundary of b unknowns of its ancestors; its
+// front F_t is (m + b)^2.  What stays resident in HBM after the factorisation is PACKED, m^2 + 2 m b scalars per node:
+//     L_t = [ F11^-1 ; -F21 F11^-1 ]   (f x m, row-major)        U_t = F11^-1 F12   (m x b, row-major)
 // so that a solve is two sweeps over the tree in which every node is ONE dense mat-vec per sweep:
-//     up   (leaves -> roots):  v = b[own] + children's updates;  y[own] = F11 v;  update_t = v[boundary-part] + F21 v
-//     down (roots -> leaves):  x[own] = y[own] - F12 x[boundary]
-// All nodes of a tree level run in one launch: 2 * (levels) dependent launches per solve (20 at 30 k unknowns) instead of
-// the O(n / B) block steps of a banded elimination, and sum(m^2 + 2 m b) scalars instead of n * bandwidth.
+//     up   (leaves -> roots):  v = b[own] + children's updates;  [y[own]; update_t - carried] = L_t v
+//     down (roots -> leaves):  x[own] = y[own] - U_t x[boundary]
+// The full front exists only while its node is being factored: the nodes of a tree level are factored in CHUNKS whose
+// working fronts (f^2 each) share one arena; the update matrix F22 - F21 F11^-1 F12 (b^2) a node hands to its parent lives
+// in a second arena from the node's chunk to its parent's (offsets from a first-fit allocator run over the chunk order at
+// analysis time).  Device memory is therefore sum(m^2 + 2 m b) + one chunk's fronts + the live update matrices, not
+// sum(f^2): what lets the 3D cases beyond a million unknowns fit (round 2 kept every front whole: 40-60 % dead storage).
+// All nodes of a tree level run in one launch per sweep: 2 * (levels) - 1 dependent launches per solve.
+//
+// Sweeps without index chasing: the iteration's vectors are kept in the elimination order (a node's own unknowns are
+// contiguous: the caller orders the matrix by lsa_nd_order and hands the tree back), children PUSH their update entries
+// into per-child slot rows of the parent (fixed slots: bitwise repeatable, no atomics) and parents push the solution
+// entries a child's boundary needs into the child's boundary vector, so every gather on a kernel's critical path is a
+// contiguous load whose address depends on the node record only; index tables (cmap, gell) feed stores.
 //
 // Pivoting: rows are chosen by magnitude inside the pivot block of each front and never physically interchanged (the
 // permutation is undone once, when the inverse is gathered).  A pivot below 1e-15 * max|C| is reported as
@@ -39,32 +46,44 @@ inline double now_s() { return std::chrono::duration<double>(std::chrono::steady
 inline size_t esize(int dtype) { return dtype == LSA_C128 ? 16 : 8; }
 
 struct NdNodeDev {
-    int64_t front_off;  // scalars into the front buffer
-    int64_t scr_off;    // scalars into the level scratch: [m*m | b*m | m*b]
-    int64_t u_off;      // into the update-vector buffer (b entries)
-    int64_t g_off;      // into gptr (f + 1 entries)
+    int64_t front_off;  // scalars into the working arena (f x f, row-major) while the node's chunk is being factored
+    int64_t lfac_off;   // packed factors: [F11^-1; -F21 F11^-1], f x m row-major
+    int64_t ufac_off;   // packed factors: F11^-1 F12, m x b row-major
+    int64_t upd_off;    // the node's update matrix (b x b, row-major) in the update arena
+    int64_t u_off;      // into the update-vector / boundary-vector buffers (b entries)
+    int64_t ge_off;     // into gell (nchild * f entries)
+    int64_t acc_off;    // upward sweep: this node's slot rows (nchild x f entries, row c written by child c), or -1: pull through gell
+    int64_t pacc_off;   // upward sweep: this node's slot row in its parent's accumulation buffer, or -1: writes its update vector
     int32_t idx_off;    // into idx (f entries)
     int32_t cmap_off;   // into cmap (b entries)
     int32_t piv_off;    // into ipiv / rowq (m entries)
+    int32_t own0;       // first own unknown when the vectors are in elimination order
     int32_t m, f, parent;
     int32_t nchild;     // rows of the node's gather table
-    int32_t pad1;
-    int64_t ge_off;     // into gell (nchild * f entries)
 };
+static_assert(sizeof(NdNodeDev) == 96, "node record layout");
 
 struct TileList {
     int64_t off = 0;  // pairs of int32 into the tile buffer
     int32_t count = 0;
 };
 
+// factorisation work unit: nodes of ONE tree level whose working fronts share the arena
+struct NdChunk {
+    int32_t node_begin = 0, node_count = 0, max_m = 0, max_f = 0;  // range of the chunk-ordered node list (own size descending)
+    std::vector<int32_t> sorted_m;
+    int64_t work_entries = 0;             // sum of f^2: scalars of the arena this chunk uses
+    int64_t asm_begin = 0, asm_count = 0;  // its range of the assembly lists
+    TileList unperm, gemm[3], save;
+    std::vector<TileList> ext;  // one per child rank
+    bool exchange_before = false;  // subtree-parallel: the ranks' subtree-root update matrices are all-gathered before this chunk
+};
+
+// one launch of each sweep: the nodes of a tree level
 struct NdLevel {
     int32_t node_begin = 0, node_count = 0, max_m = 0, max_f = 0;
-    std::vector<int32_t> sorted_m;          // own sizes of the level's nodes (descending)
-    TileList unperm, gemm[3], copyback;
     int32_t fwd_tiles = 0, bwd_tiles = 0;  // grid.y of the sweep kernels: tiles of the tallest node (0 = nothing to do)
     int32_t sweep_rows = 32;               // rows per upward-sweep tile: 32; 8 on levels with few tiles (both sweeps); 128 on thin levels
-    std::vector<TileList> ext;  // one per child rank
-    int64_t scratch = 0;
 };
 
 template <typename T>
@@ -86,10 +105,10 @@ __global__ void nd_assemble_kernel(int64_t count, const T* __restrict__ val, con
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) front[dst[e]] = val[src[e]];
 }
 
-// parent front += child's update matrix (tile = 16 rows of the child's boundary block)
+// parent front += child's update matrix (tile = 16 rows of the child's b x b update matrix in the update arena)
 template <typename T>
 __global__ __launch_bounds__(256) void nd_extend_add_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
-                                                            const int32_t* __restrict__ cmap, T* __restrict__ front) {
+                                                            const int32_t* __restrict__ cmap, T* __restrict__ front, const T* __restrict__ upd) {
     const int32_t c = tiles[2 * blockIdx.x], i0 = tiles[2 * blockIdx.x + 1];
     const NdNodeDev nc = nodes[c];
     const NdNodeDev np = nodes[nc.parent];
@@ -97,7 +116,7 @@ __global__ __launch_bounds__(256) void nd_extend_add_kernel(const int32_t* __res
     const int32_t* map = cmap + nc.cmap_off;
     const int32_t i = i0 + (threadIdx.x >> 4);
     if (i >= b) return;
-    const T* src = front + nc.front_off + (int64_t)(nc.m + i) * nc.f + nc.m;
+    const T* src = upd + nc.upd_off + (int64_t)i * b;
     T* dst = front + np.front_off + (int64_t)map[i] * np.f;
     for (int32_t j = threadIdx.x & 15; j < b; j += 16) {
         T* d = dst + map[j];
@@ -591,27 +610,28 @@ __global__ __launch_bounds__(256) void nd_tp_colblock_kernel(const int32_t* __re
     }
 }
 
-// inverse gathered out of the eliminated block: inv[a][b] = S[p_a][q_b]  (p = pivot row of column a, q = its inverse)
+// inverse gathered out of the eliminated block, straight into the packed factors: L[a][b] = S[p_a][q_b]  (p = pivot row of
+// column a, q = its inverse)
 template <typename T>
 __global__ __launch_bounds__(256) void nd_unperm_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
                                                         const T* __restrict__ front, const int32_t* __restrict__ ipiv,
-                                                        const int32_t* __restrict__ rowq, T* __restrict__ scratch) {
+                                                        const int32_t* __restrict__ rowq, T* __restrict__ lfac) {
     const int32_t t = tiles[2 * blockIdx.x], r0 = tiles[2 * blockIdx.x + 1];
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, ld = nd.f;
     const int32_t ra = r0 + (threadIdx.x >> 4);
     if (ra >= m) return;
     const T* src = front + nd.front_off + (size_t)ipiv[nd.piv_off + ra] * ld;
-    T* dst = scratch + nd.scr_off + (size_t)ra * m;
+    T* dst = lfac + nd.lfac_off + (size_t)ra * m;
     const int32_t* q = rowq + nd.piv_off;
     for (int32_t cb = threadIdx.x & 15; cb < m; cb += 16) dst[cb] = src[q[cb]];
 }
 
-// batched dense products of a level (row-major, 64 x 64 tiles, 4 x 4 per thread):
-//   KIND 0:  S1 = -F21 inv        (b x m)      KIND 1:  F22 += S1 F12   (b x b)      KIND 2:  S2 = inv F12   (m x b)
+// batched dense products of a chunk (row-major, 64 x 64 tiles, 4 x 4 per thread); inv = the first m rows of the packed L:
+//   KIND 0:  L[m:] = -F21 inv     (b x m)      KIND 1:  F22 += L[m:] F12   (b x b, in the working front)      KIND 2:  U = inv F12   (m x b)
 template <typename T, int KIND>
 __global__ __launch_bounds__(256) void nd_gemm_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
-                                                      T* __restrict__ front, T* __restrict__ scratch) {
+                                                      T* __restrict__ front, T* __restrict__ lfac, T* __restrict__ ufac) {
     constexpr int BK = 8;
     __shared__ T As[BK][kGT + 1];
     __shared__ T Bs[BK][kGT + 1];
@@ -620,9 +640,9 @@ __global__ __launch_bounds__(256) void nd_gemm_kernel(const int32_t* __restrict_
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, f = nd.f, b = f - m;
     T* F = front + nd.front_off;
-    T* inv = scratch + nd.scr_off;
+    T* inv = lfac + nd.lfac_off;
     T* S1 = inv + (size_t)m * m;
-    T* S2 = S1 + (size_t)b * m;
+    T* S2 = ufac + nd.ufac_off;
     const T *A, *B;
     T* C;
     int32_t M, N, K, lda, ldb, ldc;
@@ -683,41 +703,58 @@ __global__ __launch_bounds__(256) void nd_gemm_kernel(const int32_t* __restrict_
     }
 }
 
-// F11 <- inv, F21 <- S1, F12 <- S2  (tile = 16 front rows)
+// the update matrix leaves the working front for the update arena (tile = 16 rows of the b x b block)
 template <typename T>
-__global__ __launch_bounds__(256) void nd_copyback_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
-                                                          T* __restrict__ front, const T* __restrict__ scratch) {
+__global__ __launch_bounds__(256) void nd_save_update_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
+                                                             const T* __restrict__ front, T* __restrict__ upd) {
     const int32_t t = tiles[2 * blockIdx.x], r0 = tiles[2 * blockIdx.x + 1];
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, f = nd.f, b = f - m;
     const int32_t r = r0 + (threadIdx.x >> 4);
-    if (r >= f) return;
-    const T* inv = scratch + nd.scr_off;
-    const T* S1 = inv + (size_t)m * m;
-    const T* S2 = S1 + (size_t)b * m;
-    T* dst = front + nd.front_off + (size_t)r * f;
-    if (r < m) {
-        for (int32_t c = threadIdx.x & 15; c < m; c += 16) dst[c] = inv[(size_t)r * m + c];
-        for (int32_t c = threadIdx.x & 15; c < b; c += 16) dst[m + c] = S2[(size_t)r * b + c];
-    } else {
-        for (int32_t c = threadIdx.x & 15; c < m; c += 16) dst[c] = S1[(size_t)(r - m) * m + c];
-    }
+    if (r >= b) return;
+    const T* src = front + nd.front_off + (size_t)(m + r) * f + m;
+    T* dst = upd + nd.upd_off + (size_t)r * b;
+    for (int32_t c = threadIdx.x & 15; c < b; c += 16) dst[c] = src[c];
 }
 
-template <int LANES = 16, typename VT>
-__device__ __forceinline__ VT sub16_sum(VT v) {  // sum over the LANES lanes of a sub-wave
-    for (int o = LANES / 2; o > 0; o >>= 1) {
-        if constexpr (sizeof(VT) == 16) {
-            v.re += __shfl_xor(v.re, o);
-            v.im += __shfl_xor(v.im, o);
-        } else {
-            v += __shfl_xor(v, o);
+// sum over LPR consecutive lanes (4, 16 or 64), returned to every one of them.  DPP moves inside a row of 16 lanes (two 32-bit
+// halves per double), the four row sums of a wavefront through SGPRs: a ds_bpermute butterfly is a chain of ~100-cycle steps,
+// and the sweeps are chains of short kernels that end in exactly this reduction.  Fixed order: bitwise repeatable.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)bits & 0xFFFFFFFFull), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)bits >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+template <int LPR>
+__device__ __forceinline__ double lanes_sum(double v) {
+    static_assert(LPR == 4 || LPR == 16 || LPR == 64, "sub-wave width");
+    v += dpp_mov_f64<0xB1>(v);  // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);  // quad_perm [2,3,0,1]: every lane of a quad holds the quad's sum
+    if constexpr (LPR >= 16) {
+        v += dpp_mov_f64<0x141>(v);  // row_half_mirror
+        v += dpp_mov_f64<0x140>(v);  // row_mirror: every lane of a row of 16 holds the row's sum
+    }
+    if constexpr (LPR == 64) {
+        const long long bits = __double_as_longlong(v);
+        const int lo = (int)(unsigned)((unsigned long long)bits & 0xFFFFFFFFull), hi = (int)(unsigned)((unsigned long long)bits >> 32);
+        double tot = 0.0;
+#pragma unroll
+        for (int row = 0; row < 4; ++row) {
+            const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, 16 * row), h = (unsigned)__builtin_amdgcn_readlane(hi, 16 * row);
+            tot += __longlong_as_double((long long)(((unsigned long long)h << 32) | l));
         }
+        v = tot;
     }
     return v;
 }
+template <int LPR>
+__device__ __forceinline__ cplx lanes_sum(cplx v) {
+    return cplx{lanes_sum<LPR>(v.re), lanes_sum<LPR>(v.im)};
+}
 
-// acc0 += Fa[0:cn] . vs, acc1 += Fb[0:cn] . vs over the 16 lanes of a sub-wave; eight row loads in flight per lane (the
+// acc0 += Fa[0:cn] . vs, acc1 += Fb[0:cn] . vs over the LPR lanes of a sub-wave; eight row loads in flight per lane (the
 // sweeps are chains of short kernels: what they wait for is memory latency, not bandwidth)
 template <int LPR = 16, typename MT, typename VT>
 __device__ __forceinline__ void two_row_dot(const MT* __restrict__ Fa, const MT* __restrict__ Fb, const VT* vs, int32_t cn, int sl, VT& acc0,
@@ -742,8 +779,7 @@ __device__ __forceinline__ void two_row_dot(const MT* __restrict__ Fa, const MT*
     }
 }
 
-// the first 4 * LPR columns of a row pair, loaded before the vector they multiply is ready (the sweeps are chains of
-// dependent loads: node record -> gather table -> update vectors -> front rows; the rows depend only on the first)
+// the first 4 * LPR columns of a row pair, loaded before the vector they multiply is ready (they depend on the node record only)
 template <int LPR, typename MT>
 __device__ __forceinline__ void row_pair_prefetch(const MT* __restrict__ Fa, const MT* __restrict__ Fb, int32_t cn, int sl, MT (&pa)[4], MT (&pb)[4]) {
 #pragma unroll
@@ -768,7 +804,9 @@ __device__ __forceinline__ void two_row_dot_prefetched(const MT* __restrict__ Fa
     if (cn > 4 * LPR) two_row_dot<LPR>(Fa + 4 * LPR, Fb + 4 * LPR, vs + 4 * LPR, cn - 4 * LPR, sl, acc0, acc1);
 }
 
-// sum of the children's update-vector entries that land on front position j (fixed order: child rank)
+// PULL form: sum of the children's update-vector entries that land on front position j, through the per-child gather rows
+// (fixed order: child rank).  Used where a child's vector arrives by all-gather (the replicated top of a forest cut over ranks)
+// and by the transposed sweeps.
 template <typename VT>
 __device__ __forceinline__ VT gather_updates(const int32_t* __restrict__ ge, int32_t nchild, int32_t f, int32_t j, const VT* __restrict__ ubuf,
                                              VT v) {
@@ -789,13 +827,41 @@ __device__ __forceinline__ VT gather_updates(const int32_t* __restrict__ ge, int
     return v;
 }
 
-// upward sweep, one tree level: workgroup (x = node of the level, y = tile of 512 / LPR rows of its [F11; F21] block column);
+// PUSH form: the same sum from the node's slot rows (row c = what child c added to every front position; slots no child maps
+// to were zeroed once and are never written): contiguous loads, no index in between.  Same order of additions as the pull form.
+template <typename VT>
+__device__ __forceinline__ VT slot_sum(const VT* __restrict__ slots, int32_t nchild, int32_t f, int32_t j, VT v) {
+    int32_t c = 0;
+    for (; c + 3 < nchild; c += 4) {
+        const VT u0 = slots[(size_t)c * f + j], u1 = slots[(size_t)(c + 1) * f + j], u2 = slots[(size_t)(c + 2) * f + j], u3 = slots[(size_t)(c + 3) * f + j];
+        v = s_add(s_add(s_add(s_add(v, u0), u1), u2), u3);
+    }
+    VT u[3];
+    for (int q = 0; q < 3; ++q) u[q] = c + q < nchild ? slots[(size_t)(c + q) * f + j] : scalar_traits<VT>::zero();
+    for (int q = 0; q < 3; ++q)
+        if (c + q < nchild) v = s_add(v, u[q]);
+    return v;
+}
+
+// downward sweep: the value of front position j goes into the boundary vector of every child that has j in its boundary
+template <typename VT>
+__device__ __forceinline__ void push_down(const int32_t* __restrict__ ge, int32_t nchild, int32_t f, int32_t j, VT* __restrict__ xb, VT val) {
+    for (int32_t c = 0; c < nchild; ++c) {
+        const int32_t g = ge[(size_t)c * f + j];
+        if (g >= 0) xb[g] = val;
+    }
+}
+
+// upward sweep, one tree level: workgroup (x = node of the level, y = tile of 512 / LPR rows of its packed L block);
 // LPR lanes run along a pair of rows: 16 (32 rows per workgroup) where the level has many tiles, 64 (8 rows) near the top
-// of the tree, where a few tall fronts must still be spread over the whole chip
-template <typename MT, typename VT, int LPR>
-__global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ front,
+// of the tree, where a few tall fronts must still be spread over the whole chip, 4 (128 rows) on levels of thin separators.
+// ORDERED: the vectors are in elimination order (own unknown r of the node = own0 + r), else through idx.
+// A root (no boundary) also starts the downward sweep: its rows are final, they go to its children's boundary vectors.
+template <typename MT, typename VT, int LPR, bool ORDERED>
+__global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ lfac,
                                                      const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
-                                                     const VT* __restrict__ rhs, VT* __restrict__ x, VT* __restrict__ ubuf) {
+                                                     const int32_t* __restrict__ cmap, const VT* __restrict__ rhs, VT* __restrict__ x,
+                                                     VT* __restrict__ ubuf, VT* __restrict__ acc, VT* __restrict__ xb) {
     __shared__ VT vs[kCH];
     const NdNodeDev nd = lnodes[blockIdx.x];
     const int32_t r0 = (int32_t)blockIdx.y * (512 / LPR);
@@ -803,85 +869,129 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict
     if (r0 >= f) return;
     const int32_t* ix = idx + nd.idx_off;
     const int32_t* ge = gell + nd.ge_off;
-    const MT* F = front + nd.front_off;
+    const MT* L = lfac + nd.lfac_off;
     const int tid = threadIdx.x, sw = tid / LPR, sl = tid % LPR;
     const int32_t ra = r0 + sw, rb = r0 + sw + 256 / LPR;
-    const MT* Fa = F + (size_t)min(ra, f - 1) * f;
-    const MT* Fb = F + (size_t)min(rb, f - 1) * f;
+    const MT* La = L + (size_t)min(ra, f - 1) * m;
+    const MT* Lb = L + (size_t)min(rb, f - 1) * m;
     VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
-    // everything that depends only on the node record is requested first: the head of the two rows, and what the children
-    // add to the update entries these rows produce
+    // everything that depends only on the node record is requested first: the head of the two rows, what the children
+    // added to the update entries these rows produce, where those entries go
     MT pa[4], pb[4];
-    row_pair_prefetch<LPR>(Fa, Fb, min(kCH, m), sl, pa, pb);
+    row_pair_prefetch<LPR>(La, Lb, min(kCH, m), sl, pa, pb);
+    const bool push = nd.acc_off >= 0;
+    const VT* slots = acc + (push ? nd.acc_off : 0);
     VT ua = scalar_traits<VT>::zero(), ub = scalar_traits<VT>::zero();
-    int32_t oa = -1, ob = -1;
+    int32_t ca = 0, cb = 0;
     if (sl == 0) {
-        if (ra < m) oa = ix[ra];
-        else if (ra < f) ua = gather_updates(ge, nd.nchild, f, ra, ubuf, ua);
-        if (rb < m) ob = ix[rb];
-        else if (rb < f) ub = gather_updates(ge, nd.nchild, f, rb, ubuf, ub);
+        if (ra >= m && ra < f) {
+            ua = push ? slot_sum(slots, nd.nchild, f, ra, ua) : gather_updates(ge, nd.nchild, f, ra, ubuf, ua);
+            if (nd.pacc_off >= 0) ca = cmap[nd.cmap_off + ra - m];
+        }
+        if (rb >= m && rb < f) {
+            ub = push ? slot_sum(slots, nd.nchild, f, rb, ub) : gather_updates(ge, nd.nchild, f, rb, ubuf, ub);
+            if (nd.pacc_off >= 0) cb = cmap[nd.cmap_off + rb - m];
+        }
     }
     for (int32_t c0 = 0; c0 < m; c0 += kCH) {
         const int32_t cn = min(kCH, m - c0);
-        for (int32_t j = tid; j < cn; j += 256) vs[j] = gather_updates(ge, nd.nchild, f, c0 + j, ubuf, rhs[ix[c0 + j]]);
+        for (int32_t j = tid; j < cn; j += 256) {
+            const VT v = rhs[ORDERED ? nd.own0 + c0 + j : ix[c0 + j]];
+            vs[j] = push ? slot_sum(slots, nd.nchild, f, c0 + j, v) : gather_updates(ge, nd.nchild, f, c0 + j, ubuf, v);
+        }
         __syncthreads();
-        if (c0 == 0) two_row_dot_prefetched<LPR>(Fa, Fb, vs, cn, sl, acc0, acc1, pa, pb);
-        else two_row_dot<LPR>(Fa + c0, Fb + c0, vs, cn, sl, acc0, acc1);
+        if (c0 == 0) two_row_dot_prefetched<LPR>(La, Lb, vs, cn, sl, acc0, acc1, pa, pb);
+        else two_row_dot<LPR>(La + c0, Lb + c0, vs, cn, sl, acc0, acc1);
         __syncthreads();
     }
-    acc0 = sub16_sum<LPR>(acc0);
-    acc1 = sub16_sum<LPR>(acc1);
+    acc0 = lanes_sum<LPR>(acc0);
+    acc1 = lanes_sum<LPR>(acc1);
     if (sl == 0) {
-        if (ra < m) x[oa] = acc0;
-        else if (ra < f) ubuf[nd.u_off + (ra - m)] = s_add(ua, acc0);
-        if (rb < m) x[ob] = acc1;
-        else if (rb < f) ubuf[nd.u_off + (rb - m)] = s_add(ub, acc1);
+        if (ra < m) {
+            x[ORDERED ? nd.own0 + ra : ix[ra]] = acc0;
+            if (f == m) push_down(ge, nd.nchild, f, ra, xb, acc0);
+        } else if (ra < f) {
+            const VT u = s_add(ua, acc0);
+            if (nd.pacc_off >= 0) acc[nd.pacc_off + ca] = u;
+            else ubuf[nd.u_off + (ra - m)] = u;
+        }
+        if (rb < m) {
+            x[ORDERED ? nd.own0 + rb : ix[rb]] = acc1;
+            if (f == m) push_down(ge, nd.nchild, f, rb, xb, acc1);
+        } else if (rb < f) {
+            const VT u = s_add(ub, acc1);
+            if (nd.pacc_off >= 0) acc[nd.pacc_off + cb] = u;
+            else ubuf[nd.u_off + (rb - m)] = u;
+        }
     }
 }
 
-// downward sweep, one tree level: x[own] -= F12 x[boundary]
-template <typename MT, typename VT, int LPR>
-__global__ __launch_bounds__(256) void nd_bwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ front,
-                                                     const int32_t* __restrict__ idx, VT* __restrict__ x) {
+// downward sweep, one tree level: x[own] -= U x[boundary]; the boundary vector was filled by the ancestors' launches, and this
+// launch fills the children's: the rows it finishes, and (split over the node's tiles) the boundary entries it received
+template <typename MT, typename VT, int LPR, bool ORDERED>
+__global__ __launch_bounds__(256) void nd_bwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ ufac,
+                                                     const int32_t* __restrict__ idx, const int32_t* __restrict__ gell, VT* __restrict__ x,
+                                                     VT* __restrict__ xb) {
     __shared__ VT vs[kCH];
+    constexpr int ROWS = 512 / LPR;
     const NdNodeDev nd = lnodes[blockIdx.x];
-    const int32_t r0 = (int32_t)blockIdx.y * (512 / LPR);
+    const int32_t r0 = (int32_t)blockIdx.y * ROWS;
     const int32_t m = nd.m, f = nd.f, b = f - m;
     if (r0 >= m || b == 0) return;
     const int32_t* ix = idx + nd.idx_off;
-    const MT* F = front + nd.front_off + m;
+    const int32_t* ge = gell + nd.ge_off;
+    const MT* U = ufac + nd.ufac_off;
+    const VT* bv = xb + nd.u_off;
     const int tid = threadIdx.x, sw = tid / LPR, sl = tid % LPR;
     const int32_t ra = r0 + sw, rb = r0 + sw + 256 / LPR;
-    const MT* Fa = F + (size_t)min(ra, m - 1) * f;
-    const MT* Fb = F + (size_t)min(rb, m - 1) * f;
+    const MT* Ua = U + (size_t)min(ra, m - 1) * b;
+    const MT* Ub = U + (size_t)min(rb, m - 1) * b;
     // the rows' own entries are needed only at the end: issue their loads before the sweep over the boundary
-    const int32_t ia = ix[min(ra, m - 1)], ib = ix[min(rb, m - 1)];
-    const VT xa = x[ia], xb = x[ib];
+    const int32_t ia = ORDERED ? nd.own0 + min(ra, m - 1) : ix[min(ra, m - 1)], ib = ORDERED ? nd.own0 + min(rb, m - 1) : ix[min(rb, m - 1)];
+    const VT xa = x[ia], xc = x[ib];
     VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
     MT pa[4], pb[4];
-    row_pair_prefetch<LPR>(Fa, Fb, min(kCH, b), sl, pa, pb);
+    row_pair_prefetch<LPR>(Ua, Ub, min(kCH, b), sl, pa, pb);
     for (int32_t c0 = 0; c0 < b; c0 += kCH) {
         const int32_t cn = min(kCH, b - c0);
-        for (int32_t j = tid; j < cn; j += 256) vs[j] = x[ix[m + c0 + j]];
+        for (int32_t j = tid; j < cn; j += 256) vs[j] = bv[c0 + j];
         __syncthreads();
-        if (c0 == 0) two_row_dot_prefetched<LPR>(Fa, Fb, vs, cn, sl, acc0, acc1, pa, pb);
-        else two_row_dot<LPR>(Fa + c0, Fb + c0, vs, cn, sl, acc0, acc1);
+        if (c0 == 0) two_row_dot_prefetched<LPR>(Ua, Ub, vs, cn, sl, acc0, acc1, pa, pb);
+        else two_row_dot<LPR>(Ua + c0, Ub + c0, vs, cn, sl, acc0, acc1);
         __syncthreads();
     }
-    acc0 = sub16_sum<LPR>(acc0);
-    acc1 = sub16_sum<LPR>(acc1);
+    acc0 = lanes_sum<LPR>(acc0);
+    acc1 = lanes_sum<LPR>(acc1);
     if (sl == 0) {
-        if (ra < m) x[ia] = s_sub(xa, acc0);
-        if (rb < m) x[ib] = s_sub(xb, acc1);
+        if (ra < m) {
+            const VT v = s_sub(xa, acc0);
+            x[ia] = v;
+            push_down(ge, nd.nchild, f, ra, xb, v);
+        }
+        if (rb < m) {
+            const VT v = s_sub(xc, acc1);
+            x[ib] = v;
+            push_down(ge, nd.nchild, f, rb, xb, v);
+        }
+    }
+    if (nd.nchild > 0) {  // the boundary entries this node received, handed on to the children whose boundaries hold them
+        const int32_t ntile = (m + ROWS - 1) / ROWS;
+        const int64_t total = (int64_t)nd.nchild * b;
+        for (int64_t e = (int64_t)blockIdx.y * 256 + tid; e < total; e += (int64_t)ntile * 256) {
+            const int32_t c = (int32_t)(e / b), j = (int32_t)(e - (int64_t)c * b);
+            const int32_t g = ge[(size_t)c * f + m + j];
+            if (g >= 0) xb[g] = bv[j];
+        }
     }
 }
 
 // ---- sweeps of the transposed / conjugate-transposed system on the same factors (the adjoint eigenproblem of
 // Sensitivity/__init__.py:230-311 needs (A - sigma M)^-H without a second factorisation) --------------------------------------
 // C^T has the fronts F^T, so with the stored blocks  inv = F11^-1, S1 = -F21 inv, S2 = inv F12:
-//     up:    z = [inv | S2]^T v   (the node's first m rows, read down their columns);  y[own] = z[:m];  update = v_B - z[m:]
+//     up:    z = [inv | S2]^T v   (the columns of the packed inv and U blocks);  y[own] = z[:m];  update = v_B - z[m:]
 //     down:  x[own] = y[own] + S1^T x[boundary]
-// Column access of row-major fronts: 64 lanes run along a row (coalesced), four slices of the rows per workgroup.
+// Column access of row-major blocks: 64 lanes run along a row (coalesced), four slices of the rows per workgroup.  These
+// sweeps keep the pull form (gather rows + update vectors) and address the vectors through idx.
 template <bool CONJ, typename MT>
 __device__ __forceinline__ MT maybe_conj(MT a) {
     if constexpr (CONJ) return s_conj(a);
@@ -889,7 +999,7 @@ __device__ __forceinline__ MT maybe_conj(MT a) {
 }
 
 template <typename MT, typename VT, bool CONJ, bool DOWN>
-__global__ __launch_bounds__(256) void nd_sweepT_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ front,
+__global__ __launch_bounds__(256) void nd_sweepT_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ lfac, const MT* __restrict__ ufac,
                                                         const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
                                                         const VT* __restrict__ rhs, VT* __restrict__ x, VT* __restrict__ ubuf) {
     __shared__ VT vs[kCH];
@@ -902,9 +1012,14 @@ __global__ __launch_bounds__(256) void nd_sweepT_kernel(const NdNodeDev* __restr
     if (c0 >= ncols || (DOWN && b == 0)) return;
     const int32_t* ix = idx + nd.idx_off;
     const int32_t* ge = gell + nd.ge_off;
-    const MT* F = front + nd.front_off + (DOWN ? (size_t)m * f : 0);
     const int tid = threadIdx.x, lane = tid & 63, sl = tid >> 6;
     const int32_t col = min(c0 + lane, ncols - 1);
+    // this lane's column: base pointer and row stride inside the packed blocks
+    const MT* Fc;
+    int32_t ld;
+    if (DOWN) Fc = lfac + nd.lfac_off + (size_t)m * m + col, ld = m;
+    else if (col < m) Fc = lfac + nd.lfac_off + col, ld = m;
+    else Fc = ufac + nd.ufac_off + (col - m), ld = b;
     VT acc = scalar_traits<VT>::zero();
     for (int32_t k0 = 0; k0 < K; k0 += kCH) {
         const int32_t kn = min(kCH, K - k0);
@@ -913,16 +1028,16 @@ __global__ __launch_bounds__(256) void nd_sweepT_kernel(const NdNodeDev* __restr
             else vs[j] = gather_updates(ge, nd.nchild, f, k0 + j, ubuf, rhs[ix[k0 + j]]);
         }
         __syncthreads();
-        const MT* Fc = F + (size_t)k0 * f + col;
+        const MT* Fk = Fc + (size_t)k0 * ld;
         int32_t k = sl;
         for (; k + 12 < kn; k += 16) {
-            const MT a0 = Fc[(size_t)k * f], a1 = Fc[(size_t)(k + 4) * f], a2 = Fc[(size_t)(k + 8) * f], a3 = Fc[(size_t)(k + 12) * f];
+            const MT a0 = Fk[(size_t)k * ld], a1 = Fk[(size_t)(k + 4) * ld], a2 = Fk[(size_t)(k + 8) * ld], a3 = Fk[(size_t)(k + 12) * ld];
             fma_acc(acc, maybe_conj<CONJ>(a0), vs[k]);
             fma_acc(acc, maybe_conj<CONJ>(a1), vs[k + 4]);
             fma_acc(acc, maybe_conj<CONJ>(a2), vs[k + 8]);
             fma_acc(acc, maybe_conj<CONJ>(a3), vs[k + 12]);
         }
-        for (; k < kn; k += 4) fma_acc(acc, maybe_conj<CONJ>(Fc[(size_t)k * f]), vs[k]);
+        for (; k < kn; k += 4) fma_acc(acc, maybe_conj<CONJ>(Fk[(size_t)k * ld]), vs[k]);
         __syncthreads();
     }
     part[sl][lane] = acc;
@@ -942,22 +1057,31 @@ struct lsa_ndlu {
     lsa_ctx* ctx = nullptr;
     NdSymbolic S;
     int dtype = LSA_C128;
-    std::vector<NdLevel> levels;
+    bool ordered = false;           // the matrix came in elimination order: own unknown r of a node is own0 + r
+    std::vector<NdChunk> chunks;    // factorisation order
+    std::vector<NdLevel> levels;    // sweep order
     NdNodeDev *d_nodes = nullptr, *d_lnodes = nullptr;  // by node id / in lvl_nodes order
     int32_t* d_gell = nullptr;
-    int32_t *d_idx = nullptr, *d_cmap = nullptr, *d_tiles = nullptr, *d_lvl_nodes = nullptr;
+    int32_t *d_idx = nullptr, *d_cmap = nullptr, *d_tiles = nullptr, *d_chunk_nodes = nullptr;
     int64_t* d_asm_dst = nullptr;
     int32_t* d_asm_src = nullptr;
+    int64_t asm_count = 0;
     int32_t *d_ipiv = nullptr, *d_rowq = nullptr, *d_flag = nullptr, *d_xflag = nullptr;
     unsigned long long* d_maxabs = nullptr;
-    void *d_front = nullptr, *d_scratch = nullptr, *d_ubuf = nullptr, *d_tmp = nullptr, *d_ybuf = nullptr, *d_ysm = nullptr;
+    void *d_lfac = nullptr, *d_ufac = nullptr;  // packed factors (resident)
+    void *d_work = nullptr, *d_upd = nullptr;   // working fronts of one chunk; live update matrices
+    void *d_ubuf = nullptr, *d_xb = nullptr, *d_acc = nullptr;  // sweeps: update vectors (pull form), boundary vectors, slot rows (push form)
+    void *d_tmp = nullptr, *d_ybuf = nullptr, *d_ysm = nullptr;
+    int64_t lfac_entries = 0, ufac_entries = 0, work_entries = 0, upd_entries = 0, acc_entries = 0;
+    int64_t xupd_slot = 0;                     // subtree-parallel: scalars per rank in the exchange region at the start of the update arena
     int32_t *d_cand[2] = {nullptr, nullptr};  // tournament pivoting: candidate rows, two buffers used in turn
-    void* d_dinv = nullptr;                    // ... the inverted pivot tile of every node of the level being eliminated
-    int32_t tp_min = 1 << 30;                  // levels whose tallest pivot block has at least this many rows use it
+    void* d_dinv = nullptr;                    // ... the inverted pivot tile of every node of the chunk being eliminated
+    int32_t tp_min = 1 << 30;                  // chunks whose tallest pivot block has at least this many rows use it
     hipStream_t side = nullptr;                // ... the next block's tournament runs here, under the current block's update
     hipEvent_t ev_panel = nullptr, ev_pivots = nullptr;
     double seconds_analyse = 0.0, seconds_numeric = 0.0;
     int32_t solve_launches = 0;
+    int acc_vbytes = 0;  // scalar size of the vectors the slot rows were last used with (their never-written entries must read zero)
 };
 
 namespace {
@@ -965,8 +1089,8 @@ namespace {
 void nd_free(lsa_ndlu* f) {
     if (!f) return;
     for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
-                    (void*)f->d_lvl_nodes, (void*)f->d_asm_dst, (void*)f->d_asm_src, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_xflag, (void*)f->d_maxabs,
-                    f->d_front, f->d_scratch, f->d_ubuf, f->d_tmp, f->d_ybuf, f->d_ysm, (void*)f->d_cand[0], (void*)f->d_cand[1], f->d_dinv})
+                    (void*)f->d_chunk_nodes, (void*)f->d_asm_dst, (void*)f->d_asm_src, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_xflag, (void*)f->d_maxabs,
+                    f->d_lfac, f->d_ufac, f->d_work, f->d_upd, f->d_ubuf, f->d_xb, f->d_acc, f->d_tmp, f->d_ybuf, f->d_ysm, (void*)f->d_cand[0], (void*)f->d_cand[1], f->d_dinv})
         if (p) (void)hipFree(p);
     if (f->ev_panel) (void)hipEventDestroy(f->ev_panel);
     if (f->ev_pivots) (void)hipEventDestroy(f->ev_pivots);
@@ -982,115 +1106,313 @@ int upload(lsa_ctx* ctx, const std::vector<U>& h, U** d) {
     return LSA_OK;
 }
 
-// device tables + tile lists from the analysis
+// first-fit allocator over [0, inf) with coalescing free list, run on the host over the chunk order: the offsets it hands out
+// are the update arena's layout (a block lives from its node's chunk to its parent's), its high-water mark the arena's size
+struct ArenaPlan {
+    std::vector<std::pair<int64_t, int64_t>> free_;  // (offset, size), sorted by offset
+    int64_t top = 0;                                  // high-water mark
+    int64_t alloc(int64_t size) {
+        if (size <= 0) return 0;
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].second >= size) {
+                const int64_t off = free_[i].first;
+                if (free_[i].second == size) free_.erase(free_.begin() + (int64_t)i);
+                else free_[i] = {off + size, free_[i].second - size};
+                return off;
+            }
+        if (!free_.empty() && free_.back().first + free_.back().second == top) {  // grow the block at the end
+            const int64_t off = free_.back().first;
+            top = off + size;
+            free_.pop_back();
+            return off;
+        }
+        const int64_t off = top;
+        top += size;
+        return off;
+    }
+    void release(int64_t off, int64_t size) {
+        if (size <= 0) return;
+        auto it = std::lower_bound(free_.begin(), free_.end(), std::make_pair(off, (int64_t)0));
+        it = free_.insert(it, {off, size});
+        if (it + 1 != free_.end() && it->first + it->second == (it + 1)->first) {
+            it->second += (it + 1)->second;
+            free_.erase(it + 1);
+        }
+        if (it != free_.begin() && (it - 1)->first + (it - 1)->second == it->first) {
+            (it - 1)->second += it->second;
+            free_.erase(it);
+        }
+    }
+};
+
+// device tables, the memory plan (packed factors, chunks of working fronts, update arena) and tile lists from the analysis
 int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
-    const NdSymbolic& S = f->S;
+    NdSymbolic& S = f->S;
     const int32_t nt = S.nt;
+    const size_t es = esize(f->dtype);
+    const bool dist = S.nranks > 1;
     {
         const char* e = getenv("LSA_ND_TP_MIN");
         f->tp_min = e && *e ? std::max(1, atoi(e)) : 384;
     }
+    // (the status word of the subtree-parallel form first: ranks agree on a failed set-up through it, lsa_ndlu_create_tree)
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_xflag, 4 * sizeof(int32_t) * (size_t)std::max(1, S.nranks)));
+    f->ordered = true;
+    for (size_t k = 0; k < S.perm.size() && f->ordered; ++k) f->ordered = S.perm[k] == (int32_t)k || dist;
+    if (dist)  // a tree given by the caller owns contiguous index ranges: own0 = the first of them (the padded layout has holes)
+        for (int32_t t = 0; t < nt && f->ordered; ++t)
+            for (int32_t r = 1; r < S.m[(size_t)t]; ++r)
+                if (S.idx[(size_t)S.idx_off[(size_t)t] + r] != S.idx[(size_t)S.idx_off[(size_t)t]] + r) {
+                    f->ordered = false;
+                    break;
+                }
     std::vector<NdNodeDev> nodes((size_t)nt);
     std::vector<int32_t> tiles;
-    f->levels.assign((size_t)S.nlevels, NdLevel());
     auto begin_list = [&](TileList& tl) { tl.off = (int64_t)tiles.size() / 2; tl.count = 0; };
     auto push = [&](TileList& tl, int32_t a, int32_t b) {
         tiles.push_back(a);
         tiles.push_back(b);
         ++tl.count;
     };
-    // rank of every node among its parent's children
-    std::vector<int32_t> rank((size_t)nt, 0);
-    for (int32_t t = 0; t < nt; ++t)
-        for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) rank[(size_t)S.child_idx[(size_t)cp]] = cp - S.child_ptr[(size_t)t];
+    auto is_xroot = [&](int32_t q) { return dist && S.kind[(size_t)q] != 2 && S.parent[(size_t)q] >= 0 && S.kind[(size_t)S.parent[(size_t)q]] == 2; };
+    // ---- packed factors, slot rows of the upward sweep ----
+    int64_t lrun = 0, urun = 0, arun = 0;
     for (int32_t t = 0; t < nt; ++t) {  // every kept node, the other ranks' subtree roots included (they are children here)
         NdNodeDev& nd = nodes[(size_t)t];
-        nd.front_off = S.front_off[(size_t)t];
-        nd.scr_off = 0;
+        const int64_t m = S.m[(size_t)t], ff = S.f[(size_t)t], b = ff - m;
+        nd.front_off = 0;
+        nd.lfac_off = nd.ufac_off = 0;
+        if (S.kind[(size_t)t] != 3) {
+            nd.lfac_off = lrun;
+            nd.ufac_off = urun;
+            lrun += ff * m;
+            urun += m * b;
+        }
+        nd.upd_off = 0;
         nd.u_off = S.u_off[(size_t)t];
-        nd.g_off = S.g_off[(size_t)t];
+        nd.ge_off = S.ge_off[(size_t)t];
+        nd.acc_off = nd.pacc_off = -1;
         nd.idx_off = (int32_t)S.idx_off[(size_t)t];
         nd.cmap_off = S.cmap_off[(size_t)t];
         nd.piv_off = S.piv_off[(size_t)t];
-        nd.m = S.m[(size_t)t];
-        nd.f = S.f[(size_t)t];
+        nd.own0 = m > 0 ? S.idx[(size_t)S.idx_off[(size_t)t]] : 0;
+        nd.m = (int32_t)m;
+        nd.f = (int32_t)ff;
         nd.parent = S.parent[(size_t)t];
         nd.nchild = S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t];
-        nd.pad1 = 0;
-        nd.ge_off = S.ge_off[(size_t)t];
     }
-    int64_t max_scratch = 1;
+    for (int32_t t = 0; t < nt; ++t) {
+        // push form unless a child's update vector arrives by all-gather (another rank's subtree root): then the node pulls
+        const int32_t c0 = S.child_ptr[(size_t)t], c1 = S.child_ptr[(size_t)t + 1];
+        bool pull = false;
+        for (int32_t cp = c0; cp < c1; ++cp) pull |= is_xroot(S.child_idx[(size_t)cp]);
+        if (c1 == c0 || pull || S.kind[(size_t)t] == 3) continue;
+        nodes[(size_t)t].acc_off = arun;
+        for (int32_t cp = c0; cp < c1; ++cp) nodes[(size_t)S.child_idx[(size_t)cp]].pacc_off = arun + (int64_t)(cp - c0) * S.f[(size_t)t];
+        arun += (int64_t)(c1 - c0) * S.f[(size_t)t];
+    }
+    f->lfac_entries = lrun;
+    f->ufac_entries = urun;
+    f->acc_entries = arun;
+    // ---- chunks: the nodes of a work level, larger pivot blocks first, cut where the working fronts would outgrow the arena ----
+    int64_t max_front = 1, max_level = 1;
     for (int32_t l = 0; l < S.nlevels; ++l) {
-        NdLevel& L = f->levels[(size_t)l];
-        L.node_begin = S.lvl_ptr[(size_t)l];
-        L.node_count = S.lvl_ptr[(size_t)l + 1] - L.node_begin;
-        int64_t scr = 0;
-        int32_t lvl_children = 0;
-        for (int32_t q = 0; q < L.node_count; ++q) {
-            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            const int64_t m = S.m[(size_t)t], ff = S.f[(size_t)t], b = ff - m;
-            nodes[(size_t)t].scr_off = scr;
-            scr += m * m + 2 * m * b;
-            L.max_m = std::max(L.max_m, (int32_t)m);
-            L.sorted_m.push_back((int32_t)m);
-            lvl_children = std::max(lvl_children, S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t]);
+        int64_t sum = 0;
+        for (int32_t q = S.lvl_ptr[(size_t)l]; q < S.lvl_ptr[(size_t)l + 1]; ++q) {
+            const int64_t ff = S.f[(size_t)S.lvl_nodes[(size_t)q]];
+            sum += ff * ff;
+            max_front = std::max(max_front, ff * ff);
         }
-        L.scratch = scr;
-        max_scratch = std::max(max_scratch, scr);
-        // extend-add: one list per child rank (children of one parent never share a launch)
-        L.ext.assign((size_t)lvl_children, TileList());
-        for (int32_t r = 0; r < lvl_children; ++r) {
-            begin_list(L.ext[(size_t)r]);
-            for (int32_t q = 0; q < L.node_count; ++q) {
-                const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-                if (S.child_ptr[(size_t)t] + r >= S.child_ptr[(size_t)t + 1]) continue;
-                const int32_t c = S.child_idx[(size_t)S.child_ptr[(size_t)t] + r];
-                const int32_t bc = S.f[(size_t)c] - S.m[(size_t)c];
-                for (int32_t i0 = 0; i0 < bc; i0 += 16) push(L.ext[(size_t)r], c, i0);
+        max_level = std::max(max_level, sum);
+    }
+    int64_t budget = max_level;
+    {
+        // a level is factored in one go while its fronts fit a quarter of what the packed factors leave free (LSA_ND_WORK_MB
+        // overrides); a single front always has to fit
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
+        const int64_t after = (int64_t)free_b - (lrun + urun) * (int64_t)es;
+        int64_t cap = std::max<int64_t>(after / 4, (int64_t)256 << 20) / (int64_t)es;
+        if (const char* e = getenv("LSA_ND_WORK_MB")) cap = std::max<int64_t>(atoll(e), 1) * (1 << 20) / (int64_t)es;
+        budget = std::max(max_front, std::min(max_level, cap));
+    }
+    f->chunks.clear();
+    std::vector<int32_t> chunk_nodes;  // node ids in chunk order
+    std::vector<int32_t> chunk_of((size_t)nt, -1);
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+        int64_t used = 0;
+        for (int32_t q = S.lvl_ptr[(size_t)l]; q < S.lvl_ptr[(size_t)l + 1]; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)q];
+            const int64_t ff = S.f[(size_t)t];
+            if (q == S.lvl_ptr[(size_t)l] || used + ff * ff > budget) {
+                NdChunk c;
+                c.node_begin = (int32_t)chunk_nodes.size();
+                c.exchange_before = dist && l == S.phase_b_level && q == S.lvl_ptr[(size_t)l];
+                f->chunks.push_back(c);
+                used = 0;
+            }
+            NdChunk& c = f->chunks.back();
+            nodes[(size_t)t].front_off = used;
+            used += ff * ff;
+            c.work_entries = used;
+            ++c.node_count;
+            c.max_m = std::max(c.max_m, S.m[(size_t)t]);
+            c.max_f = std::max(c.max_f, (int32_t)ff);
+            c.sorted_m.push_back(S.m[(size_t)t]);
+            chunk_of[(size_t)t] = (int32_t)f->chunks.size() - 1;
+            chunk_nodes.push_back(t);
+        }
+    }
+    f->work_entries = 1;
+    for (const NdChunk& c : f->chunks) f->work_entries = std::max(f->work_entries, c.work_entries);
+    // ---- update arena: the subtree roots of the ranks in one slot per rank at its start (the exchange region of the in-place
+    // all-gather, laid out from what every rank knows: same order, same sizes), the rest by first fit over the chunk order ----
+    f->xupd_slot = 0;
+    if (dist) {
+        std::vector<int64_t> use((size_t)S.nranks, 0);
+        for (int32_t q = 0; q < nt; ++q)
+            if (is_xroot(q)) {
+                const int64_t b = S.f[(size_t)q] - S.m[(size_t)q];
+                const int32_t o = (int32_t)(S.front_off[(size_t)q] / std::max<int64_t>(S.xfront_slot, 1));  // owner: its slot of the logical layout
+                use[(size_t)o] += b * b;
+            }
+        for (int64_t v : use) f->xupd_slot = std::max(f->xupd_slot, v);
+        std::fill(use.begin(), use.end(), 0);
+        for (int32_t q = 0; q < nt; ++q)
+            if (is_xroot(q)) {
+                const int64_t b = S.f[(size_t)q] - S.m[(size_t)q];
+                const int32_t o = (int32_t)(S.front_off[(size_t)q] / std::max<int64_t>(S.xfront_slot, 1));
+                nodes[(size_t)q].upd_off = f->xupd_slot * o + use[(size_t)o];
+                use[(size_t)o] += b * b;
+            }
+    }
+    {
+        ArenaPlan arena;
+        const int64_t base = f->xupd_slot * S.nranks;
+        for (size_t ci = 0; ci < f->chunks.size(); ++ci) {
+            const NdChunk& c = f->chunks[ci];
+            for (int32_t q = 0; q < c.node_count; ++q) {  // blocks written by this chunk
+                const int32_t t = chunk_nodes[(size_t)c.node_begin + q];
+                const int64_t b = S.f[(size_t)t] - S.m[(size_t)t];
+                if (b > 0 && !is_xroot(t)) nodes[(size_t)t].upd_off = base + arena.alloc(b * b);
+            }
+            // blocks consumed by this chunk are free from the next chunk on.  (This chunk's own blocks were placed first: a
+            // block a parent reads in this chunk's extend-add must not be handed to a node that is saved in the same chunk.)
+            for (int32_t q = 0; q < c.node_count; ++q) {
+                const int32_t t = chunk_nodes[(size_t)c.node_begin + q];
+                for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) {
+                    const int32_t ch = S.child_idx[(size_t)cp];
+                    const int64_t b = S.f[(size_t)ch] - S.m[(size_t)ch];
+                    if (!is_xroot(ch)) arena.release(nodes[(size_t)ch].upd_off - base, b * b);
+                }
             }
         }
-        begin_list(L.unperm);
-        for (int32_t q = 0; q < L.node_count; ++q) {
-            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            for (int32_t r0 = 0; r0 < S.m[(size_t)t]; r0 += 16) push(L.unperm, t, r0);
+        f->upd_entries = std::max<int64_t>(base + arena.top, 1);
+    }
+    // ---- assembly lists by chunk: front_buffer[work offset] = values[asm_src] ----
+    {
+        std::vector<std::pair<int64_t, int32_t>> by_off;  // (offset of the node's front in the analysis' logical layout, node)
+        by_off.reserve((size_t)nt);
+        for (int32_t t = 0; t < nt; ++t) by_off.emplace_back(S.front_off[(size_t)t], t);
+        std::sort(by_off.begin(), by_off.end());
+        const size_t ne = S.asm_src.size();
+        std::vector<int32_t> node_of_entry(ne);
+        std::vector<int64_t> count(f->chunks.size() + 1, 0);
+        for (size_t e = 0; e < ne; ++e) {
+            auto it = std::upper_bound(by_off.begin(), by_off.end(), std::make_pair(S.asm_dst[e], (int32_t)0x7fffffff));
+            const int32_t t = (it - 1)->second;
+            node_of_entry[e] = t;
+            ++count[(size_t)chunk_of[(size_t)t] + 1];
         }
+        for (size_t c = 0; c < f->chunks.size(); ++c) {
+            f->chunks[c].asm_begin = count[c];
+            f->chunks[c].asm_count = count[c + 1];
+            count[c + 1] += count[c];
+        }
+        std::vector<int32_t> src(ne);
+        std::vector<int64_t> dst(ne);
+        std::vector<int64_t> fill(count.begin(), count.end() - 1);
+        for (size_t e = 0; e < ne; ++e) {
+            const int32_t t = node_of_entry[e];
+            const int64_t at = fill[(size_t)chunk_of[(size_t)t]]++;
+            src[(size_t)at] = S.asm_src[e];
+            dst[(size_t)at] = nodes[(size_t)t].front_off + (S.asm_dst[e] - S.front_off[(size_t)t]);
+        }
+        f->asm_count = (int64_t)ne;
+        LSA_CHECK(upload(ctx, dst, &f->d_asm_dst));
+        LSA_CHECK(upload(ctx, src, &f->d_asm_src));
+        // (the analysis' own copies are not needed again: the refactorisations walk the device lists)
+        std::vector<int32_t>().swap(S.asm_src);
+        std::vector<int64_t>().swap(S.asm_dst);
+    }
+    // ---- tile lists of the chunks ----
+    int32_t widest_tp = 0;
+    for (NdChunk& c : f->chunks) {
+        auto node = [&](int32_t q) { return chunk_nodes[(size_t)c.node_begin + q]; };
+        int32_t lvl_children = 0;
+        for (int32_t q = 0; q < c.node_count; ++q) lvl_children = std::max(lvl_children, S.child_ptr[(size_t)node(q) + 1] - S.child_ptr[(size_t)node(q)]);
+        // extend-add: one list per child rank (children of one parent never share a launch)
+        c.ext.assign((size_t)lvl_children, TileList());
+        for (int32_t r = 0; r < lvl_children; ++r) {
+            begin_list(c.ext[(size_t)r]);
+            for (int32_t q = 0; q < c.node_count; ++q) {
+                const int32_t t = node(q);
+                if (S.child_ptr[(size_t)t] + r >= S.child_ptr[(size_t)t + 1]) continue;
+                const int32_t ch = S.child_idx[(size_t)S.child_ptr[(size_t)t] + r];
+                const int32_t bc = S.f[(size_t)ch] - S.m[(size_t)ch];
+                for (int32_t i0 = 0; i0 < bc; i0 += 16) push(c.ext[(size_t)r], ch, i0);
+            }
+        }
+        begin_list(c.unperm);
+        for (int32_t q = 0; q < c.node_count; ++q)
+            for (int32_t r0 = 0; r0 < S.m[(size_t)node(q)]; r0 += 16) push(c.unperm, node(q), r0);
         for (int kind = 0; kind < 3; ++kind) {
-            begin_list(L.gemm[kind]);
-            for (int32_t q = 0; q < L.node_count; ++q) {
-                const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+            begin_list(c.gemm[kind]);
+            for (int32_t q = 0; q < c.node_count; ++q) {
+                const int32_t t = node(q);
                 const int32_t m = S.m[(size_t)t], b = S.f[(size_t)t] - m;
                 if (b == 0) continue;
                 const int32_t M = kind == 2 ? m : b, N = kind == 0 ? m : b;
                 for (int32_t tm = 0; tm * kGT < M; ++tm)
-                    for (int32_t tn = 0; tn * kGT < N; ++tn) push(L.gemm[kind], t, (tm << 16) | tn);
+                    for (int32_t tn = 0; tn * kGT < N; ++tn) push(c.gemm[kind], t, (tm << 16) | tn);
             }
         }
-        {
-            // the sweeps wait for memory: a level whose fronts make fewer 32-row tiles than a few per CU gets 8-row tiles
-            int64_t tiles32 = 0;
-            for (int32_t q = 0; q < L.node_count; ++q) tiles32 += (S.f[(size_t)S.lvl_nodes[(size_t)L.node_begin + q]] + kRT - 1) / kRT;
-            static const int64_t few = getenv("LSA_ND_SWEEP_FEW") ? atoll(getenv("LSA_ND_SWEEP_FEW")) : 4 * (int64_t)ctx->num_cu;
-            // thin separators (pivot blocks of a few dozen unknowns under fronts of a few hundred rows): the upward sweep reads
-            // f short rows per node; four lanes per row pair and 128 rows per workgroup gather the node's vector 1/4 as often
-            static const int32_t thin = getenv("LSA_ND_SWEEP_THIN") ? atoi(getenv("LSA_ND_SWEEP_THIN")) : 64;
-            L.sweep_rows = tiles32 <= few ? 8 : (L.max_m <= thin && l > 0) ? 128 : kRT;
+        begin_list(c.save);
+        for (int32_t q = 0; q < c.node_count; ++q) {
+            const int32_t t = node(q);
+            for (int32_t r0 = 0; r0 < S.f[(size_t)t] - S.m[(size_t)t]; r0 += 16) push(c.save, t, r0);
         }
+        if (c.max_m > 16384 && c.max_m < f->tp_min)  // (the tournament path has no such limit)
+            return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a pivot block of %d rows exceeds the 16 384 the panel kernels hold in registers (LSA_ND_TP_MIN = %d)",
+                                 c.max_m, f->tp_min);
+        if (c.max_m >= f->tp_min) widest_tp = std::max(widest_tp, c.node_count);
+    }
+    // ---- sweep levels ----
+    f->levels.assign((size_t)S.nlevels, NdLevel());
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+        NdLevel& L = f->levels[(size_t)l];
+        L.node_begin = S.lvl_ptr[(size_t)l];
+        L.node_count = S.lvl_ptr[(size_t)l + 1] - L.node_begin;
+        // the sweeps wait for memory: a level whose fronts make fewer 32-row tiles than a few per CU gets 8-row tiles
+        int64_t tiles32 = 0;
+        for (int32_t q = 0; q < L.node_count; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+            tiles32 += (S.f[(size_t)t] + kRT - 1) / kRT;
+            L.max_m = std::max(L.max_m, S.m[(size_t)t]);
+            L.max_f = std::max(L.max_f, S.f[(size_t)t]);
+        }
+        static const int64_t few = getenv("LSA_ND_SWEEP_FEW") ? atoll(getenv("LSA_ND_SWEEP_FEW")) : 4 * (int64_t)ctx->num_cu;
+        // thin separators (pivot blocks of a few dozen unknowns under fronts of a few hundred rows): the upward sweep reads
+        // f short rows per node; four lanes per row pair and 128 rows per workgroup gather the node's vector 1/4 as often
+        static const int32_t thin = getenv("LSA_ND_SWEEP_THIN") ? atoi(getenv("LSA_ND_SWEEP_THIN")) : 64;
+        L.sweep_rows = tiles32 <= few ? 8 : (L.max_m <= thin && l > 0) ? 128 : kRT;
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
             L.fwd_tiles = std::max(L.fwd_tiles, (S.f[(size_t)t] + L.sweep_rows - 1) / L.sweep_rows);
-            L.max_f = std::max(L.max_f, S.f[(size_t)t]);
             const int32_t bwd_rows = L.sweep_rows == 8 ? 8 : kRT;  // (the downward sweep of a thin level has few, long rows: 32-row tiles)
             if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.m[(size_t)t] + bwd_rows - 1) / bwd_rows);
         }
         if (L.fwd_tiles > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a front of more than %d rows is not supported", 65535 * 8);
-        begin_list(L.copyback);
-        for (int32_t q = 0; q < L.node_count; ++q) {
-            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            for (int32_t r0 = 0; r0 < S.f[(size_t)t]; r0 += 16) push(L.copyback, t, r0);
-        }
-        if (L.max_m > 16384 && L.max_m < f->tp_min)  // (the tournament path has no such limit)
-            return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a pivot block of %d rows exceeds the 16 384 the panel kernels hold in registers (LSA_ND_TP_MIN = %d)",
-                                 L.max_m, f->tp_min);
     }
     LSA_CHECK(upload(ctx, nodes, &f->d_nodes));
     {
@@ -1101,42 +1423,42 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     LSA_CHECK(upload(ctx, S.gell, &f->d_gell));
     LSA_CHECK(upload(ctx, S.idx, &f->d_idx));
     LSA_CHECK(upload(ctx, S.cmap, &f->d_cmap));
-    LSA_CHECK(upload(ctx, S.asm_dst, &f->d_asm_dst));
-    LSA_CHECK(upload(ctx, S.asm_src, &f->d_asm_src));
-    LSA_CHECK(upload(ctx, S.lvl_nodes, &f->d_lvl_nodes));
+    LSA_CHECK(upload(ctx, chunk_nodes, &f->d_chunk_nodes));
     LSA_CHECK(upload(ctx, tiles, &f->d_tiles));
-    const size_t es = esize(f->dtype);
     const size_t nn = (size_t)std::max<int32_t>(S.n, 1);
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_ipiv, nn * sizeof(int32_t)));
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_rowq, nn * sizeof(int32_t)));
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_flag, 4 * sizeof(int32_t)));
-    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_xflag, 4 * sizeof(int32_t) * (size_t)std::max(1, S.nranks)));
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_maxabs, sizeof(unsigned long long)));
-    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_front, (size_t)std::max<int64_t>(S.front_entries, 1) * es));
-    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_scratch, (size_t)max_scratch * es));
-    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ubuf, (size_t)std::max<int64_t>(S.u_off[(size_t)nt], 1) * 16));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_lfac, (size_t)std::max<int64_t>(f->lfac_entries, 1) * es));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ufac, (size_t)std::max<int64_t>(f->ufac_entries, 1) * es));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_work, (size_t)f->work_entries * es));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_upd, (size_t)f->upd_entries * es));
+    const size_t ub = (size_t)std::max<int64_t>(S.u_off[(size_t)nt], 1) * 16;
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ubuf, ub));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_xb, ub));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_acc, (size_t)std::max<int64_t>(f->acc_entries, 1) * 16));
+    // slots no child maps to are read by every solve and written by none: zero, once
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_acc, 0, (size_t)std::max<int64_t>(f->acc_entries, 1) * 16, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_ubuf, 0, ub, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_xb, 0, ub, ctx->stream));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_tmp, nn * 16));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ybuf, nn * kNB * es));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ysm, (size_t)std::max(nt, 1) * 8 * kNB * es));
-    {
-        int32_t widest = 0;  // nodes of the most populous level that eliminates by tournament
-        for (const NdLevel& L : f->levels)
-            if (L.max_m >= f->tp_min) widest = std::max(widest, L.node_count);
-        if (widest > 0) {
-            const size_t cand = ((size_t)S.n / kTRmin + (size_t)nt + 1) * kNB * sizeof(int32_t);
-            LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[0], cand));
-            LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[1], cand));
-            LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_dinv, (size_t)widest * kNB * kNB * es));
-            const char* la = getenv("LSA_ND_LOOKAHEAD");
-            if (!(la && *la && atoi(la) == 0)) {
-                // highest priority: the tournament's few workgroups must not queue behind the thousands of the product they
-                // run under
-                int lo_pri = 0, hi_pri = 0;
-                LSA_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
-                LSA_HIP_CHECK(ctx, hipStreamCreateWithPriority(&f->side, hipStreamNonBlocking, hi_pri));
-                LSA_HIP_CHECK(ctx, hipEventCreateWithFlags(&f->ev_panel, hipEventDisableTiming));
-                LSA_HIP_CHECK(ctx, hipEventCreateWithFlags(&f->ev_pivots, hipEventDisableTiming));
-            }
+    if (widest_tp > 0) {
+        const size_t cand = ((size_t)S.n / kTRmin + (size_t)nt + 1) * kNB * sizeof(int32_t);
+        LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[0], cand));
+        LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[1], cand));
+        LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_dinv, (size_t)widest_tp * kNB * kNB * es));
+        const char* la = getenv("LSA_ND_LOOKAHEAD");
+        if (!(la && *la && atoi(la) == 0)) {
+            // highest priority: the tournament's few workgroups must not queue behind the thousands of the product they
+            // run under
+            int lo_pri = 0, hi_pri = 0;
+            LSA_HIP_CHECK(ctx, hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+            LSA_HIP_CHECK(ctx, hipStreamCreateWithPriority(&f->side, hipStreamNonBlocking, hi_pri));
+            LSA_HIP_CHECK(ctx, hipEventCreateWithFlags(&f->ev_panel, hipEventDisableTiming));
+            LSA_HIP_CHECK(ctx, hipEventCreateWithFlags(&f->ev_pivots, hipEventDisableTiming));
         }
     }
     f->solve_launches = 0;
@@ -1145,10 +1467,10 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
 }
 
 template <typename T, int NT, int RPT, int W>
-void launch_block(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t kb, double tiny2) {
+void launch_block(lsa_ctx* ctx, lsa_ndlu* f, const NdChunk& L, int32_t kb, double tiny2) {
     hipStream_t st = ctx->stream;
-    const int32_t* lv = f->d_lvl_nodes + L.node_begin;
-    T* front = (T*)f->d_front;
+    const int32_t* lv = f->d_chunk_nodes + L.node_begin;
+    T* front = (T*)f->d_work;
     auto active_at = [&](int32_t k) {  // nodes are sorted by own size: those that still have column k form a prefix
         return (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), k, std::greater<int32_t>()) - L.sorted_m.begin());
     };
@@ -1175,9 +1497,9 @@ void launch_block(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, int32_t kb, doubl
 // the tournament for the block of columns starting at kb, on stream `st`: leaves D^-1 per node in d_dinv and the pivot
 // rows in ipiv / rowq
 template <typename T>
-void launch_tournament(lsa_ndlu* f, const NdLevel& L, int32_t kb, double tiny2, hipStream_t st) {
-    const int32_t* lv = f->d_lvl_nodes + L.node_begin;
-    const T* front = (const T*)f->d_front;
+void launch_tournament(lsa_ndlu* f, const NdChunk& L, int32_t kb, double tiny2, hipStream_t st) {
+    const int32_t* lv = f->d_chunk_nodes + L.node_begin;
+    const T* front = (const T*)f->d_work;
     const int32_t active = (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), kb, std::greater<int32_t>()) - L.sorted_m.begin());
     if (active == 0) return;
     int32_t sets = (L.max_m + tp_first<T>::rows - 1) / tp_first<T>::rows;
@@ -1202,10 +1524,10 @@ void launch_tournament(lsa_ndlu* f, const NdLevel& L, int32_t kb, double tiny2, 
 // the next block's 32 columns are updated first, and its tournament (a chain of single-workgroup launches) runs on a
 // second stream underneath the rank-32 product that updates everything else.
 template <typename T>
-int launch_level_tp(lsa_ctx* ctx, lsa_ndlu* f, const NdLevel& L, double tiny2) {
+int launch_level_tp(lsa_ctx* ctx, lsa_ndlu* f, const NdChunk& L, double tiny2) {
     hipStream_t st = ctx->stream, side = f->side;
-    const int32_t* lv = f->d_lvl_nodes + L.node_begin;
-    T* front = (T*)f->d_front;
+    const int32_t* lv = f->d_chunk_nodes + L.node_begin;
+    T* front = (T*)f->d_work;
     auto active_at = [&](int32_t k) {
         return (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), k, std::greater<int32_t>()) - L.sorted_m.begin());
     };
@@ -1249,36 +1571,53 @@ template <typename T>
 int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
     const NdSymbolic& S = f->S;
     hipStream_t st = ctx->stream;
-    T* front = (T*)f->d_front;
-    T* scratch = (T*)f->d_scratch;
-    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_front, 0, (size_t)std::max<int64_t>(S.front_entries, 1) * sizeof(T), st));
-    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_rowq, 0xFF, (size_t)std::max<int32_t>(S.n, 1) * sizeof(int32_t), st));
-    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_flag, 0, 4 * sizeof(int32_t), st));
-    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_maxabs, 0, sizeof(unsigned long long), st));
-    if (S.nnz > 0) {
-        const int blocks = (int)std::min<int64_t>((S.nnz + 255) / 256, (int64_t)ctx->num_cu * 16);
-        hipLaunchKernelGGL((nd_maxabs2_kernel<T>), dim3(blocks), dim3(256), 0, st, S.nnz, (const T*)C->val, f->d_maxabs);
-        if (!S.asm_src.empty())
-            hipLaunchKernelGGL((nd_assemble_kernel<T>), dim3(blocks), dim3(256), 0, st, (int64_t)S.asm_src.size(), (const T*)C->val, f->d_asm_src,
-                               f->d_asm_dst, front);
+    T* front = (T*)f->d_work;
+    T* lfac = (T*)f->d_lfac;
+    T* ufac = (T*)f->d_ufac;
+    T* upd = (T*)f->d_upd;
+    int rc0 = LSA_OK;
+    double max2 = 0.0;
+    {
+        // (a local failure up to here -- non-finite input, a HIP error -- is agreed on by all ranks before the first exchange)
+        auto head = [&]() -> int {
+            LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_rowq, 0xFF, (size_t)std::max<int32_t>(S.n, 1) * sizeof(int32_t), st));
+            LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_flag, 0, 4 * sizeof(int32_t), st));
+            LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_maxabs, 0, sizeof(unsigned long long), st));
+            if (S.nnz > 0) {
+                const int blocks = (int)std::min<int64_t>((S.nnz + 255) / 256, (int64_t)ctx->num_cu * 16);
+                hipLaunchKernelGGL((nd_maxabs2_kernel<T>), dim3(blocks), dim3(256), 0, st, S.nnz, (const T*)C->val, f->d_maxabs);
+            }
+            unsigned long long mbits = 0;
+            LSA_HIP_CHECK(ctx, hipMemcpyAsync(&mbits, f->d_maxabs, sizeof mbits, hipMemcpyDeviceToHost, st));
+            LSA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            memcpy(&max2, &mbits, sizeof max2);
+            if (!std::isfinite(max2)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "lsa_ndlu: the matrix holds non-finite values");
+            return LSA_OK;
+        };
+        rc0 = k_agree_status(ctx, head());
+        if (rc0 != LSA_OK) return rc0;
     }
-    unsigned long long mbits = 0;
-    LSA_HIP_CHECK(ctx, hipMemcpyAsync(&mbits, f->d_maxabs, sizeof mbits, hipMemcpyDeviceToHost, st));
-    LSA_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    double max2;
-    memcpy(&max2, &mbits, sizeof max2);
-    if (!std::isfinite(max2)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "lsa_ndlu: the matrix holds non-finite values");
     // (1e-15 * max|C|)^2: rounding level.  A shift next to an eigenvalue (the adjoint problem of the reference is shifted exactly at
     // a converged eigenvalue) gives legitimate pivots of 1e-12 max|C|; those solves are judged by their backward error.
     const double tiny2 = 1e-30 * max2;
     const int32_t* tl = f->d_tiles;
-    for (size_t li = 0; li < f->levels.size(); ++li) {
-        const NdLevel& L = f->levels[li];
-        // subtree-parallel: the ranks' subtree roots are done; every rank receives all of their fronts (update matrices)
-        if ((int32_t)li == S.phase_b_level && S.nranks > 1 && S.xfront_slot > 0)
-            LSA_CHECK(k_allgather_inplace(ctx, f->d_front, (size_t)S.xfront_slot * sizeof(T)));
+    bool exchanged = false;
+    for (size_t ci = 0; ci < f->chunks.size(); ++ci) {
+        const NdChunk& L = f->chunks[ci];
+        // subtree-parallel: the ranks' subtree roots are done; every rank receives all of their update matrices
+        if (L.exchange_before && f->xupd_slot > 0) {
+            LSA_CHECK(k_allgather_inplace(ctx, f->d_upd, (size_t)f->xupd_slot * sizeof(T)));
+            exchanged = true;
+        }
+        LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_work, 0, (size_t)L.work_entries * sizeof(T), st));
+        if (L.asm_count > 0) {
+            const int blocks = (int)std::min<int64_t>((L.asm_count + 255) / 256, (int64_t)ctx->num_cu * 16);
+            hipLaunchKernelGGL((nd_assemble_kernel<T>), dim3(blocks), dim3(256), 0, st, L.asm_count, (const T*)C->val, f->d_asm_src + L.asm_begin,
+                               f->d_asm_dst + L.asm_begin, front);
+        }
         for (const TileList& e : L.ext)
-            if (e.count > 0) hipLaunchKernelGGL((nd_extend_add_kernel<T>), dim3(e.count), dim3(256), 0, st, tl + 2 * e.off, f->d_nodes, f->d_cmap, front);
+            if (e.count > 0)
+                hipLaunchKernelGGL((nd_extend_add_kernel<T>), dim3(e.count), dim3(256), 0, st, tl + 2 * e.off, f->d_nodes, f->d_cmap, front, (const T*)upd);
         if (L.max_m >= f->tp_min) LSA_CHECK(launch_level_tp<T>(ctx, f, L, tiny2));
         for (int32_t kb = 0; kb < L.max_m && L.max_m < f->tp_min; kb += kNB) {
             if (L.max_m <= 64) launch_block<T, 64, 1, 8>(ctx, f, L, kb, tiny2);
@@ -1292,19 +1631,19 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
             else launch_block<T, 1024, 16, 1>(ctx, f, L, kb, tiny2);
         }
         if (L.unperm.count > 0)
-            hipLaunchKernelGGL((nd_unperm_kernel<T>), dim3(L.unperm.count), dim3(256), 0, st, tl + 2 * L.unperm.off, f->d_nodes, front, f->d_ipiv,
-                               f->d_rowq, scratch);
+            hipLaunchKernelGGL((nd_unperm_kernel<T>), dim3(L.unperm.count), dim3(256), 0, st, tl + 2 * L.unperm.off, f->d_nodes, (const T*)front, f->d_ipiv,
+                               f->d_rowq, lfac);
         if (L.gemm[0].count > 0)
-            hipLaunchKernelGGL((nd_gemm_kernel<T, 0>), dim3(L.gemm[0].count), dim3(256), 0, st, tl + 2 * L.gemm[0].off, f->d_nodes, front, scratch);
+            hipLaunchKernelGGL((nd_gemm_kernel<T, 0>), dim3(L.gemm[0].count), dim3(256), 0, st, tl + 2 * L.gemm[0].off, f->d_nodes, front, lfac, ufac);
         if (L.gemm[1].count > 0)
-            hipLaunchKernelGGL((nd_gemm_kernel<T, 1>), dim3(L.gemm[1].count), dim3(256), 0, st, tl + 2 * L.gemm[1].off, f->d_nodes, front, scratch);
+            hipLaunchKernelGGL((nd_gemm_kernel<T, 1>), dim3(L.gemm[1].count), dim3(256), 0, st, tl + 2 * L.gemm[1].off, f->d_nodes, front, lfac, ufac);
         if (L.gemm[2].count > 0)
-            hipLaunchKernelGGL((nd_gemm_kernel<T, 2>), dim3(L.gemm[2].count), dim3(256), 0, st, tl + 2 * L.gemm[2].off, f->d_nodes, front, scratch);
-        if (L.copyback.count > 0)
-            hipLaunchKernelGGL((nd_copyback_kernel<T>), dim3(L.copyback.count), dim3(256), 0, st, tl + 2 * L.copyback.off, f->d_nodes, front, scratch);
+            hipLaunchKernelGGL((nd_gemm_kernel<T, 2>), dim3(L.gemm[2].count), dim3(256), 0, st, tl + 2 * L.gemm[2].off, f->d_nodes, front, lfac, ufac);
+        if (L.save.count > 0)
+            hipLaunchKernelGGL((nd_save_update_kernel<T>), dim3(L.save.count), dim3(256), 0, st, tl + 2 * L.save.off, f->d_nodes, (const T*)front, upd);
     }
-    if ((int32_t)f->levels.size() == S.phase_b_level && S.nranks > 1 && S.xfront_slot > 0)  // (no replicated level: still a collective)
-        LSA_CHECK(k_allgather_inplace(ctx, f->d_front, (size_t)S.xfront_slot * sizeof(T)));
+    if (!exchanged && S.nranks > 1 && f->xupd_slot > 0)  // (no replicated level: still a collective)
+        LSA_CHECK(k_allgather_inplace(ctx, f->d_upd, (size_t)f->xupd_slot * sizeof(T)));
     int32_t hflag[4] = {0, 0, 0, 0};
     if (S.nranks > 1) {
         // every rank must take the same decision (a rank that returned early would leave the others in a collective):
@@ -1342,39 +1681,51 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
     return LSA_OK;
 }
 
-template <typename MT, typename VT>
-int nd_apply(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
+template <typename MT, typename VT, bool ORDERED>
+int nd_apply_ordered(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
     hipStream_t st = ctx->stream;
-    const MT* front = (const MT*)f->d_front;
+    const MT* lfac = (const MT*)f->d_lfac;
+    const MT* ufac = (const MT*)f->d_ufac;
     const NdSymbolic& S = f->S;
+    VT *ubuf = (VT*)f->d_ubuf, *acc = (VT*)f->d_acc, *xb = (VT*)f->d_xb;
+    if (f->acc_vbytes != (int)sizeof(VT)) {
+        // the slot rows are indexed in units of the vector scalar: after a solve with the other scalar type the entries no
+        // child writes no longer read zero
+        LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_acc, 0, (size_t)std::max<int64_t>(f->acc_entries, 1) * 16, st));
+        f->acc_vbytes = (int)sizeof(VT);
+    }
     for (size_t li = 0; li <= f->levels.size(); ++li) {
         // subtree-parallel: the update vectors of all ranks' subtree roots, before the replicated top of the tree
         if ((int32_t)li == S.phase_b_level && S.nranks > 1 && S.xu_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, f->d_ubuf, (size_t)S.xu_slot * sizeof(VT)));
         if (li == f->levels.size()) break;
         const NdLevel& L = f->levels[li];
         if (L.fwd_tiles > 0) {
+            const dim3 grid(L.node_count, L.fwd_tiles);
+            const NdNodeDev* ln = f->d_lnodes + L.node_begin;
             if (L.sweep_rows == 8)
-                hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 64>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,
-                                   f->d_gell, b, x, (VT*)f->d_ubuf);
+                hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 64, ORDERED>), grid, dim3(256), 0, st, ln, lfac, f->d_idx, f->d_gell, f->d_cmap, b, x, ubuf, acc, xb);
             else if (L.sweep_rows == 128)
-                hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 4>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,
-                                   f->d_gell, b, x, (VT*)f->d_ubuf);
+                hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 4, ORDERED>), grid, dim3(256), 0, st, ln, lfac, f->d_idx, f->d_gell, f->d_cmap, b, x, ubuf, acc, xb);
             else
-                hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 16>), dim3(L.node_count, L.fwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx,
-                                   f->d_gell, b, x, (VT*)f->d_ubuf);
+                hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 16, ORDERED>), grid, dim3(256), 0, st, ln, lfac, f->d_idx, f->d_gell, f->d_cmap, b, x, ubuf, acc, xb);
         }
     }
     for (size_t l = f->levels.size(); l-- > 0;) {
         const NdLevel& L = f->levels[l];
         if (L.bwd_tiles > 0) {
-            if (L.sweep_rows == 8)
-                hipLaunchKernelGGL((nd_bwd_kernel<MT, VT, 64>), dim3(L.node_count, L.bwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx, x);
-            else
-                hipLaunchKernelGGL((nd_bwd_kernel<MT, VT, 16>), dim3(L.node_count, L.bwd_tiles), dim3(256), 0, st, f->d_lnodes + L.node_begin, front, f->d_idx, x);
+            const dim3 grid(L.node_count, L.bwd_tiles);
+            const NdNodeDev* ln = f->d_lnodes + L.node_begin;
+            if (L.sweep_rows == 8) hipLaunchKernelGGL((nd_bwd_kernel<MT, VT, 64, ORDERED>), grid, dim3(256), 0, st, ln, ufac, f->d_idx, f->d_gell, x, xb);
+            else hipLaunchKernelGGL((nd_bwd_kernel<MT, VT, 16, ORDERED>), grid, dim3(256), 0, st, ln, ufac, f->d_idx, f->d_gell, x, xb);
         }
     }
     LSA_HIP_CHECK(ctx, hipGetLastError());
     return LSA_OK;
+}
+
+template <typename MT, typename VT>
+int nd_apply(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
+    return f->ordered ? nd_apply_ordered<MT, VT, true>(ctx, f, b, x) : nd_apply_ordered<MT, VT, false>(ctx, f, b, x);
 }
 
 }  // namespace
@@ -1383,7 +1734,8 @@ namespace {
 template <typename MT, typename VT, bool CONJ>
 int nd_apply_T(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
     hipStream_t st = ctx->stream;
-    const MT* front = (const MT*)f->d_front;
+    const MT* lfac = (const MT*)f->d_lfac;
+    const MT* ufac = (const MT*)f->d_ufac;
     const NdSymbolic& S = f->S;
     for (size_t li = 0; li <= f->levels.size(); ++li) {
         if ((int32_t)li == S.phase_b_level && S.nranks > 1 && S.xu_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, f->d_ubuf, (size_t)S.xu_slot * sizeof(VT)));
@@ -1391,13 +1743,13 @@ int nd_apply_T(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
         const NdLevel& L = f->levels[li];
         if (L.fwd_tiles > 0)
             hipLaunchKernelGGL((nd_sweepT_kernel<MT, VT, CONJ, false>), dim3(L.node_count, (L.max_f + 63) / 64), dim3(256), 0, st, f->d_lnodes + L.node_begin,
-                               front, f->d_idx, f->d_gell, b, x, (VT*)f->d_ubuf);
+                               lfac, ufac, f->d_idx, f->d_gell, b, x, (VT*)f->d_ubuf);
     }
     for (size_t l = f->levels.size(); l-- > 0;) {
         const NdLevel& L = f->levels[l];
         if (L.bwd_tiles > 0)
             hipLaunchKernelGGL((nd_sweepT_kernel<MT, VT, CONJ, true>), dim3(L.node_count, (L.max_m + 63) / 64), dim3(256), 0, st, f->d_lnodes + L.node_begin,
-                               front, f->d_idx, f->d_gell, b, x, (VT*)f->d_ubuf);
+                               lfac, ufac, f->d_idx, f->d_gell, b, x, (VT*)f->d_ubuf);
     }
     LSA_HIP_CHECK(ctx, hipGetLastError());
     return LSA_OK;
@@ -1502,7 +1854,9 @@ static int nd_symbolic_phase(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t 
                 }
             want |= 1ull;
         }
-        if (c->S.n == P->n && c->S.nnz == P->nnz && c->dtype == dtype && c->S.leaf_size == leaf_size && (!strict || c->S.constraint_hash == want) &&
+        // (an analysis parked with the caller's tree -- lsa_ndlu_prepare_tree -- stands for its pattern whatever the leaf size)
+        if (c->S.n == P->n && c->S.nnz == P->nnz && c->dtype == dtype && c->S.nranks == 1 && (c->S.tree_hash != 0 || c->S.leaf_size == leaf_size) &&
+            (!strict || c->S.constraint_hash == want) &&
             c->S.pattern_hash == nd_pattern_hash(P->n, P->h_rp.data(), P->h_ci.data())) {
             ctx->nd_cache = nullptr;
             c->seconds_analyse = 0.0;
@@ -1542,6 +1896,35 @@ int lsa_ndlu_prepare(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t leaf_siz
     LSA_CHECK(nd_symbolic_phase(ctx, P, dtype, leaf_size, constraint, true, &f));
     lsa_ndlu_drop_cache(ctx);
     ctx->nd_cache = f;  // the next lsa_ndlu_create on this pattern only runs the numeric phase
+    return LSA_OK;
+}
+
+int lsa_ndlu_prepare_tree(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t ntree, const int32_t* first, const int32_t* size, const int32_t* parent) {
+    if (!ctx || !P || (dtype != LSA_F64 && dtype != LSA_C128) || ntree < 0 || (ntree > 0 && (!first || !size || !parent)))
+        return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_prepare_tree: bad argument");
+    if (P->n != P->ncols || P->row0 != 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_prepare_tree: needs a square, unsharded matrix");
+    if ((int64_t)P->h_rp.size() != (int64_t)P->n + 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_prepare_tree: the matrix has no host copy of its pattern");
+    const double t0 = now_s();
+    lsa_ndlu_drop_cache(ctx);
+    lsa_ndlu* f = new lsa_ndlu();
+    f->ctx = ctx;
+    f->dtype = dtype;
+    char buf[256] = {0};
+    int rc;
+    try {
+        rc = nd_analyse_tree(P->n, P->h_rp.data(), P->h_ci.data(), ntree, first, size, parent, nullptr, 0, 1, &f->S, buf, (int)sizeof buf);
+    } catch (const std::bad_alloc&) {
+        rc = LSA_ERR_ARG;
+        snprintf(buf, sizeof buf, "lsa_ndlu_prepare_tree: out of host memory in the analysis");
+    }
+    if (rc != LSA_OK) lsa_set_error(ctx, rc, "%s", buf);
+    else rc = nd_setup(ctx, f);
+    if (rc != LSA_OK) {
+        nd_free(f);
+        return rc;
+    }
+    f->seconds_analyse = now_s() - t0;
+    ctx->nd_cache = f;
     return LSA_OK;
 }
 
@@ -1585,6 +1968,7 @@ int lsa_ndlu_create_tree(lsa_ctx* ctx, const lsa_mat* C, int32_t ntree, const in
     if ((int64_t)C->h_rp.size() != (int64_t)C->n + 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_create_tree: the matrix has no host copy of its pattern");
     const double t0 = now_s();
     lsa_ndlu* f = nullptr;
+    int setup_rc = LSA_OK;
     // the parked factorisation, if it was made for this pattern, this tree and this rank
     if (ctx->nd_cache) {
         lsa_ndlu* c = ctx->nd_cache;
@@ -1624,11 +2008,16 @@ int lsa_ndlu_create_tree(lsa_ctx* ctx, const lsa_mat* C, int32_t ntree, const in
         }
         if (rc == LSA_OK) rc = nd_setup(ctx, f);
         else lsa_set_error(ctx, rc, "%s", buf);
-        if (rc != LSA_OK) {
-            nd_free(f);
-            return rc;
-        }
+        setup_rc = rc;
         f->seconds_analyse = now_s() - t0;
+    }
+    // Collective agreement on the set-up (out of device memory for this rank's buffers -- their sizes differ from rank to
+    // rank --, a limit of the kernels, out of host memory in the analysis): no rank enters the exchanges of the numeric
+    // phase alone.
+    setup_rc = k_agree_status(ctx, setup_rc);
+    if (setup_rc != LSA_OK) {
+        nd_free(f);
+        return setup_rc;
     }
     const int rc = lsa_ndlu_refactor(ctx, f, C);
     if (rc != LSA_OK) {
@@ -1692,7 +2081,7 @@ int lsa_ndlu_info(const lsa_ndlu* f, int32_t* ntree, int32_t* nlevels, int32_t* 
         *max_front = mf;
     }
     if (factor_entries) *factor_entries = S.factor_entries;
-    if (front_entries) *front_entries = S.front_entries;
+    if (front_entries) *front_entries = f->lfac_entries + f->ufac_entries + f->work_entries + f->upd_entries;  // scalars of the device buffers
     // one solve reads every factor scalar once, the right-hand side once, and reads + writes the solution and the update vectors
     if (apply_bytes) *apply_bytes = S.factor_entries * (int64_t)esize(f->dtype) + 16 * (3 * (int64_t)S.n + 2 * S.u_off[(size_t)S.nt]);
     if (apply_launches) *apply_launches = f->solve_launches;

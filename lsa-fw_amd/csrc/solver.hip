@@ -25,7 +25,13 @@ inline double now_s() {
 struct OrthWork {
     void *h1 = nullptr, *h2 = nullptr, *hcol = nullptr;
     double* nrm2 = nullptr;
+    void* fused = nullptr;  // workspace of the five-launch CGS2 (k_cgs2_fused), allocated on first use
     int cap = 0;
+    int ensure_fused(lsa_ctx* ctx, int64_t n) {
+        if (fused) return LSA_OK;
+        LSA_HIP_ALLOC(ctx, hipMalloc(&fused, k_cgs2_fused_work_bytes(ctx, n, cap)));
+        return LSA_OK;
+    }
     int alloc(lsa_ctx* ctx, int cap_, int dtype) {
         cap = cap_;
         const size_t b = (size_t)(cap + 2) * esize(dtype);
@@ -36,9 +42,9 @@ struct OrthWork {
         return LSA_OK;
     }
     void release() {
-        for (void* p : {h1, h2, hcol, (void*)nrm2})
+        for (void* p : {h1, h2, hcol, (void*)nrm2, fused})
             if (p) (void)hipFree(p);
-        h1 = h2 = hcol = nullptr;
+        h1 = h2 = hcol = fused = nullptr;
         nrm2 = nullptr;
     }
 };
@@ -47,6 +53,12 @@ struct OrthWork {
 // `hcol_dev`, nothing is read back
 int orthonormalize_enqueue(lsa_ctx* ctx, int dtype, int64_t n, const void* V, int64_t ldv, int j, void* w, void* vnext, OrthWork& ow,
                            void* hcol_dev) {
+    static const bool fuse = !(getenv("LSA_KRYLOV_FUSED") && atoi(getenv("LSA_KRYLOV_FUSED")) == 0);
+    if (fuse) {  // five launches instead of nine where the shape allows it (same arithmetic as the batched Arnoldi steps)
+        LSA_CHECK(ow.ensure_fused(ctx, n));
+        const int frc = k_cgs2_fused(ctx, dtype, n, j, V, ldv, w, vnext, hcol_dev, ow.fused, nullptr, nullptr, nullptr);
+        if (frc <= 0) return frc;
+    }
     LSA_CHECK(k_multi_dot(ctx, dtype, n, j, V, ldv, w, ow.h1));
     LSA_CHECK(k_multi_axpy(ctx, dtype, n, j, V, ldv, ow.h1, w, nullptr));
     LSA_CHECK(k_multi_dot(ctx, dtype, n, j, V, ldv, w, ow.h2));
@@ -828,6 +840,13 @@ void lsa_krylov_drop_cache(lsa_ctx* ctx) {
     }
 }
 
+int lsa_krylov_shape(const lsa_krylov* k, int64_t* n, int32_t* ncv) {
+    if (!k) return LSA_ERR_ARG;
+    if (n) *n = k->n;
+    if (ncv) *ncv = k->ncv;
+    return LSA_OK;
+}
+
 int lsa_krylov_set_row_permutation(lsa_ctx* ctx, lsa_krylov* k, const int32_t* perm) {
     if (!ctx || !k) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_krylov_set_row_permutation: null argument");
     LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -888,9 +907,19 @@ static int krylov_enqueue_step(lsa_ctx* ctx, lsa_krylov* k, int32_t j, int32_t s
     pcr.adjoint = op->adjoint;
     LSA_CHECK(pc_global(ctx, pcr, op->Kfac->row0, op->n, dtype, rhs, k->w));
     LSA_CHECK(spmv_global(ctx, op->Kfac, dtype, k->w, op->gw.z, op->adjoint));
+    void* hcol_dev = (char*)k->Hdev + (size_t)slot * (size_t)(k->ncv + 2) * 16;
+    static const bool fuse = !(getenv("LSA_KRYLOV_FUSED") && atoi(getenv("LSA_KRYLOV_FUSED")) == 0);
+    if (fuse) {
+        // the check ||b - C y||, ||b|| rides in the first reduction of the orthogonalisation (its vector b - C y is needed only
+        // by the one-step path, which recomputes it)
+        LSA_CHECK(k->ow.ensure_fused(ctx, k->n));
+        if (op->keep) LSA_CHECK(k_mask(ctx, dtype, op->n, op->keep, k->w));
+        const int frc = k_cgs2_fused(ctx, dtype, k->n, j + 1, k->V, k->n, k->w, vn, hcol_dev, k->ow.fused, rhs, op->gw.z, k->checks + 2 * (size_t)slot);
+        if (frc <= 0) return frc;
+    }
     LSA_CHECK(k_residual_norms(ctx, dtype, op->n, rhs, op->gw.z, op->gw.w, k->checks + 2 * (size_t)slot));
-    if (op->keep) LSA_CHECK(k_mask(ctx, dtype, op->n, op->keep, k->w));
-    return orthonormalize_enqueue(ctx, dtype, k->n, k->V, k->n, j + 1, k->w, vn, k->ow, (char*)k->Hdev + (size_t)slot * (size_t)(k->ncv + 2) * 16);
+    if (op->keep && !fuse) LSA_CHECK(k_mask(ctx, dtype, op->n, op->keep, k->w));
+    return orthonormalize_enqueue(ctx, dtype, k->n, k->V, k->n, j + 1, k->w, vn, k->ow, hcol_dev);
 }
 
 // true when an operator apply is one exact LU solve whose result only needs checking, with nothing on the way that

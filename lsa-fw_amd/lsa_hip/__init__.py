@@ -67,6 +67,32 @@ class lsa_op_options(ctypes.Structure):
     ]
 
 
+class lsa_ks_options(ctypes.Structure):
+    _fields_ = [
+        ("nev", ctypes.c_int32),
+        ("max_restarts", ctypes.c_int32),
+        ("tol", ctypes.c_double),
+        ("which", ctypes.c_int32),
+        ("transform", ctypes.c_int32),
+        ("sigma", ctypes.c_double * 2),
+        ("antishift", ctypes.c_double * 2),
+        ("target", ctypes.c_double * 2),
+        ("seed", ctypes.c_uint64),
+        ("keep_fraction", ctypes.c_double),
+    ]
+
+
+class lsa_ks_result(ctypes.Structure):
+    _fields_ = [
+        ("nconv", ctypes.c_int32),
+        ("nout", ctypes.c_int32),
+        ("restarts", ctypes.c_int32),
+        ("pad", ctypes.c_int32),
+        ("op_applies", ctypes.c_int64),
+        ("next_unconverged", ctypes.c_double),
+    ]
+
+
 _P = ctypes.c_void_p
 _I32, _I64, _DBL = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 _PP = ctypes.POINTER(ctypes.c_void_p)
@@ -105,6 +131,7 @@ SIGNATURES = {
     "lsa_blu_apply_bytes": (ctypes.c_int, [_P, ctypes.POINTER(_I64)]),
     "lsa_blu_apply_launches": (ctypes.c_int, [_P, ctypes.POINTER(_I32)]),
     "lsa_nd_analyse": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _PP]),
+    "lsa_nd_order": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _PP]),
     "lsa_nd_analyse_tree": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _PP]),
     "lsa_nd_sym_export_dist": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "lsa_nd_sym_error": (ctypes.c_char_p, [_P]),
@@ -115,6 +142,7 @@ SIGNATURES = {
     "lsa_nd_sym_export_tables": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "lsa_ndlu_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
     "lsa_ndlu_prepare": (ctypes.c_int, [_P, _P, ctypes.c_int, _I32, _P]),
+    "lsa_ndlu_prepare_tree": (ctypes.c_int, [_P, _P, ctypes.c_int, _I32, _P, _P, _P]),
     "lsa_ndlu_create_tree": (ctypes.c_int, [_P, _P, _I32, _P, _P, _P, _P, _PP]),
     "lsa_ndlu_refactor": (ctypes.c_int, [_P, _P, _P]),
     "lsa_ndlu_destroy": (None, [_P]),
@@ -141,6 +169,13 @@ SIGNATURES = {
     "lsa_krylov_restart": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32]),
     "lsa_krylov_ritz_vectors": (ctypes.c_int, [_P, _P, _I32, _I32, _P, _I32, ctypes.c_int, _P]),
     "lsa_krylov_imag_norms": (ctypes.c_int, [_P, _I32, _P]),
+    "lsa_krylov_shape": (ctypes.c_int, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I32)]),
+    "lsa_mat_rows": (_I64, [_P]),
+    "lsa_krylov_solve": (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _P, _P, _P, _P]),
+    "lsa_eigs_sinvert": (ctypes.c_int, [_P, _P, _P, _DBL * 2, _I32, _I32, _DBL, _I32, ctypes.POINTER(lsa_op_options), _P, _P, _I32, _P, _P, _P, _P, _P]),
+    "lsa_dense_schur": (ctypes.c_int, [_I32, _P, _I32, _P, _I32]),
+    "lsa_dense_schur_reorder": (ctypes.c_int, [_I32, _P, _I32, _P, _I32, _P, ctypes.POINTER(_I32)]),
+    "lsa_dense_tri_eigenvectors": (ctypes.c_int, [_I32, _P, _I32, _P, _I32]),
     "lsa_eig_residuals": (ctypes.c_int, [_P, _P, _P, _I32, _P, _P, _P]),
     "lsa_mm_open": (ctypes.c_int, [ctypes.c_char_p, _PP, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64), ctypes.POINTER(ctypes.c_int)]),
     "lsa_mm_read_csr": (ctypes.c_int, [_P, _P, _P, _P]),
@@ -380,6 +415,13 @@ class CsrMatrix:
         self.ctx.check(self.ctx._lib.lsa_ndlu_prepare(self.ctx.handle, self.handle, LSA_C128 if complex_factors else LSA_F64, int(leaf_size),
                                                       None if flags is None else _ptr(flags)))
 
+    def prepare_lu_tree(self, complex_factors: bool, first, size, parent) -> None:
+        """The same phase with the caller's forest (``lsa_ndlu_prepare_tree``): for a matrix already permuted into the
+        elimination order of :func:`nd_order`, whose forest this is."""
+        first, size, parent = (np.ascontiguousarray(a, dtype=np.int32) for a in (first, size, parent))
+        self.ctx.check(self.ctx._lib.lsa_ndlu_prepare_tree(self.ctx.handle, self.handle, LSA_C128 if complex_factors else LSA_F64, len(parent),
+                                                           _ptr(first), _ptr(size), _ptr(parent)))
+
     def axpby(self, other: "CsrMatrix", alpha: complex, beta: complex, dtype=None) -> "CsrMatrix":
         """alpha*self + beta*other on the shared pattern (MatAXPY, Solver/eigen2.py:110-111)."""
         alpha, beta = complex(alpha), complex(beta)
@@ -507,8 +549,9 @@ class NdAnalysis:
     """Host-only analysis of the nested-dissection multifrontal LU (``lsa_nd_analyse``): ordering, elimination forest
     and the index tables of the device kernels.  Needs no GPU; used by the tests and by sizing tools."""
 
-    def __init__(self, A, leaf_size: int = 0, constraint=None, tree=None, rank: int = 0, nranks: int = 1):
-        """``constraint``: optional boolean mask of the unknowns with a numerically zero diagonal (eliminated after all
+    def __init__(self, A, leaf_size: int = 0, constraint=None, tree=None, rank: int = 0, nranks: int = 1, order_only: bool = False):
+        """``order_only``: the elimination order and the forest without the index tables (``lsa_nd_order``).
+        ``constraint``: optional boolean mask of the unknowns with a numerically zero diagonal (eliminated after all
         their neighbours: the pressure rows of a saddle-point matrix).  ``tree``: instead of dissecting, take the forest
         ``{"first", "size", "parent"[, "owner"]}`` (``lsa_nd_analyse_tree``), localised for ``rank`` of ``nranks``."""
         import scipy.sparse as sp
@@ -524,7 +567,9 @@ class NdAnalysis:
         flags = None if constraint is None else np.ascontiguousarray(constraint, dtype=np.int8)
         if flags is not None and flags.shape != (self.n,):
             raise ValueError("constraint mask must have one entry per row")
-        if tree is None:
+        if tree is None and order_only:
+            rc = self._lib.lsa_nd_order(self.n, _ptr(rp), _ptr(ci), int(leaf_size), None if flags is None else _ptr(flags), ctypes.byref(h))
+        elif tree is None:
             rc = self._lib.lsa_nd_analyse(self.n, _ptr(rp), _ptr(ci), int(leaf_size), None if flags is None else _ptr(flags), ctypes.byref(h))
         else:
             first, size, parent = (np.ascontiguousarray(tree[k], dtype=np.int32) for k in ("first", "size", "parent"))
@@ -575,6 +620,17 @@ class NdAnalysis:
         if getattr(self, "handle", None):
             self._lib.lsa_nd_sym_destroy(self.handle)
             self.handle = None
+
+
+def nd_order(A, leaf_size: int = 0, constraint=None) -> dict:
+    """Elimination order of the nested-dissection LU for the pattern of ``A`` (host only): ``perm`` (new -> old index) and the
+    forest ``first`` / ``size`` / ``parent`` of contiguous index ranges of the permuted matrix ``A[perm][:, perm]``."""
+    an = NdAnalysis(A, leaf_size, constraint=constraint, order_only=True)
+    ex = {"perm": np.empty(an.n, np.int32), "node_start": np.empty(an.ntree + 1, np.int32), "parent": np.empty(an.ntree, np.int32),
+          "level": np.empty(an.ntree, np.int32)}
+    an._lib.lsa_nd_sym_export(an.handle, _ptr(ex["perm"]), _ptr(ex["node_start"]), _ptr(ex["parent"]), _ptr(ex["level"]), None, None)
+    return {"perm": ex["perm"].astype(np.int64), "first": ex["node_start"][:-1].copy(), "size": np.diff(ex["node_start"]).astype(np.int32),
+            "parent": ex["parent"], "level": ex["level"]}
 
 
 class NdLu:
@@ -751,10 +807,73 @@ class KrylovBasis:
                 self.imag_norms = out
         return X
 
+    def solve(self, nev: int, tol: float, max_restarts: int, which: int, transform: int, sigma: complex, *, antishift: complex = 0.0,
+              target: complex | None = None, v0: np.ndarray | None = None, seed: int = 0, max_out: int | None = None, vectors: bool = True):
+        """The whole Krylov-Schur iteration inside the library (``lsa_krylov_solve``: the dense algebra on the projected
+        matrix is the library's own).  ``which``: EPSWhich code (``iEpsWhich.value``); ``transform``: 0 shift-invert,
+        1 shift, 2 Cayley.  Returns a :class:`lsa_hip.krylov_schur.KrylovSchurResult` plus the eigenvalues ``lam``."""
+        from .krylov_schur import KrylovSchurResult
+
+        max_out = self.ncv if max_out is None else int(max_out)
+        target = sigma if target is None else target
+        o = lsa_ks_options(nev=int(nev), max_restarts=int(max_restarts), tol=float(tol), which=int(which), transform=int(transform),
+                           sigma=(_DBL * 2)(complex(sigma).real, complex(sigma).imag), antishift=(_DBL * 2)(complex(antishift).real, complex(antishift).imag),
+                           target=(_DBL * 2)(complex(target).real, complex(target).imag), seed=int(seed), keep_fraction=0.5)
+        theta = np.zeros(max(max_out, 1), dtype=np.complex128)
+        lam = np.zeros(max(max_out, 1), dtype=np.complex128)
+        est = np.zeros(max(max_out, 1), dtype=np.float64)
+        X = np.empty((self.n, max_out), dtype=np.complex128, order="F") if vectors else None
+        res = lsa_ks_result()
+        v = None
+        if v0 is not None:
+            v = np.ascontiguousarray(v0, dtype=np.complex128)
+            if v.shape != (self.n,):
+                raise ValueError(f"start vector must have shape ({self.n},)")
+        mask = None if self._mask is None else np.ascontiguousarray(self._mask, dtype=np.float64)
+        self.ctx.check(self.ctx._lib.lsa_krylov_solve(self.ctx.handle, self.handle, ctypes.byref(o), None if v is None else _ptr(v),
+                                                      None if mask is None else _ptr(mask), max_out, _ptr(theta), _ptr(lam),
+                                                      None if X is None else _ptr(X), _ptr(est), ctypes.byref(res)))
+        k = res.nout
+        self.imag_norms = None
+        if X is not None and k > 0:
+            out = np.zeros(k, dtype=np.float64)
+            if self.ctx._lib.lsa_krylov_imag_norms(self.handle, k, _ptr(out)) == 0:
+                self.imag_norms = out
+        vec = np.zeros((self.n, 0), dtype=np.complex128) if X is None else (X[:, :k] if k == max_out else np.asfortranarray(X[:, :k]))
+        r = KrylovSchurResult(theta[:k].copy(), vec, est[:k].copy(), int(res.nconv), int(res.restarts), int(res.op_applies),
+                              [{"nconv": int(res.nconv), "next_unconverged": float(res.next_unconverged)}])
+        r.lam = lam[:k].copy()
+        return r
+
     def __del__(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self.ctx._lib.lsa_krylov_destroy(self.handle)
             self.handle = None
+
+
+def eigs_sinvert(ctx: Context, A: CsrMatrix, M: CsrMatrix | None, sigma: complex, nev: int, *, ncv: int = 0, tol: float = 1e-10, max_restarts: int = 500,
+                 pc_type: int = 2, ksp_rtol: float = 1e-12, v0: np.ndarray | None = None, row_perm: np.ndarray | None = None):
+    """``lsa_eigs_sinvert``: the eigenpairs of ``A x = lam M x`` nearest ``sigma`` from ONE library call on uploaded matrices
+    (factorisation, Krylov-Schur, Ritz vectors).  Returns ``(lam, X, estimates, result dict, stats dict)``."""
+    n = A.shape[0]
+    nout = int(ncv) if ncv > 0 else max(2 * nev, nev + 15)
+    nout = min(nout, n)
+    opts = lsa_op_options(ilu_levels=2, ilu_shift=0.0, ksp_rtol=float(ksp_rtol), ksp_restart=min(200, max(n, 1)), ksp_maxit=4000, pc_type=int(pc_type),
+                          antishift=(_DBL * 2)(0.0, 0.0))
+    lam = np.zeros(max(nout, 1), dtype=np.complex128)
+    est = np.zeros(max(nout, 1), dtype=np.float64)
+    X = np.empty((n, nout), dtype=np.complex128, order="F")
+    res, st = lsa_ks_result(), lsa_stats()
+    v = None if v0 is None else np.ascontiguousarray(v0, dtype=np.complex128)
+    p = None if row_perm is None else np.ascontiguousarray(row_perm, dtype=np.int32)
+    sg = (_DBL * 2)(complex(sigma).real, complex(sigma).imag)
+    ctx.check(ctx._lib.lsa_eigs_sinvert(ctx.handle, A.handle, None if M is None else M.handle, sg, int(nev), int(ncv), float(tol), int(max_restarts),
+                                        ctypes.byref(opts), None if v is None else _ptr(v), None if p is None else _ptr(p), nout, _ptr(lam), _ptr(X),
+                                        _ptr(est), ctypes.byref(res), ctypes.byref(st)))
+    k = res.nout
+    return (lam[:k].copy(), np.asfortranarray(X[:, :k]), est[:k].copy(),
+            {"nconv": res.nconv, "restarts": res.restarts, "op_applies": res.op_applies, "next_unconverged": res.next_unconverged},
+            {name: getattr(st, name) for name, _ in lsa_stats._fields_})
 
 
 def read_matrix_market(path) -> "scipy.sparse.csr_matrix":  # noqa: F821

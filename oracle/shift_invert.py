@@ -90,3 +90,42 @@ def dense_generalized(A, M=None) -> np.ndarray:
     Md = M.toarray() if sp.issparse(M) else np.asarray(M)
     w = sla.eigvals(Ad, Md)
     return w[np.isfinite(w)]
+
+
+def solve_two_sided(A, M, sigma: complex, k: int = 20, *, tol: float = 0.0, ncv: int | None = None, maxiter: int = 500):
+    """Right AND left eigenpairs nearest ``sigma`` on ONE factorisation, and what they say about each eigenvalue.
+
+    Direct problem as :func:`solve`.  Adjoint problem as the reference states it (``Sensitivity/__init__.py:247-274``):
+    eigenpairs of ``(A^H, M^H)`` nearest ``conj(sigma)`` -- here through ``OP_adj x = C^-H (M^H x)`` on the same SuperLU
+    factors (``trans='H'``) instead of a second factorisation of the transposed matrices.  Pairing by eigenvalue
+    (``lambda_adj = conj(lambda)``), normalisation ``a^H M v = 1`` (``Sensitivity/__init__.py:281-287``).
+
+    Returns a dict: ``lam`` (ARPACK's values, nearest first), ``V``, ``A_left`` (paired, scaled), ``res`` / ``res_left``
+    (relative residuals, ``Solver/eigen2.py:48-56``), ``kappa[i] = ||a_i|| ||M v_i|| / |a_i^H M v_i|`` -- first-order,
+    ``|delta lambda_i| <= ||a_i|| ||r_i|| / |a_i^H M v_i|`` with ``||r_i|| = res_i (||A v_i|| + |lambda_i| ||M v_i||)``,
+    so ``|delta lambda_i| / |lambda_i| <~ 2 kappa_i res_i`` -- and ``lam_rq``, the two-sided Rayleigh quotients
+    ``a^H A v / a^H M v``, whose error is of second order (``~ kappa res res_left``): the refined eigenvalue."""
+    n = A.shape[0]
+    Ac = sp.csr_matrix(A).astype(np.complex128)
+    Mc = sp.identity(n, dtype=np.complex128, format="csr") if M is None else sp.csr_matrix(M).astype(np.complex128)
+    lu = spla.splu((Ac - sigma * Mc).tocsc())
+    MH, AH = Mc.conj().T.tocsr(), Ac.conj().T.tocsr()
+    ncv = min(ncv if ncv is not None else max(4 * k, 40), n - 1)
+    op = spla.LinearOperator((n, n), matvec=lambda x: lu.solve(Mc @ x), dtype=np.complex128)
+    op_adj = spla.LinearOperator((n, n), matvec=lambda x: lu.solve(MH @ x, trans="H"), dtype=np.complex128)
+    mu, W = spla.eigs(op, k=k, which="LM", tol=tol, maxiter=maxiter, ncv=ncv)
+    lam = sigma + 1.0 / mu
+    order = np.argsort(np.abs(lam - sigma), kind="stable")
+    lam, V = lam[order], W[:, order] / np.linalg.norm(W[:, order], axis=0)
+    mu2, W2 = spla.eigs(op_adj, k=k, which="LM", tol=tol, maxiter=maxiter, ncv=ncv)
+    lam_adj = np.conj(sigma) + 1.0 / mu2
+    pick = np.array([int(np.argmin(np.abs(np.conj(lam_adj) - z))) for z in lam])
+    pair_gap = np.abs(np.conj(lam_adj[pick]) - lam) / np.abs(lam)
+    L = W2[:, pick] / np.linalg.norm(W2[:, pick], axis=0)
+    MV, AV = Mc @ V, Ac @ V
+    prod = np.einsum("ij,ij->j", L.conj(), MV)  # a^H M v
+    kappa = np.linalg.norm(L, axis=0) * np.linalg.norm(MV, axis=0) / np.abs(prod)
+    lam_rq = np.einsum("ij,ij->j", L.conj(), AV) / prod
+    return {"lam": lam, "V": V, "A_left": L / np.conj(prod)[np.newaxis, :], "res": compute_residuals(Ac, Mc, lam, V),
+            "res_left": compute_residuals(AH, MH, np.conj(lam), L), "kappa": kappa, "lam_rq": lam_rq, "pair_gap": pair_gap,
+            "distinct_left": len(set(pick.tolist())) == len(pick)}

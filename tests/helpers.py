@@ -71,3 +71,31 @@ def match_nearest(found: np.ndarray, ref: np.ndarray) -> np.ndarray:
     """For every reference eigenvalue the relative distance to the nearest computed one."""
     found = np.asarray(found)
     return np.array([np.min(np.abs(found - r)) / max(abs(r), 1e-300) for r in ref])
+
+
+def eigenvalue_condition_numbers(es, lam: np.ndarray, V: np.ndarray, atol: float = 1e-9) -> np.ndarray:
+    """kappa_i = ||a_i|| ||M v_i|| / |a_i^H M v_i| for computed eigenpairs (lam_i, v_i) of (A, M), on the GPU path.
+
+    The left eigenvector a_i comes the way the reference gets it (``Sensitivity/__init__.py:247-274``): the eigenpair of
+    (A^H, M^H) nearest conj(lam_i) by shift-invert AT conj(lam_i) -- here ``adjoint=True``, the transposed sweeps on the
+    factors of A - lam_i M, one small solve per eigenvalue on one prepared solver (only the target moves).  First-order
+    perturbation theory: a residual r_i = A v_i - lam_i M v_i moves the eigenvalue by a_i^H r_i / (a_i^H M v_i), so two
+    solvers with relative residuals res (``Solver/eigen2.py:48-56``: ||r|| / (||A v|| + |lam| ||M v||) ~ ||r|| / (2 |lam| ||M v||))
+    agree to  |d lam| / |lam| <= 2 kappa_i (res_1 + res_2)  plus second-order terms."""
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=1, atol=atol, ncv=24, max_it=200), check_hermitian=False, adjoint=True)
+    s.solver.set_st_type(iSTType.SINVERT)
+    s.solver.set_st_pc_type(PreconditionerType.LU)
+    MV = es.M @ V
+    kappa = np.full(len(lam), np.inf)
+    for i, z in enumerate(lam):
+        s.solver.set_target(np.conj(z))
+        s.solver.solve()
+        if s.solver.get_num_converged() < 1:
+            continue
+        a = s.solver.get_eigenvector_array(0)
+        kappa[i] = np.linalg.norm(a) * np.linalg.norm(MV[:, i]) / abs(np.vdot(a, MV[:, i]))
+    s.solver.release()
+    return kappa

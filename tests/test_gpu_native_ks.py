@@ -1,0 +1,99 @@
+"""GPU suite: the eigen-solve behind ONE library call (``lsa_eigs_sinvert`` / ``lsa_krylov_solve``: Krylov-Schur with the
+library's own dense algebra) against the golden fixture and against the Python-over-LAPACK loop
+(``lsa_hip/krylov_schur.py``, the test double)."""
+
+import json
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import helpers  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def test_one_call_eigensolve_matches_the_s30k_golden_fixture(hip_ctx):
+    """A consumer of include/lsa_hip.h: lsa_ctx_create -> lsa_csr_upload x 2 -> lsa_eigs_sinvert, nothing else (no ordering, no
+    prepared analysis, no Python loop).  BASELINE config 2 at rtol 1e-8 against the oracle's eigenvalues."""
+    import lsa_hip
+    from oracle import fem, shift_invert
+
+    gold = json.loads((GOLDEN / "cylinder_s30k_k20.json").read_text())
+    es = fem.cylinder_case("S30k")
+    assert es.n == gold["n"] and es.A.nnz == gold["nnz"]
+    sigma = complex(*gold["sigma"])
+    ref = np.array([complex(a, b) for a, b in gold["eigenvalues"]])
+    dA = lsa_hip.CsrMatrix.from_scipy(hip_ctx, es.A)
+    dM = lsa_hip.CsrMatrix.from_scipy(hip_ctx, es.M)
+    lam, X, est, res, st = lsa_hip.eigs_sinvert(hip_ctx, dA, dM, sigma, 20, ncv=80, tol=1e-10)
+    assert res["nconv"] >= 20 and len(lam) >= 20
+    d = helpers.match_nearest(lam, ref[:20])
+    assert d.max() <= 1e-8, d
+    assert np.all(np.diff(np.abs(lam - sigma)) >= -1e-12)  # nearest the target first
+    r = shift_invert.compute_residuals(es.A.astype(complex), es.M.astype(complex), lam[:20], X[:, :20])
+    assert r.max() <= 1e-8 and np.allclose(np.linalg.norm(X, axis=0), 1.0)
+    assert st["gmres_iters"] == 0 and st["pc_fallback"] == 0 and st["op_applies"] == res["op_applies"]
+
+
+@pytest.mark.parametrize("case,k,ncv", [("S5k", 20, 80), ("S2k", 6, 40)])
+def test_library_loop_equals_the_python_loop(monkeypatch, case, k, ncv):
+    """Same start vector, same device kernels; only the dense algebra on the projected matrix differs (in-tree QR algorithm
+    against LAPACK): same eigenvalues to 1e-10, same number of operator applies, eigenvectors equal up to rounding."""
+    from oracle import fem
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    es = fem.cylinder_case(case)
+    out = {}
+    for driver in ("python", "native"):
+        monkeypatch.setenv("LSA_KS_DRIVER", driver)
+        s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=k, atol=1e-10, ncv=ncv), check_hermitian=False)
+        s.solver.set_st_type(iSTType.SINVERT)
+        s.solver.set_st_pc_type(PreconditionerType.LU)
+        s.solver.set_target(fem.SIGMA_RE50)
+        pairs = s.solve()
+        assert len(pairs) == k and s.solver.residuals()[:k].max() <= 1e-8
+        out[driver] = (np.array([p[0] for p in pairs]), np.column_stack([s.solver.get_eigenvector_array(i) for i in range(k)]), s.solver.stats)
+        s.solver.release()
+    (l1, X1, s1), (l2, X2, s2) = out["python"], out["native"]
+    assert np.abs(l1 - l2).max() <= 1e-10 * np.abs(l1).max()
+    assert s1["op_applies"] == s2["op_applies"] and s1["krylov_restarts"] == s2["krylov_restarts"]
+    assert np.abs(np.abs(np.einsum("ij,ij->j", X1.conj(), X2)) - 1.0).max() <= 1e-8
+
+
+def test_which_policies_and_breakdown_through_the_library_loop(hip_ctx):
+    """lsa_krylov_solve on small operators: every EPSWhich code, the plain shift transform, an exact breakdown (invariant
+    subspace reached, fresh direction injected by the library's own generator), fewer pairs than asked for."""
+    import scipy.sparse as sp
+
+    import lsa_hip
+
+    n = 60
+    rng = np.random.default_rng(2)
+    d = np.sort(rng.uniform(1.0, 9.0, n)) + 1j * rng.uniform(-1.0, 1.0, n)
+    A = lsa_hip.CsrMatrix.from_scipy(hip_ctx, sp.diags(d).tocsr())
+    I = lsa_hip.CsrMatrix.from_scipy(hip_ctx, sp.identity(n, format="csr"))
+    sigma = 4.0 + 0.2j
+    op = lsa_hip.ShiftInvertOperator(hip_ctx, A, I, sigma, pc_type=2)
+    kb = lsa_hip.KrylovBasis(hip_ctx, op, 30)
+    op2 = lsa_hip.ShiftInvertOperator(hip_ctx, A, None, 0.0, mode=1, pc_type=0)  # plain shift with sigma = 0: the operator is A
+    kb2 = lsa_hip.KrylovBasis(hip_ctx, op2, 30)
+    # the target policies through shift-invert, the extreme ones (largest / smallest ...) through the untransformed operator
+    want = {7: np.abs(d - sigma), 8: np.abs(d.real - sigma.real), 9: np.abs(d.imag - sigma.imag), 1: -np.abs(d), 3: -d.real, 4: d.real, 5: -d.imag, 6: d.imag}
+    for which, key in want.items():
+        res = kb.solve(4, 1e-10, 200, which, 0, sigma, seed=1) if which >= 7 else kb2.solve(3, 1e-10, 500, which, 1, 0.0, seed=1)
+        assert res.nconv >= 3, which
+        found = np.array([int(np.argmin(np.abs(d - z))) for z in res.lam])
+        assert np.abs(d[found] - res.lam).max() <= 1e-8 and np.all(np.diff(key[found]) >= -1e-9), which  # eigenvalues, in the requested order
+        if which not in (8, 9):  # (one coordinate of the target only: a Krylov space built around sigma need not hold the global optimum)
+            best = d[np.argsort(key, kind="stable")[:3]]
+            assert helpers.match_nearest(res.lam, best).max() <= 1e-8, which
+        X = res.vectors
+        assert np.abs(d[:, None] * X - X * res.lam[None, :]).max() <= 1e-7
+    # invariant subspace of dimension 3: breakdown, continued with fresh directions; every returned pair is exact
+    v = np.zeros(n, dtype=np.complex128)
+    v[[4, 9, 20]] = 1.0
+    res = kb.solve(3, 1e-12, 50, 7, 0, sigma, v0=v)
+    assert res.nconv >= 3 and helpers.match_nearest(d, res.lam).max() <= 1e-10  # every returned value is an eigenvalue

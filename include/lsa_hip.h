@@ -333,6 +333,9 @@ typedef struct {
     int32_t pad;
     int64_t op_applies;
     double next_unconverged; /* relative residual estimate of the first pair that missed the tolerance                 */
+    double seconds_expand;   /* wall time inside the Arnoldi expansions (device work + waiting for it)                 */
+    double seconds_dense;    /* ... in the host's dense algebra on the projected matrix (Schur forms, reordering)      */
+    double seconds_restart;  /* ... in the basis updates V <- V Q and the final Ritz vectors                           */
 } lsa_ks_result;
 /* n and ncv of a basis */
 int lsa_krylov_shape(const lsa_krylov *k, int64_t *n, int32_t *ncv);

@@ -631,6 +631,8 @@ class iEpsSolver:
                 X[perm, :] = vecs
             self._stats = op.stats()
             self._stats["krylov_restarts"] = res.restarts
+            if res.history and "seconds_dense" in res.history[-1]:  # the library's loop times its phases
+                self._stats.update({k: res.history[-1][k] for k in ("seconds_expand", "seconds_dense", "seconds_restart")})
             if part is not None:
                 now = ctx.comm_stats()
                 last = getattr(self, "_comm_seen", {"allgather_calls": 0, "allgather_bytes_received": 0})

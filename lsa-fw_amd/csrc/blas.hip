@@ -222,14 +222,41 @@ __global__ void hess_column_kernel(int cnt, const T* __restrict__ h1, const T* _
 constexpr int kFuseChunks = 64;
 constexpr int kFuseCols = 128;  // two threads per column in the prologue of cgs_axpy
 
+// sum over the wavefront by DPP moves (two 32-bit halves per double) inside rows of 16 lanes and readlane across the four rows:
+// a __shfl_xor butterfly is a chain of six ~100-cycle ds_bpermute steps per scalar, and the reductions below sum 16 scalars
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)bits & 0xFFFFFFFFull), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)bits >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_mov_f64<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov_f64<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov_f64<0x141>(v);  // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);  // row_mirror: every lane of a row of 16 holds the row's sum
+    const long long bits = __double_as_longlong(v);
+    const int lo = (int)(unsigned)((unsigned long long)bits & 0xFFFFFFFFull), hi = (int)(unsigned)((unsigned long long)bits >> 32);
+    double tot = 0.0;
+#pragma unroll
+    for (int row = 0; row < 4; ++row) {
+        const unsigned l = (unsigned)__builtin_amdgcn_readlane(lo, 16 * row), h = (unsigned)__builtin_amdgcn_readlane(hi, 16 * row);
+        tot += __longlong_as_double((long long)(((unsigned long long)h << 32) | l));
+    }
+    return tot;
+}
+__device__ __forceinline__ cplx wave_sum_dpp(cplx v) { return cplx{wave_sum_dpp(v.re), wave_sum_dpp(v.im)}; }
+
 template <typename T>
 __global__ __launch_bounds__(kThreads) void cgs_dot_kernel(int64_t n, int j, int64_t rows_per_block, const T* __restrict__ V, int64_t ldv,
                                                            const T* __restrict__ w, T* __restrict__ part, int ldp,
                                                            const T* __restrict__ chk_b, const T* __restrict__ chk_z, double* __restrict__ chk_part) {
-    __shared__ T smem[4];
-    __shared__ double dsm[4];
+    __shared__ T wsum[4][kColTile];
+    __shared__ double dsm[4][2];
     const int chunk = blockIdx.x;
     const int c0 = blockIdx.y * kColTile;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t r0 = (int64_t)chunk * rows_per_block;
     const int64_t r1 = (r0 + rows_per_block < n) ? r0 + rows_per_block : n;
     T acc[kColTile];
@@ -250,34 +277,47 @@ __global__ __launch_bounds__(kThreads) void cgs_dot_kernel(int64_t n, int j, int
                 if (c < nc) fma_conj_acc(acc[c], V[i + (int64_t)(c0 + c) * ldv], wv);
         }
     }
+    // one barrier for all columns: wave sums by DPP, the four wave sums through LDS, added in wave order
 #pragma unroll
     for (int c = 0; c < kColTile; ++c) {
-        T s = block_sum<T>(acc[c], smem);
-        if (threadIdx.x == 0 && c < nc) part[(int64_t)chunk * ldp + c0 + c] = s;
+        const T s = wave_sum_dpp(acc[c]);
+        if (lane == 0) wsum[wave][c] = s;
     }
-    if (chk_part && blockIdx.y == 0) {
-        double rw = 0.0, rb = 0.0;
+    double rw = 0.0, rb = 0.0;
+    const bool chk = chk_part != nullptr && blockIdx.y == 0;
+    if (chk) {
         for (int64_t i = r0 + threadIdx.x; i < r1; i += kThreads) {
             const T bi = chk_b[i];
             rw += s_abs2(s_sub(bi, chk_z[i]));
             rb += s_abs2(bi);
         }
-        const double sw = block_sum<double>(rw, dsm);
-        __syncthreads();
-        const double sb = block_sum<double>(rb, dsm);
-        if (threadIdx.x == 0) {
-            chk_part[2 * chunk] = sw;
-            chk_part[2 * chunk + 1] = sb;
+        rw = wave_sum_dpp(rw);
+        rb = wave_sum_dpp(rb);
+        if (lane == 0) {
+            dsm[wave][0] = rw;
+            dsm[wave][1] = rb;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < nc) {
+        const int c = threadIdx.x;
+        part[(int64_t)chunk * ldp + c0 + c] = s_add(s_add(wsum[0][c], wsum[1][c]), s_add(wsum[2][c], wsum[3][c]));
+    }
+    if (chk && threadIdx.x >= 64 && threadIdx.x < 66) {
+        const int q = threadIdx.x - 64;
+        chk_part[2 * chunk + q] = (dsm[0][q] + dsm[1][q]) + (dsm[2][q] + dsm[3][q]);
     }
 }
 
+// w -= V h.  Workgroup = 64 rows; four lanes share a row (lane q of the four takes the columns c = q mod 4) so that a thread
+// keeps a quarter of the row's loads in flight at once: with a thread per row the j loads of a row are a chain of j / 4
+// dependent batches (17.8 us per launch at 30 k rows and j = 60, on half of the CUs).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void cgs_axpy_kernel(int64_t n, int j, const T* __restrict__ V, int64_t ldv, const T* __restrict__ part,
                                                             int nchunks, int ldp, T* __restrict__ w, T* __restrict__ h_out,
                                                             double* __restrict__ nrm_part, const double* __restrict__ chk_part,
                                                             double* __restrict__ chk_out) {
-    __shared__ double smem[4];
+    __shared__ double wn[4];
     __shared__ T hs[kFuseCols];
     {
         // h[c] = sum over the chunks, in chunk order inside each of two interleaved halves, then half 0 + half 1
@@ -300,27 +340,46 @@ __global__ __launch_bounds__(kThreads) void cgs_axpy_kernel(int64_t n, int j, co
         }
     }
     __syncthreads();
-    double nrm = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        T acc = scalar_traits<T>::zero();
-        int c = 0;
-        for (; c + 4 <= j; c += 4) {
-            const T v0 = V[i + (int64_t)c * ldv], v1 = V[i + (int64_t)(c + 1) * ldv];
-            const T v2 = V[i + (int64_t)(c + 2) * ldv], v3 = V[i + (int64_t)(c + 3) * ldv];
-            fma_acc(acc, hs[c], v0);
-            fma_acc(acc, hs[c + 1], v1);
-            fma_acc(acc, hs[c + 2], v2);
-            fma_acc(acc, hs[c + 3], v3);
+    // thread -> (row, column class): 16 consecutive lanes are 16 consecutive rows (one 256-byte segment per column), the four
+    // groups of 16 lanes of a wave are the four column classes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
+    T acc = scalar_traits<T>::zero();
+    if (i < n) {
+        int c = q;
+        for (; c + 28 < j; c += 32) {  // eight loads in flight
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = V[i + (int64_t)(c + 4 * u) * ldv];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fma_acc(acc, hs[c + 4 * u], v[u]);
         }
-        for (; c < j; ++c) fma_acc(acc, hs[c], V[i + (int64_t)c * ldv]);
-        const T r = s_sub(w[i], acc);
+        for (; c < j; c += 4) fma_acc(acc, hs[c], V[i + (int64_t)c * ldv]);
+    }
+    // the four partial sums of a row sit 16 lanes apart: bring them together in class order (fixed order of additions)
+    T a1, a2, a3;
+    if constexpr (sizeof(T) == 16) {
+        a1 = cplx{__shfl(acc.re, (lane & 15) + 16), __shfl(acc.im, (lane & 15) + 16)};
+        a2 = cplx{__shfl(acc.re, (lane & 15) + 32), __shfl(acc.im, (lane & 15) + 32)};
+        a3 = cplx{__shfl(acc.re, (lane & 15) + 48), __shfl(acc.im, (lane & 15) + 48)};
+    } else {
+        a1 = __shfl(acc, (lane & 15) + 16);
+        a2 = __shfl(acc, (lane & 15) + 32);
+        a3 = __shfl(acc, (lane & 15) + 48);
+    }
+    double nrm = 0.0;
+    if (q == 0 && i < n) {
+        const T tot = s_add(s_add(acc, a1), s_add(a2, a3));
+        const T r = s_sub(w[i], tot);
         w[i] = r;
-        nrm += s_abs2(r);
+        nrm = s_abs2(r);
     }
     if (nrm_part) {
-        double s = block_sum<double>(nrm, smem);
-        if (threadIdx.x == 0) nrm_part[blockIdx.x] = s;
+        nrm = wave_sum_dpp(nrm);
+        if (lane == 0) wn[wave] = nrm;
+        __syncthreads();
+        if (threadIdx.x == 0) nrm_part[blockIdx.x] = (wn[0] + wn[1]) + (wn[2] + wn[3]);
     }
 }
 
@@ -687,7 +746,9 @@ int k_basis_gemm(lsa_ctx* ctx, int dtype, int64_t n, int m, int k, const void* V
 // k_cgs2_fused_work_bytes(ctx, n, j) bytes.  Returns 1 when the shape is outside what the fused form handles (nothing was
 // launched: the caller takes the kernel-per-stage path), LSA_OK or a negative status otherwise.
 size_t k_cgs2_fused_work_bytes(lsa_ctx* ctx, int64_t n, int jmax) {
-    return (size_t)16 * (size_t)(2 * kFuseChunks * kFuseCols + 2 * kFuseCols) + sizeof(double) * (size_t)(2 * kFuseChunks + stream_blocks(ctx, n) + 8) + (size_t)jmax * 0;
+    (void)ctx;
+    (void)jmax;
+    return (size_t)16 * (size_t)(2 * kFuseChunks * kFuseCols + 2 * kFuseCols) + sizeof(double) * (size_t)(2 * kFuseChunks + (n + 63) / 64 + 8);
 }
 
 int k_cgs2_fused(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, void* w, void* vnext, void* hcol_dev, void* work,
@@ -695,10 +756,10 @@ int k_cgs2_fused(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64
     if (j <= 0 || j > kFuseCols || n <= 0) return 1;
     int64_t rpb = (n + kFuseChunks - 1) / kFuseChunks;
     rpb = ((rpb + kThreads - 1) / kThreads) * kThreads;
-    if (rpb < 512) rpb = 512;
-    if (rpb > 2048) return 1;  // long vectors: the second stages are noise there, and wider grids stream better
+    if (rpb < 1024) rpb = 1024;  // (every workgroup of the axpy sums the partials of all chunks: few, fat chunks)
+    if (rpb > 4096) return 1;    // long vectors: the second stages are noise there, and wider grids stream better
     const int nchunks = (int)((n + rpb - 1) / rpb);
-    const int blocks = stream_blocks(ctx, n);
+    const int blocks = (int)((n + 63) / 64);  // workgroups of the axpy: 64 rows each
     const size_t esz = dtype == LSA_C128 ? 16 : 8;
     char* p = (char*)work;
     void* part1 = p;
@@ -721,7 +782,7 @@ int k_cgs2_fused(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64
                            (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
         hipLaunchKernelGGL((cgs_axpy_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, j, (const T*)V, ldv, (const T*)part2, nchunks, kFuseCols,
                            (T*)w, (T*)h2, nrm_part, (const double*)nullptr, (double*)nullptr);
-        hipLaunchKernelGGL((cgs_scale_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, (const T*)w, (const double*)nrm_part, blocks, (T*)vnext,
+        hipLaunchKernelGGL((cgs_scale_kernel<T>), dim3(stream_blocks(ctx, n)), dim3(kThreads), 0, ctx->stream, n, (const T*)w, (const double*)nrm_part, blocks, (T*)vnext,
                            j, (const T*)h1, (const T*)h2, (T*)hcol_dev);
     });
     return check_launch(ctx, "cgs2_fused");

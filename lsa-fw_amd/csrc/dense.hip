@@ -13,6 +13,7 @@
 //   krylov_schur       Stewart's Krylov-Schur restart: expand to ncv vectors, Schur form with the wanted Ritz values first,
 //                      residual estimates |b^H y|, relative convergence test (EPS_CONV_REL), truncate to nconv + (m - nconv)/2
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -105,117 +106,225 @@ inline void rot_cols(const Mat& A, int p, int q, int i0, int i1, double c, Z s) 
     }
 }
 
-// A <- P^H A P (upper Hessenberg on return), Q <- Q P;  Q must hold a unitary matrix on entry (the identity, or a basis to carry along)
+// A <- P^H A P (upper Hessenberg on return), Q <- Q P;  Q must hold a unitary matrix on entry (the identity, or a basis to carry along).
+// Row-oriented, from the bottom: row r keeps only its entry in column r - 1 of those left of the diagonal, by a Householder
+// reflector on the coordinates 0 .. r - 1.  Rows that conform already cost nothing, so the matrix of a Krylov-Schur restart
+// (triangle of k rows, one full row, Hessenberg below) costs the reduction of a k x k matrix, not of the whole.
 void hessenberg_reduce(int n, const Mat& A, const Mat& Q) {
     std::vector<Z> v((size_t)n), w((size_t)n);
-    for (int k = 0; k + 2 < n; ++k) {
+    for (int r = n - 1; r >= 2; --r) {
+        // x = A[r, 0:r]: wanted x^T P = gamma e_{r-1}^T with P = I - tp v v^H on the coordinates 0 .. r - 1
         double xnorm2 = 0.0;
-        for (int i = k + 2; i < n; ++i) xnorm2 += abs2(A(i, k));
-        const Z alpha = A(k + 1, k);
-        if (xnorm2 == 0.0 && alpha.im == 0.0) continue;
+        for (int j = 0; j < r - 1; ++j) xnorm2 += abs2(A(r, j));
+        if (xnorm2 == 0.0) continue;
+        const Z alpha = A(r, r - 1);
         const double nrm = std::sqrt(abs2(alpha) + xnorm2);
         const double beta = alpha.re >= 0.0 ? -nrm : nrm;
+        // LAPACK's zlarfg on (alpha; x): G^H (alpha; x) = beta e, G = I - tau u u^H, u = (1; x / (alpha - beta)).  Here P^T = G^H,
+        // i.e. v = conj(u) and tp = conj(tau).
         const Z tau = {(beta - alpha.re) / beta, -alpha.im / beta};
         const Z scale = zdiv({1.0, 0.0}, alpha - Z{beta, 0.0});
-        v[(size_t)k + 1] = {1.0, 0.0};
-        for (int i = k + 2; i < n; ++i) v[(size_t)i] = scale * A(i, k);
-        A(k + 1, k) = {beta, 0.0};
-        for (int i = k + 2; i < n; ++i) A(i, k) = {0.0, 0.0};
-        // left: A[k+1:, k+1:] -= conj(tau) v (v^H A)
-        const Z ctau = conj(tau);
-        for (int j = k + 1; j < n; ++j) {
-            Z d = {0.0, 0.0};
-            for (int i = k + 1; i < n; ++i) d = d + conj(v[(size_t)i]) * A(i, j);
-            d = ctau * d;
-            for (int i = k + 1; i < n; ++i) A(i, j) = A(i, j) - v[(size_t)i] * d;
-        }
-        // right: A[:, k+1:] -= tau (A v) v^H ;  Q[:, k+1:] -= tau (Q v) v^H
-        for (const Mat* B : {&A, &Q}) {
-            for (int i = 0; i < n; ++i) w[(size_t)i] = {0.0, 0.0};
-            for (int j = k + 1; j < n; ++j) {
+        const Z tp = conj(tau);
+        v[(size_t)r - 1] = {1.0, 0.0};
+        for (int j = 0; j < r - 1; ++j) v[(size_t)j] = conj(scale * A(r, j));
+        // right: B[0:r+1, 0:r] -= tp (B v) v^H  (rows below r have no entries in these columns), and Q[:, 0:r] likewise
+        for (int pass = 0; pass < 2; ++pass) {
+            const Mat& B = pass == 0 ? A : Q;
+            const int rows = pass == 0 ? r + 1 : n;
+            for (int i = 0; i < rows; ++i) w[(size_t)i] = {0.0, 0.0};
+            for (int j = 0; j < r; ++j) {
                 const Z vj = v[(size_t)j];
-                const Z* col = &(*B)(0, j);
-                for (int i = 0; i < n; ++i) w[(size_t)i] = w[(size_t)i] + col[i] * vj;
+                const Z* col = &B(0, j);
+                for (int i = 0; i < rows; ++i) w[(size_t)i] = w[(size_t)i] + col[i] * vj;
             }
-            for (int j = k + 1; j < n; ++j) {
-                const Z f = tau * conj(v[(size_t)j]);
-                Z* col = &(*B)(0, j);
-                for (int i = 0; i < n; ++i) col[i] = col[i] - w[(size_t)i] * f;
+            for (int j = 0; j < r; ++j) {
+                const Z f = tp * conj(v[(size_t)j]);
+                Z* col = &B(0, j);
+                for (int i = 0; i < rows; ++i) col[i] = col[i] - w[(size_t)i] * f;
             }
+        }
+        A(r, r - 1) = {beta, 0.0};
+        for (int j = 0; j < r - 1; ++j) A(r, j) = {0.0, 0.0};
+        // left: A[0:r, :] -= conj(tp) v (v^H A[0:r, :])
+        const Z ctp = conj(tp);
+        for (int j = 0; j < n; ++j) {
+            Z d = {0.0, 0.0};
+            Z* col = &A(0, j);
+            for (int i = 0; i < r; ++i) d = d + conj(v[(size_t)i]) * col[i];
+            d = ctp * d;
+            for (int i = 0; i < r; ++i) col[i] = col[i] - v[(size_t)i] * d;
         }
     }
+}
+
+// [x; y] <- R [x; y] element-wise on split (real / imaginary) contiguous arrays: the inner loops of the QR sweeps.
+// R = [c s; -conj(s) c].  Two builds of the same body: the portable one and one for AVX2 + FMA hosts, picked at run time.
+#define LSA_ROT_BODY                                                     \
+    for (int j = 0; j < len; ++j) {                                      \
+        const double ar = xr[j], ai = xi[j], br = yr[j], bi = yi[j];     \
+        xr[j] = c * ar + (sr * br - si * bi);                            \
+        xi[j] = c * ai + (sr * bi + si * br);                            \
+        yr[j] = c * br - (sr * ar + si * ai);                            \
+        yi[j] = c * bi - (sr * ai - si * ar);                            \
+    }
+void rot_pair_generic(int len, double* __restrict__ xr, double* __restrict__ xi, double* __restrict__ yr, double* __restrict__ yi, double c, double sr,
+                      double si) {
+    LSA_ROT_BODY
+}
+#if !defined(__HIP_DEVICE_COMPILE__)  // (this file is host code; the device pass of the compiler knows neither the target nor the builtins)
+__attribute__((target("avx2,fma"))) void rot_pair_avx2(int len, double* __restrict__ xr, double* __restrict__ xi, double* __restrict__ yr,
+                                                       double* __restrict__ yi, double c, double sr, double si) {
+    LSA_ROT_BODY
+}
+#endif
+#undef LSA_ROT_BODY
+typedef void (*rot_pair_fn)(int, double*, double*, double*, double*, double, double, double);
+rot_pair_fn pick_rot_pair() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_cpu_init();
+    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) return rot_pair_avx2;
+#endif
+    return rot_pair_generic;
 }
 
 // Schur form of an upper Hessenberg H (in place: upper triangular T on return), Q <- Q U with H = U T U^H.
 // Single-shift QR with Wilkinson shifts and the standard small-subdiagonal deflation test; returns false if an eigenvalue
 // fails to converge in 30 sweeps per eigenvalue (does not happen for the Rayleigh quotients of an Arnoldi process).
+//
+// Work layout (80 x 80 is 2.9 ms with complex scalars in column-major storage, four times per 30 k-unknown eigen-solve, the GPU
+// idle meanwhile): H is kept ROW-major and Q column-major, both split into real and imaginary planes, so that the two long
+// updates of every rotation -- rows k, k + 1 of H to the right of the bulge, columns k, k + 1 of Q -- are contiguous real
+// loops the compiler vectorises.  The column update of H inside the active window (a few rows around the bulge) stays
+// strided; its part ABOVE the window (rows that only collect the sweep's rotations) is applied after the sweep, row by row,
+// four rows at a time.
 bool hessenberg_qr(int n, const Mat& H, const Mat& Q) {
+    static const rot_pair_fn rot_pair = pick_rot_pair();
     const double ulp = 2.220446049250313e-16, smlnum = 2.2250738585072014e-308 * (n / ulp);
+    const int ld = (n + 3) & ~3;
+    std::vector<double> store((size_t)4 * ld * std::max(n, 1));
+    double* hr = store.data();            // hr[i * ld + j] = Re H(i, j)
+    double* hi = hr + (size_t)ld * n;
+    double* qr = hi + (size_t)ld * n;     // qr[j * ld + i] = Re Q(i, j)
+    double* qi = qr + (size_t)ld * n;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            hr[(size_t)i * ld + j] = H(i, j).re;
+            hi[(size_t)i * ld + j] = H(i, j).im;
+            qr[(size_t)j * ld + i] = Q(i, j).re;
+            qi[(size_t)j * ld + i] = Q(i, j).im;
+        }
+    auto h = [&](int i, int j) { return Z{hr[(size_t)i * ld + j], hi[(size_t)i * ld + j]}; };
+    auto seth = [&](int i, int j, Z v) {
+        hr[(size_t)i * ld + j] = v.re;
+        hi[(size_t)i * ld + j] = v.im;
+    };
+    std::vector<double> rc((size_t)n), rsr((size_t)n), rsi((size_t)n);  // the rotations of the current sweep
     int ihi = n - 1;
     int its = 0, total = 0;
+    bool ok = true;
     while (ihi >= 0) {
         int l = ihi;
         for (; l > 0; --l) {
-            const double sub = abs1(H(l, l - 1));
+            const double sub = abs1(h(l, l - 1));
             if (sub <= smlnum) break;
-            double tst = abs1(H(l - 1, l - 1)) + abs1(H(l, l));
+            double tst = abs1(h(l - 1, l - 1)) + abs1(h(l, l));
             if (tst == 0.0) {
-                if (l - 2 >= 0) tst += std::fabs(H(l - 1, l - 2).re);
-                if (l + 1 <= ihi) tst += std::fabs(H(l + 1, l).re);
+                if (l - 2 >= 0) tst += std::fabs(h(l - 1, l - 2).re);
+                if (l + 1 <= ihi) tst += std::fabs(h(l + 1, l).re);
             }
             if (sub <= ulp * tst) {
                 // (Ahues & Tisseur) a small subdiagonal next to diagonal entries of very different size
-                const double ab = std::max(abs1(H(l, l - 1)), abs1(H(l - 1, l))), ba = std::min(abs1(H(l, l - 1)), abs1(H(l - 1, l)));
-                const double aa = std::max(abs1(H(l, l)), abs1(H(l - 1, l - 1) - H(l, l))), bb = std::min(abs1(H(l, l)), abs1(H(l - 1, l - 1) - H(l, l)));
+                const double ab = std::max(abs1(h(l, l - 1)), abs1(h(l - 1, l))), ba = std::min(abs1(h(l, l - 1)), abs1(h(l - 1, l)));
+                const Z dd = h(l - 1, l - 1) - h(l, l);
+                const double aa = std::max(abs1(h(l, l)), abs1(dd)), bb = std::min(abs1(h(l, l)), abs1(dd));
                 const double s = aa + ab;
                 if (ba * (ab / s) <= std::max(smlnum, ulp * (bb * (aa / s)))) break;
             }
         }
-        if (l > 0) H(l, l - 1) = {0.0, 0.0};
+        if (l > 0) seth(l, l - 1, {0.0, 0.0});
         if (l == ihi) {  // one eigenvalue has split off
             --ihi;
             its = 0;
             continue;
         }
-        if (++its > 30 || ++total > 30 * n + 300) return false;
+        if (++its > 30 || ++total > 30 * n + 300) {
+            ok = false;
+            break;
+        }
         Z shift;
         if (its == 10) {
-            shift = H(l, l) + Z{0.75 * std::fabs(H(l + 1, l).re), 0.0};
+            shift = h(l, l) + Z{0.75 * std::fabs(h(l + 1, l).re), 0.0};
         } else if (its == 20) {
-            shift = H(ihi, ihi) + Z{0.75 * std::fabs(H(ihi, ihi - 1).re), 0.0};
+            shift = h(ihi, ihi) + Z{0.75 * std::fabs(h(ihi, ihi - 1).re), 0.0};
         } else {
             // the eigenvalue of the trailing 2 x 2 block nearer to its last diagonal entry
-            shift = H(ihi, ihi);
-            const Z u2 = H(ihi - 1, ihi) * H(ihi, ihi - 1);
+            shift = h(ihi, ihi);
+            const Z u2 = h(ihi - 1, ihi) * h(ihi, ihi - 1);
             if (abs1(u2) != 0.0) {
-                const Z x = 0.5 * (H(ihi - 1, ihi - 1) - shift);
+                const Z x = 0.5 * (h(ihi - 1, ihi - 1) - shift);
                 const Z y = zsqrt(x * x + u2);
-                Z d = x.re * y.re + x.im * y.im < 0.0 ? x - y : x + y;  // the larger of x +- y
+                const Z d = x.re * y.re + x.im * y.im < 0.0 ? x - y : x + y;  // the larger of x +- y
                 shift = shift - zdiv(u2, d);
             }
         }
         // one implicit single-shift sweep over rows l .. ihi
-        Z x = H(l, l) - shift, y = H(l + 1, l);
+        Z x = h(l, l) - shift, y = h(l + 1, l);
         for (int k = l; k < ihi; ++k) {
             double c;
             Z s, r;
             givens(x, y, c, s, r);
+            rc[(size_t)k] = c;
+            rsr[(size_t)k] = s.re;
+            rsi[(size_t)k] = s.im;
             if (k > l) {
-                H(k, k - 1) = r;
-                H(k + 1, k - 1) = {0.0, 0.0};
+                seth(k, k - 1, r);
+                seth(k + 1, k - 1, {0.0, 0.0});
             }
-            rot_rows(H, k, k + 1, k, n, c, s);
-            rot_cols(H, k, k + 1, 0, std::min(k + 3, ihi + 1), c, s);
-            rot_cols(Q, k, k + 1, 0, n, c, s);
+            // rows k, k + 1 <- R rows, columns k .. n - 1 (contiguous)
+            rot_pair(n - k, hr + (size_t)k * ld + k, hi + (size_t)k * ld + k, hr + (size_t)(k + 1) * ld + k, hi + (size_t)(k + 1) * ld + k, c, s.re, s.im);
+            // columns k, k + 1 <- columns R^H, rows l .. min(k + 2, ihi) (the window; strided).  With R^H = [c -s; conj(s) c]:
+            // new_k = c a + conj(s) b,  new_k1 = c b - s a
+            const int i1 = std::min(k + 2, ihi);
+            for (int i = l; i <= i1; ++i) {
+                double* pr = hr + (size_t)i * ld + k;
+                double* pi = hi + (size_t)i * ld + k;
+                const double ar = pr[0], ai = pi[0], br = pr[1], bi = pi[1];
+                pr[0] = c * ar + (s.re * br + s.im * bi);
+                pi[0] = c * ai + (s.re * bi - s.im * br);
+                pr[1] = c * br - (s.re * ar - s.im * ai);
+                pi[1] = c * bi - (s.re * ai + s.im * ar);
+            }
+            // columns k, k + 1 of Q <- columns R^H (contiguous): in the form of rot_pair, [x; y] <- [c conj(s); -s c] [x; y],
+            // i.e. the rotation with s replaced by conj(s)
+            rot_pair(n, qr + (size_t)k * ld, qi + (size_t)k * ld, qr + (size_t)(k + 1) * ld, qi + (size_t)(k + 1) * ld, c, s.re, -s.im);
             if (k + 1 < ihi) {
-                x = H(k + 1, k);
-                y = H(k + 2, k);
+                x = h(k + 1, k);
+                y = h(k + 2, k);
+            }
+        }
+        // the rows above the window collect the sweep's column rotations, one row after the other (four rows interleaved)
+        for (int i0 = 0; i0 < l; i0 += 4) {
+            const int ni = std::min(4, l - i0);
+            for (int k = l; k < ihi; ++k) {
+                const double c = rc[(size_t)k], sr = rsr[(size_t)k], si = rsi[(size_t)k];
+                for (int u = 0; u < ni; ++u) {
+                    double* pr = hr + (size_t)(i0 + u) * ld + k;
+                    double* pi = hi + (size_t)(i0 + u) * ld + k;
+                    const double ar = pr[0], ai = pi[0], br = pr[1], bi = pi[1];
+                    pr[0] = c * ar + (sr * br + si * bi);
+                    pi[0] = c * ai + (sr * bi - si * br);
+                    pr[1] = c * br - (sr * ar - si * ai);
+                    pi[1] = c * bi - (sr * ai + si * ar);
+                }
             }
         }
     }
     for (int j = 0; j < n; ++j)
-        for (int i = j + 1; i < n; ++i) H(i, j) = {0.0, 0.0};
-    return true;
+        for (int i = 0; i < n; ++i) {
+            H(i, j) = (ok && i > j) ? Z{0.0, 0.0} : Z{hr[(size_t)i * ld + j], hi[(size_t)i * ld + j]};
+            Q(i, j) = {qr[(size_t)j * ld + i], qi[(size_t)j * ld + i]};
+        }
+    return ok;
 }
 
 // T, Q: Schur form.  Swaps the diagonal entries k and k + 1 by one rotation (LAPACK's ztrexc step).
@@ -319,6 +428,8 @@ struct Selector {
     }
 };
 
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct Rng {  // splitmix64 + Box-Muller: start vectors and the fresh directions after a breakdown
     uint64_t s;
     uint64_t next() {
@@ -359,7 +470,7 @@ int lsa_dense_tri_eigenvectors(int32_t n, const void* T, int32_t ldt, void* S, i
     return LSA_OK;
 }
 
-static_assert(sizeof(lsa_ks_options) == 88, "lsa_ks_options layout is part of the C-ABI (tests/test_abi.py)");
+static_assert(sizeof(lsa_ks_result) == 56 && sizeof(lsa_ks_options) == 88, "lsa_ks_options layout is part of the C-ABI (tests/test_abi.py)");
 
 int lsa_krylov_solve(lsa_ctx* ctx, lsa_krylov* k, const lsa_ks_options* o, const void* v0, const double* mask, int32_t max_out, void* theta_out,
                      void* lambda_out, void* X_out, double* est_out, lsa_ks_result* result) {
@@ -399,8 +510,10 @@ int lsa_krylov_solve(lsa_ctx* ctx, lsa_krylov* k, const lsa_ks_options* o, const
     int kept = 0, restarts = 0;
     int64_t applies = 0;
     memset(result, 0, sizeof *result);
+    double t_expand = 0.0, t_dense = 0.0, t_restart = 0.0;
     while (true) {
         // ---- expand to m vectors; continue past exact breakdowns (invariant subspace) with a fresh direction ----
+        double t0 = now_s();
         int j = kept;
         while (j < m) {
             int32_t bd = -1;
@@ -416,6 +529,8 @@ int lsa_krylov_solve(lsa_ctx* ctx, lsa_krylov* k, const lsa_ks_options* o, const
             LSA_CHECK(lsa_krylov_inject(ctx, k, bd + 1, vec.data()));
             j = bd + 1;
         }
+        t_expand += now_s() - t0;
+        t0 = now_s();
         for (int c = 0; c < m; ++c) {
             b[(size_t)c] = Hm(m, c);  // b^H: the row under the square part
             for (int r = 0; r < m; ++r) Tm(r, c) = Hm(r, c);
@@ -455,8 +570,16 @@ int lsa_krylov_solve(lsa_ctx* ctx, lsa_krylov* k, const lsa_ks_options* o, const
                     ((Z*)lambda_out)[c] = sel.back(w[(size_t)src]);
                     if (est_out) est_out[c] = rel[(size_t)src];
                 }
+                t_dense += now_s() - t0;
+                t0 = now_s();
                 if (X_out) LSA_CHECK(lsa_krylov_ritz_vectors(ctx, k, m, nout, Y.data(), m, 3, X_out));
+                t_restart += now_s() - t0;
+                t0 = now_s();
             }
+            t_dense += now_s() - t0;
+            result->seconds_expand = t_expand;
+            result->seconds_dense = t_dense;
+            result->seconds_restart = t_restart;
             result->nconv = nconv;
             result->nout = nout;
             result->restarts = restarts;
@@ -476,7 +599,10 @@ int lsa_krylov_solve(lsa_ctx* ctx, lsa_krylov* k, const lsa_ks_options* o, const
             const int sdim = schur_reorder(m, Tm, Qm, select);
             knew = std::max(std::min(sdim, m - 1), 1);
         }
+        t_dense += now_s() - t0;
+        t0 = now_s();
         LSA_CHECK(lsa_krylov_restart(ctx, k, m, knew, Q.data(), m));
+        t_restart += now_s() - t0;
         std::fill(H.begin(), H.end(), Z{0.0, 0.0});
         for (int c = 0; c < knew; ++c) {
             for (int r = 0; r <= c; ++r) Hm(r, c) = Tm(r, c);

@@ -90,6 +90,9 @@ class lsa_ks_result(ctypes.Structure):
         ("pad", ctypes.c_int32),
         ("op_applies", ctypes.c_int64),
         ("next_unconverged", ctypes.c_double),
+        ("seconds_expand", ctypes.c_double),
+        ("seconds_dense", ctypes.c_double),
+        ("seconds_restart", ctypes.c_double),
     ]
 
 
@@ -841,7 +844,8 @@ class KrylovBasis:
                 self.imag_norms = out
         vec = np.zeros((self.n, 0), dtype=np.complex128) if X is None else (X[:, :k] if k == max_out else np.asfortranarray(X[:, :k]))
         r = KrylovSchurResult(theta[:k].copy(), vec, est[:k].copy(), int(res.nconv), int(res.restarts), int(res.op_applies),
-                              [{"nconv": int(res.nconv), "next_unconverged": float(res.next_unconverged)}])
+                              [{"nconv": int(res.nconv), "next_unconverged": float(res.next_unconverged), "seconds_expand": res.seconds_expand,
+                                "seconds_dense": res.seconds_dense, "seconds_restart": res.seconds_restart}])
         r.lam = lam[:k].copy()
         return r
 
@@ -872,7 +876,8 @@ def eigs_sinvert(ctx: Context, A: CsrMatrix, M: CsrMatrix | None, sigma: complex
                                         _ptr(est), ctypes.byref(res), ctypes.byref(st)))
     k = res.nout
     return (lam[:k].copy(), np.asfortranarray(X[:, :k]), est[:k].copy(),
-            {"nconv": res.nconv, "restarts": res.restarts, "op_applies": res.op_applies, "next_unconverged": res.next_unconverged},
+            {"nconv": res.nconv, "restarts": res.restarts, "op_applies": res.op_applies, "next_unconverged": res.next_unconverged,
+             "seconds_expand": res.seconds_expand, "seconds_dense": res.seconds_dense, "seconds_restart": res.seconds_restart},
             {name: getattr(st, name) for name, _ in lsa_stats._fields_})
 
 

@@ -1,13 +1,14 @@
-"""cProfile of one warm EigenSolver.solve() on the bench workload (development aid)."""
+"""Phase timing of repeated eigen-solves of one case through the drop-in API (development aid)."""
 import argparse
-import cProfile
-import pstats
+import os
 import sys
 import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 sys.path[:0] = [str(ROOT), str(ROOT / "lsa-fw_amd")]
+os.environ.setdefault("LSA_HOST_BLAS_THREADS", "1")
+os.environ.setdefault("OPENBLAS_NUM_THREADS", "1")
 import numpy as np  # noqa: E402
 
 from synthetic import fem  # noqa: E402
@@ -16,40 +17,23 @@ from Solver.utils import PreconditionerType, iSTType  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--case", default="S30k")
-ap.add_argument("--pc", default="lu")
-ap.add_argument("--plain", action="store_true", help="no cProfile pass: the last thing the process does is one plain warm solve")
-ap.add_argument("--torch", action="store_true", help="initialise PyTorch's HIP context first, as bench.py does")
+ap.add_argument("--k", type=int, default=20)
+ap.add_argument("--ncv", type=int, default=80)
+ap.add_argument("--reps", type=int, default=8)
 args = ap.parse_args()
-if args.torch:
-    import torch
-
-    torch.cuda.set_device(0)
-    torch.cuda.synchronize()
-    print("torch initialised; threads", torch.get_num_threads())
-es = fem.cylinder_case(args.case)
-cfg = EigensolverConfig(num_eig=20, atol=1e-10, ncv=80, max_it=500)
-pc = PreconditionerType.LU if args.pc == "lu" else PreconditionerType.ILU
-solver = EigenSolver(es.A, es.M, cfg, check_hermitian=False)
-inner = solver.solver
-inner.set_st_type(iSTType.SINVERT)
-inner.set_target(fem.SIGMA_RE50)
-inner.set_st_pc_type(pc)
-inner.prepare()
-inner.solve()
-for _ in range(3):
-    t0 = time.time()
-    inner.solve()
-    print(f"warm solve {time.time() - t0:.3f} s  factor {inner.stats['seconds_factor']:.3f} solve {inner.stats['seconds_solve']:.3f}")
-t0 = time.time()
-solver.solve()
-print(f"warm EigenSolver.solve() {time.time() - t0:.3f} s")
-if args.plain:
-    t0 = time.time()
-    inner.solve()
-    print(f"last solve {1e3 * (time.time() - t0):.1f} ms; stats {inner.stats}")
-    sys.exit(0)
-pr = cProfile.Profile()
-pr.enable()
-solver.solve()
-pr.disable()
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+es = fem.cube_case(args.case) if args.case.startswith("C") else fem.cylinder_case(args.case)
+sigma = fem.SIGMA_CUBE if args.case.startswith("C") else fem.SIGMA_RE50
+s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=args.k, atol=1e-10, ncv=args.ncv), check_hermitian=False)
+s.solver.set_st_type(iSTType.SINVERT)
+s.solver.set_target(sigma)
+s.solver.set_st_pc_type(PreconditionerType.LU)
+t0 = time.perf_counter()
+s.solver.prepare()
+print(f"prepare {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
+for r in range(args.reps):
+    t0 = time.perf_counter()
+    pairs = s.solve()
+    dt = time.perf_counter() - t0
+    st = s.solver.stats
+    print(f"solve {1e3 * dt:7.2f} ms  pairs {len(pairs)}  applies {st['op_applies']}  factor {1e3 * st['seconds_factor']:.2f}  expand {1e3 * st.get('seconds_expand', 0):.2f}  "
+          f"dense {1e3 * st.get('seconds_dense', 0):.2f}  restart+ritz {1e3 * st.get('seconds_restart', 0):.2f}  restarts {st['krylov_restarts']}", flush=True)

@@ -335,9 +335,15 @@ __global__ __launch_bounds__(256) void nd_gj_stage_kernel(const int32_t* __restr
 // Column windows (tournament path with look-ahead): `only` non-empty = update just the columns [only_lo, only_hi) (the next
 // block's, so that its pivot search can start while the rest is updated); `skip` = leave [skip_lo, skip_hi) alone (done
 // already).  ztile0 = first 64-column tile of the grid.
+// INVARIANT the look-ahead relies on (launch_level_tp): while this product for block kb runs, the side stream's tournament
+// for block kb + kNB may write rowq[r] for rows r that have not been pivots yet.  Such a row goes from -1 to a value
+// >= kb + kNB; both read as "not a pivot row of block kb" in the test below (q >= kb && q < kb + nb), so the race cannot
+// change a result.  rowq is therefore read through a plain pointer here (no __restrict__ / read-only cache path that a
+// future compiler could use to assume the array does not change), and any change to rowq's encoding or to that test must
+// keep the two values on the same side of it.  tests/test_gpu_ndlu.py runs the two-stream path (LSA_ND_LOOKAHEAD_MIN lowered).
 template <typename T>
 __global__ __launch_bounds__(256) void nd_gj_gemm_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
-                                                         T* __restrict__ front, const int32_t* __restrict__ rowq, int32_t kb,
+                                                         T* __restrict__ front, const int32_t* rowq, int32_t kb,
                                                          const T* __restrict__ ybuf, int32_t only_lo, int32_t only_hi, int32_t skip_lo,
                                                          int32_t skip_hi, int32_t ztile0) {
     __shared__ T Ws[kNB][kGT + 1];
@@ -1533,7 +1539,7 @@ int launch_level_tp(lsa_ctx* ctx, lsa_ndlu* f, const NdChunk& L, double tiny2) {
     };
     // (two cross-stream hand-offs per block cost ~15 us: worth it only where the product they hide behind is long.
     // Measured: C300k 472 -> 438 ms, C160k 186 -> 183 ms; S500k, tallest pivot block 838 rows, 56 -> 59 ms without this limit)
-    static const int32_t ahead_min = getenv("LSA_ND_LOOKAHEAD_MIN") ? atoi(getenv("LSA_ND_LOOKAHEAD_MIN")) : 1024;
+    const int32_t ahead_min = getenv("LSA_ND_LOOKAHEAD_MIN") ? atoi(getenv("LSA_ND_LOOKAHEAD_MIN")) : 1024;
     const bool ahead = side != nullptr && L.max_m >= std::max(ahead_min, 2 * kNB + 1);
     launch_tournament<T>(f, L, 0, tiny2, st);
     for (int32_t kb = 0; kb < L.max_m; kb += kNB) {

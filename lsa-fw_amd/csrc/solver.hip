@@ -644,12 +644,15 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
     }
     if (op->Kfac && (op->nd || op->blu) && fac_src && fac_src->nnz > 0) {
         // ||C||_F (one reduction over the values): the scale of the backward-error test of the direct solves
-        double* nr = (double*)ctx->dscratch;
+        // (the result goes to the head of the operator's own temp vector, not to the context's scratch: k_nrm2 keeps its partial
+        //  sums there and may reallocate it; the head is zeroed again afterwards -- padding rows must read zero)
+        double* nr = (double*)op->t;
         double v2 = 0.0;
         if (k_nrm2(ctx, fac_src->dtype, fac_src->nnz, fac_src->val, nr) == LSA_OK &&
             hipMemcpyAsync(&v2, nr, sizeof v2, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess &&
             std::isfinite(v2))
             op->normF = std::sqrt(v2);
+        (void)hipMemsetAsync(op->t, 0, sizeof(double), ctx->stream);
     }
     op->st.seconds_factor = now_s() - t0;
     *out = op;

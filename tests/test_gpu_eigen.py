@@ -170,7 +170,7 @@ def test_repeated_eigenvalues(diagonal_matrix):  # :284-304
 # ---- north-star parity: cylinder pair vs the CPU oracle ---------------------------------------------------------------
 
 
-@pytest.mark.parametrize("case,k,levels", [("S2k", 6, 1), ("S5k", 20, 2)])
+@pytest.mark.parametrize("case,k,levels", [("S2k", 6, 0), ("S2k", 6, 1), ("S5k", 20, 2)])  # levels 0: ILU(0), the preconditioner BASELINE.json names, at the size where it still converges
 def test_cylinder_eigenvalues_match_oracle(case, k, levels):
     """Leading k eigenvalues nearest sigma within rtol 1e-8 of the oracle (BASELINE.json north_star), vectors up to
     a complex phase, residuals of Solver/eigen2.py:48-56 below 1e-8."""
@@ -395,6 +395,31 @@ def test_all_eigenvalues_in_an_interval():
     gm = np.array([ms.solver.get_eigenvalue(i) for i in range(ms.solver.get_num_converged())])
     assert len(gm) == 4 and np.allclose(gm[:3], ref["published"], atol=5e-7)
     assert abs(gm[3] - fem.membrane_analytic(4)[3]) <= 2e-3
+    # a double eigenvalue (two shifts return differently rotated bases of its eigenspace: counted twice, not three or four
+    # times) beside simple ones; the sweep says that its completeness is heuristic
+    import logging
+
+    D = np.diag([1.0, 2.0, 3.0, 5.0, 5.0, 6.0, 7.5, 7.5, 9.0, 12.0] + list(np.linspace(20.0, 60.0, 30)))
+    rng = np.random.default_rng(4)
+    U = np.linalg.qr(rng.standard_normal((40, 40)))[0]
+    Ad = U @ D @ U.T
+    Ad = 0.5 * (Ad + Ad.T)
+    dbl = EigenSolver(Ad, None, EigensolverConfig(problem_type=iEpsProblemType.HEP, num_eig=3, atol=1e-10, ncv=12))
+    dbl.solver.set_interval(1.5, 10.0)
+    dbl.solver.set_which_eigenpairs(iEpsWhich.ALL)
+    records = []
+    handler = logging.Handler()
+    handler.emit = records.append
+    logging.getLogger("Solver.utils").addHandler(handler)
+    try:
+        dbl.solver.solve()
+    finally:
+        logging.getLogger("Solver.utils").removeHandler(handler)
+    gd = np.array([dbl.solver.get_eigenvalue(i) for i in range(dbl.solver.get_num_converged())])
+    assert np.allclose(gd, [2.0, 3.0, 5.0, 5.0, 6.0, 7.5, 7.5, 9.0], atol=1e-8), gd
+    Vd = np.column_stack([dbl.solver.get_eigenvector_array(i) for i in range(len(gd))])
+    assert np.linalg.matrix_rank(Vd, tol=1e-6) == len(gd)  # the copies of a double eigenvalue are independent vectors
+    assert any("heuristic" in r.getMessage() for r in records)
     # not Hermitian: refused like SLEPc; no interval: refused
     bad = EigenSolver(A + np.triu(np.ones((40, 40)), 2), None, EigensolverConfig(problem_type=iEpsProblemType.NHEP, num_eig=2, atol=1e-8))
     bad.solver.set_interval(1.0, 2.0)

@@ -227,3 +227,70 @@ def test_ndlu_tournament_pivoting(hip_ctx, monkeypatch, case, sigma, leaf, tp_mi
     assert np.linalg.norm(C.conj().T @ xa - b) <= 1e-12 * np.linalg.norm(b)
     f.refactor(lsa_hip.CsrMatrix.from_scipy(hip_ctx, C))  # same values: the second elimination reproduces the first bit for bit
     assert np.array_equal(_solve(hip_ctx, f, b), x)
+
+
+@pytest.mark.parametrize("case,sigma,work_mb", [("S5k", 0.018 + 0.7379601143282424j, 1), ("C9k", -5.0, 2), ("S5k", 0.05, 0)])
+def test_ndlu_packed_factors_chunked_fronts_and_elimination_order(hip_ctx, monkeypatch, case, sigma, work_mb):
+    """The memory plan of round 3: factors packed to m^2 + 2 m b scalars per node, the working fronts of a level factored in
+    chunks that share one arena (forced here onto small cases by ``LSA_ND_WORK_MB``: several chunks per level, update matrices
+    recycled by the first-fit arena), and the caller's matrix in the elimination order of ``lsa_nd_order`` with the forest
+    handed back (sweeps without index lists).  Same answers as SuperLU and as the library's own dissection of the
+    unpermuted matrix; the device buffers are smaller than the sum of the fronts."""
+    import lsa_hip
+    from oracle import fem
+
+    monkeypatch.setenv("LSA_ND_NO_CACHE", "1")
+    if work_mb:
+        monkeypatch.setenv("LSA_ND_WORK_MB", str(work_mb))
+    if case.startswith("C"):
+        es = fem.cube_case(case)
+        C = sp.csr_matrix((es.A.data - sigma * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+    else:
+        es, C = _shifted(case, sigma)
+    zd = C.diagonal() == 0
+    o = lsa_hip.nd_order(C, 64, constraint=zd if case.startswith("C") else None)
+    perm = o["perm"]
+    Cp = C[perm][:, perm].tocsr()
+    Cp.sort_indices()
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(es.n) + (1j * rng.standard_normal(es.n) if np.iscomplexobj(C.data) else 0.0)
+    f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, Cp), tree={"first": o["first"], "size": o["size"], "parent": o["parent"]})
+    xp = _solve(hip_ctx, f, b[perm])
+    x = np.empty_like(xp)
+    x[perm] = xp
+    assert np.linalg.norm(C @ x - b) <= 1e-12 * np.linalg.norm(b)
+    xref = spla.splu(sp.csc_matrix(C)).solve(b)
+    assert np.linalg.norm(x - xref) <= 1e-10 * np.linalg.norm(xref)
+    assert np.array_equal(_solve(hip_ctx, f, b[perm]), xp)  # bitwise repeatable
+    info = f.info()
+    an = lsa_hip.NdAnalysis(Cp, tree={"first": o["first"], "size": o["size"], "parent": o["parent"]})
+    assert info["factor_entries"] == an.factor_entries
+    if work_mb:  # packed factors + one chunk + live update matrices: less than every front kept whole
+        assert info["front_entries"] < an.front_entries
+    g = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, C), 64)  # the library's own dissection, vectors through index lists
+    x2 = _solve(hip_ctx, g, b)
+    assert np.linalg.norm(x2 - xref) <= 1e-10 * np.linalg.norm(xref)
+    dxa = lsa_hip.DeviceVector(hip_ctx, es.n, b.dtype)
+    f.solve_adjoint(lsa_hip.DeviceVector.from_numpy(hip_ctx, b[perm]), dxa)  # transposed sweeps on the packed blocks
+    xa = dxa.numpy()
+    assert np.linalg.norm(Cp.conj().T @ xa - b[perm]) <= 1e-11 * np.linalg.norm(b)
+
+
+def test_ndlu_lookahead_two_stream_path(hip_ctx, monkeypatch):
+    """The tournament of the next column block on a second stream under the current block's rank-32 product (default: pivot
+    blocks of 1024 rows and more), forced onto a small case: same factors as the one-stream order."""
+    import lsa_hip
+    from oracle import fem
+
+    es = fem.cube_case("C9k")
+    C = sp.csr_matrix((es.A.data - fem.SIGMA_CUBE * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+    b = np.random.default_rng(8).standard_normal(es.n)
+    monkeypatch.setenv("LSA_ND_NO_CACHE", "1")
+    monkeypatch.setenv("LSA_ND_TP_MIN", "64")
+    xs = []
+    for ahead in ("100000", "65"):
+        monkeypatch.setenv("LSA_ND_LOOKAHEAD_MIN", ahead)
+        f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, C), 128)
+        xs.append(_solve(hip_ctx, f, b))
+        assert np.linalg.norm(C @ xs[-1] - b) <= 1e-11 * np.linalg.norm(b)
+    assert np.array_equal(xs[0], xs[1])

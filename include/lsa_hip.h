@@ -257,7 +257,9 @@ int lsa_op_apply(lsa_ctx *ctx, lsa_op *op, const lsa_vec *x, lsa_vec *y);
 int lsa_op_stats(const lsa_op *op, lsa_stats *out);
 /* Adjoint form of a shift-invert operator on the SAME factors: y = Kfac^-H Kmul^H x = (A - sigma M)^-H M^H x, the operator of
  * the adjoint eigenproblem (A^H, M^H) at the target conj(sigma) (Sensitivity/__init__.py:230-311, which forms the two
- * transposes and factorises again).  Transposed sweeps of the nested-dissection LU, transposed SpMV; one rank. */
+ * transposes and factorises again).  Transposed sweeps of the nested-dissection LU, transposed SpMV; one rank, or the
+ * subtree-parallel layout of lsa_op_create_dist (same exchanges as the forward solve; the transposed products use the whole
+ * matrices every rank holds). */
 int lsa_op_set_adjoint(lsa_ctx *ctx, lsa_op *op, int on);
 /* Projected operator  y = P Kfac^-1 Kmul x  with P = diag(keep): keep[i] in {0, 1}, host array of n doubles (NULL
  * removes the projection).  Stands in for the velocity-subspace projection of ArpackEigenSolver's matvec

@@ -570,8 +570,9 @@ class iEpsSolver:
         which = self._which or (iEpsWhich.TARGET_MAGNITUDE if sinvert else iEpsWhich.LARGEST_MAGNITUDE)
         # (like SLEPc, an interval set without iEpsWhich.ALL has no effect; ALL is handled by _solve_interval)
         lam_key = _lambda_rank_key(which, self._target)
-        if self._adjoint and (not sinvert or cayley or prep["pc_code"] != 2 or prep["part"] is not None):
-            raise NotImplementedError("adjoint=True needs shift-invert with the exact LU (PreconditionerType.LU, lu='nd') in the single-GPU layout")
+        if self._adjoint and (not sinvert or cayley or prep["pc_code"] != 2 or (prep["part"] is not None and prep["forest"] is None)):
+            raise NotImplementedError("adjoint=True needs shift-invert with the exact LU (PreconditionerType.LU, lu='nd'), on one GPU or in the "
+                                      "subtree-parallel sharded layout")
         ksp_rtol = self._ksp_rtol if self._ksp_rtol is not None else float(np.clip(self._tol * 1e-2, 1e-13, 1e-8))
         op = basis = None
         try:

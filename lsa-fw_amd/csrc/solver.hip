@@ -114,7 +114,7 @@ int upload_small(lsa_ctx* ctx, int dtype, const zc* src, size_t count, void* dst
 // y = A x for a (possibly row-sharded) matrix; x and y are global-length vectors replicated on every rank: the
 // shard writes its own rows, then the equal-sized padded blocks are exchanged with one in-place all-gather
 int spmv_global(lsa_ctx* ctx, const lsa_mat* A, int dtype, const void* x, void* y, bool adjoint = false) {
-    if (adjoint) return k_spmv_transpose(ctx, A, 1, dtype, x, y);  // y = A^H x (one rank only: checked when the mode is set)
+    if (adjoint) return k_spmv_transpose(ctx, A, 1, dtype, x, y);  // y = A^H x with the whole matrix (lsa_op_set_adjoint sees to that on every rank)
     const size_t es = esize(dtype);
     LSA_CHECK(k_spmv(ctx, A, dtype, x, (char*)y + (size_t)A->row0 * es));
     // (a whole square matrix was multiplied on every rank: nothing to exchange)
@@ -138,7 +138,7 @@ int pc_global(lsa_ctx* ctx, PcRef pc, int32_t row0, int64_t nglobal, int dtype, 
     const size_t es = esize(dtype);
     const char* bl = (const char*)b + (size_t)row0 * es;
     char* xl = (char*)x + (size_t)row0 * es;
-    if (pc.nd && pc.adjoint) LSA_CHECK(ndlu_solve_adjoint_dev(ctx, pc.nd, 1, dtype, bl, xl));
+    if (pc.nd && pc.adjoint) LSA_CHECK(ndlu_solve_adjoint_dev(ctx, pc.nd, 1, dtype, pc.nd_dist ? b : bl, pc.nd_dist ? x : xl));
     else if (pc.nd && pc.nd_dist) LSA_CHECK(ndlu_solve_dev(ctx, pc.nd, dtype, b, x));  // own subtrees + replicated top; x completed below
     else if (pc.nd) LSA_CHECK(ndlu_solve_dev(ctx, pc.nd, dtype, bl, xl));
     else if (pc.blu) LSA_CHECK(blu_solve_dev(ctx, pc.blu, dtype, bl, xl));
@@ -424,6 +424,7 @@ struct lsa_op {
     bool adjoint = false;    // y = Kfac^-H Kmul^H x on the same factors (lsa_op_set_adjoint)
     double normF = 0.0;      // ||Kfac||_F
     lsa_mat *view_fac = nullptr, *view_mul = nullptr;  // this rank's rows of the whole matrices (subtree-parallel layout)
+    const lsa_mat* M_whole = nullptr;                  // the caller's M (modes 0 and 2)
     lsa_op_options opts;
     GmresWork gw;
     bool gw_ready;
@@ -558,6 +559,7 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
     if (mode == 0 || mode == 2) {
         op->Kfac = C;
         op->Kmul = M;
+        op->M_whole = M;
         // Subtree-parallel layout: every rank holds the whole matrices.  A product over this rank's rows only must be
         // completed by an all-gather of the result (16 B per unknown over xGMI); the whole product costs 20 B per stored
         // entry from HBM.  With the ~30 entries per row of the 2D pattern the replicated product is the cheaper one at any
@@ -732,8 +734,17 @@ static int op_apply_dev(lsa_ctx* ctx, lsa_op* op, const void* x, void* y) {
 
 int lsa_op_set_adjoint(lsa_ctx* ctx, lsa_op* op, int on) {
     if (!ctx || !op) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_set_adjoint: null argument");
-    if (on && (!op->nd || op->nd_dist || ctx->nranks != 1 || !op->Kfac))
-        return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_set_adjoint: needs the nested-dissection LU (pc_type 2) of a factorising mode on one rank");
+    if (on && (!op->nd || !op->Kfac || (ctx->nranks != 1 && !op->nd_dist)))
+        return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_set_adjoint: needs the nested-dissection LU (pc_type 2) of a factorising mode, on one rank or in the "
+                                                "subtree-parallel layout");
+    if (op->nd_dist) {
+        // Subtree-parallel layout: the transposed sweeps walk the same forest with the same exchanges (own subtrees, all-gather of
+        // the subtree roots' update vectors, replicated top, all-gather of the solution blocks).  The transposed sparse products
+        // are taken with the WHOLE matrices every rank holds (a transposed product over a row block would need a reduction
+        // over the ranks instead of an all-gather), whatever the forward products use.
+        op->Kfac = (on || !op->view_fac) ? op->owned : op->view_fac;
+        op->Kmul = (on || !op->view_mul) ? (op->owned_mul ? op->owned_mul : op->M_whole) : op->view_mul;
+    }
     op->adjoint = on != 0;
     return LSA_OK;
 }

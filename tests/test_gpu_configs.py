@@ -190,8 +190,11 @@ def test_s500k_eigenvalues_match_the_golden_fixture():
     # the oracle's two-sided Rayleigh quotients a^H A v / a^H M v (error of second order in its residuals) tell which side an
     # outer eigenvalue's gap belongs to: the GPU's value is at least as close to them as ARPACK's own
     rq = _complex(gold["eigenvalues_two_sided_rq"])
-    print("GPU vs oracle RQ:", np.array2string(np.abs(lam[pick] - rq) / np.abs(rq), precision=1), "\noracle vs its RQ:",
-          np.array2string(np.abs(ref[:20] - rq) / np.abs(rq), precision=1))
+    gpu_rq, ref_rq = np.abs(lam[pick] - rq) / np.abs(rq), np.abs(ref[:20] - rq) / np.abs(rq)
+    print("GPU vs oracle RQ:", np.array2string(gpu_rq, precision=1), "\noracle vs its RQ:", np.array2string(ref_rq, precision=1))
+    # measured: 2.5e-14 .. 9e-8 for the GPU against 9e-12 .. 4e-7 for ARPACK's own values -- the gap of the outer eigenvalues to
+    # the oracle is the ORACLE's (kappa up to 2.4e11 times the rounding of its solves)
+    assert np.all(gpu_rq <= np.maximum(1e-8, ref_rq)), (gpu_rq, ref_rq)
     assert s.solver.residuals()[:20].max() <= 1e-8
     st = s.solver.stats
     assert st["gmres_iters"] == 0 and st["pc_fallback"] == 0 and st["stagnated_solves"] == 0

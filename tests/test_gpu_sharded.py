@@ -130,6 +130,61 @@ def test_sharded_solve_with_several_ranks_on_one_gpu(tmp_path, world, pc, case):
         assert int(out[0]["gmres"]) > int(out[0]["applies"]) and int(out[0]["gathers"]) > 2 * int(out[0]["applies"])
 
 
+def _rank_adjoint(rank: int, world: int, port: int, out_dir: str) -> None:
+    import os
+    import sys
+    from pathlib import Path
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    root = Path(__file__).resolve().parents[1]
+    sys.path[:0] = [str(root), str(root / "lsa-fw_amd"), str(root / "tests")]
+    import torch.distributed as dist
+
+    from oracle import fem
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    es = fem.cylinder_case("S2k")
+    solver = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=4, atol=1e-10, ncv=40), check_hermitian=False, layout="sharded", adjoint=True)
+    solver.solver.set_st_type(iSTType.SINVERT)
+    solver.solver.set_target(np.conj(fem.SIGMA_RE50))
+    solver.solver.set_st_pc_type(PreconditionerType.LU)
+    pairs = solver.solve()
+    np.savez(Path(out_dir) / f"adj{rank}.npz", lam=np.array([p[0] for p in pairs[:4]]), V=np.column_stack([p[1].as_array() for p in pairs[:4]]),
+             res=solver.solver.residuals()[:4], gmres=solver.solver.stats["gmres_iters"])
+    solver.solver.release()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_adjoint_solve(tmp_path, world):
+    """The adjoint eigenproblem (left eigenvectors: ``Sensitivity/__init__.py:247-274``) in the subtree-parallel layout: the
+    transposed sweeps on each rank's subtrees with the same two exchanges as the forward solve, transposed products with the
+    whole matrices.  Eigenvalues = the conjugates of the direct ones, vectors = eigenvectors of (A^H, M^H), ranks bit-identical."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from oracle import fem, shift_invert
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_adjoint, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    out = [np.load(tmp_path / f"adj{r}.npz") for r in range(world)]
+    for o in out[1:]:
+        assert np.array_equal(o["lam"], out[0]["lam"]) and np.array_equal(o["V"], out[0]["V"])
+    es = fem.cylinder_case("S2k")
+    ref, _, _ = shift_invert.solve(es.A, es.M, fem.SIGMA_RE50, k=4, tol=1e-13)
+    for r in ref:
+        assert np.min(np.abs(out[0]["lam"] - np.conj(r))) <= 1e-8 * abs(r)
+    AH, MH = es.A.conj().T.tocsr(), es.M.conj().T.tocsr()
+    assert shift_invert.compute_residuals(AH, MH, out[0]["lam"], out[0]["V"]).max() <= 1e-8
+    assert out[0]["res"].max() <= 1e-8 and int(out[0]["gmres"]) == 0
+
+
 def test_rccl_plumbing_with_one_rank(hip_ctx):
     """What a one-GPU box can run of the RCCL path: dlopen, ncclGetUniqueId, ncclCommInitRank (one rank) on the library's
     device, one in-place ncclAllGather on the library's stream, destroy -- the call sequence and signatures the sharded

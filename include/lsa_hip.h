@@ -173,6 +173,13 @@ void lsa_nd_sym_destroy(lsa_nd_sym *h);
  * m^2 + 2 m b over the nodes), scalars of all fronts (sum of f^2), multiply-adds of the numeric factorisation */
 int lsa_nd_sym_info(const lsa_nd_sym *h, int32_t *ntree, int32_t *nlevels, int32_t *max_front, int64_t *index_entries,
                     int64_t *factor_entries, int64_t *front_entries, double *flops);
+/* Device memory of a factorisation of this analysis, in bytes, before any GPU is touched (what lsa_ndlu_create will allocate;
+ * scalar_bytes 8 or 16; work_budget_bytes: what the working fronts of one chunk may take, <= 0: a whole level): out[0] packed
+ * factors sum(m^2 + 2 m b), out[1] working arena, out[2] update arena (out[3] of it: the exchange region of a forest cut over
+ * ranks), out[4] sweep buffers, out[5] number of chunks, out[6] the largest front, out[7] index tables.  Optional per-node
+ * copies of the plan (tests): upd_off[ntree], work_off[ntree] (scalars), chunk_of[ntree] (-1: not factored here). */
+int lsa_nd_sym_memory(const lsa_nd_sym *h, int32_t scalar_bytes, int64_t work_budget_bytes, int64_t *out, int64_t *upd_off, int64_t *work_off,
+                      int32_t *chunk_of);
 /* copies of the analysis (any pointer may be NULL): perm[n] (elimination order -> original index), node_start[ntree + 1],
  * parent[ntree] (-1 = root), level[ntree], front_size[ntree], idx[index_entries] (front index lists, original numbering) */
 int lsa_nd_sym_export(const lsa_nd_sym *h, int32_t *perm, int32_t *node_start, int32_t *parent, int32_t *level, int32_t *front_size,

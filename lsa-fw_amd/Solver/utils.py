@@ -617,8 +617,12 @@ class iEpsSolver:
             else:
                 # one library call: Krylov-Schur with the library's own dense algebra (lsa_krylov_solve).  The start vector is
                 # drawn here so that both drivers begin from the same one.
-                rng = np.random.default_rng(self._seed)
-                v0 = rng.standard_normal(basis.n) + 1j * rng.standard_normal(basis.n)
+                cached = getattr(self, "_v0_cache", None)
+                if cached is None or cached[0] != (basis.n, self._seed):  # (0.7 ms at 30 k unknowns: a shift sweep draws it once)
+                    rng = np.random.default_rng(self._seed)
+                    cached = ((basis.n, self._seed), rng.standard_normal(basis.n) + 1j * rng.standard_normal(basis.n))
+                    self._v0_cache = cached
+                v0 = cached[1]
                 res = basis.solve(nev, self._tol, self._max_it, which.value, 2 if cayley else 0 if sinvert else 1, sigma, antishift=nu,
                                   target=self._target, v0=v0, seed=self._seed)
             imag_norms = getattr(basis, "imag_norms", None)  # set when the device already put the vectors into canonical phase
@@ -835,8 +839,15 @@ class iEpsSolver:
         # takes 50 ms longer (tools/micro/after_eigensolve.py: 74 -> 125 ms per solve at 30 k unknowns on a 256-core host).
         from lsa_hip.krylov_schur import _single_threaded_blas
 
-        with _single_threaded_blas():
-            pairs = [self.get_eigenpair(i) for i in range(min(self.get_num_converged(), num))]
+        count = min(self.get_num_converged(), num)
+        imag_norms = getattr(self, "_imag_norms", None)
+        if imag_norms is not None and not np.any(imag_norms[:count] <= 1e-6):
+            # complex vectors that left the device normalised and in canonical phase: handing them out calls no BLAS at all
+            # (entering the thread-pool guard alone costs 0.6 ms: it walks the loaded libraries)
+            pairs = [self.get_eigenpair(i) for i in range(count)]
+        else:
+            with _single_threaded_blas():
+                pairs = [self.get_eigenpair(i) for i in range(count)]
         yield from pairs
 
     def get_eigenvector_array(self, idx: int) -> np.ndarray:

@@ -62,3 +62,19 @@ int nd_analyse_tree(int32_t n, const int32_t* rp, const int32_t* ci, int32_t nt,
 int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_size, const int8_t* constraint, NdSymbolic* out, char* err,
                int errlen, bool order_only = false);
 uint64_t nd_pattern_hash(int32_t n, const int32_t* rp, const int32_t* ci);
+
+// Where everything of a factorisation lives on the device, from the analysis alone (host arithmetic; nd_symbolic.hip):
+// packed factors, the chunks of working fronts that share one arena, the update arena laid out by a first-fit allocator run
+// over the chunk order (a node's update matrix lives from its chunk to its parent's; the subtree roots of a forest cut
+// over ranks sit in one slot per rank at its start, the exchange region of the in-place all-gather), the slot rows of the
+// upward sweep.  All offsets and sizes in scalars.
+struct NdMemoryPlan {
+    std::vector<int64_t> work_off, upd_off, lfac_off, ufac_off, acc_off, pacc_off;  // per kept node (acc / pacc: -1 = pull form)
+    std::vector<int32_t> chunk_begin;          // chunk c = lvl_nodes[chunk_begin[c] .. chunk_begin[c + 1])
+    std::vector<int64_t> chunk_work;           // scalars of the working arena chunk c uses
+    std::vector<char> chunk_exchange_before;   // the subtree roots' update matrices are all-gathered before this chunk
+    int64_t lfac_entries = 0, ufac_entries = 0, work_entries = 1, upd_entries = 1, acc_entries = 0, xupd_slot = 0;
+    int64_t max_front_entries = 0, max_level_entries = 0;
+};
+// budget_entries: scalars the working arena may take (a single front always fits); <= 0: every level in one chunk
+void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P);

@@ -752,6 +752,148 @@ int nd_analyse_tree(int32_t n, const int32_t* rp, const int32_t* ci, int32_t nt,
     return nd_finish(S, n, rp, ci, g, own, par, owner, rank, nranks, fail);
 }
 
+// ---- memory plan -------------------------------------------------------------------------------------------------------------
+namespace {
+// first-fit allocator over [0, inf) with a coalescing free list, run on the host over the chunk order: the offsets it hands
+// out are the update arena's layout, its high-water mark the arena's size
+struct ArenaPlan {
+    std::vector<std::pair<int64_t, int64_t>> free_;  // (offset, size), sorted by offset
+    int64_t top = 0;                                  // high-water mark
+    int64_t alloc(int64_t size) {
+        if (size <= 0) return 0;
+        for (size_t i = 0; i < free_.size(); ++i)
+            if (free_[i].second >= size) {
+                const int64_t off = free_[i].first;
+                if (free_[i].second == size) free_.erase(free_.begin() + (int64_t)i);
+                else free_[i] = {off + size, free_[i].second - size};
+                return off;
+            }
+        if (!free_.empty() && free_.back().first + free_.back().second == top) {  // grow the block at the end
+            const int64_t off = free_.back().first;
+            top = off + size;
+            free_.pop_back();
+            return off;
+        }
+        const int64_t off = top;
+        top += size;
+        return off;
+    }
+    void release(int64_t off, int64_t size) {
+        if (size <= 0) return;
+        auto it = std::lower_bound(free_.begin(), free_.end(), std::make_pair(off, (int64_t)0));
+        it = free_.insert(it, {off, size});
+        if (it + 1 != free_.end() && it->first + it->second == (it + 1)->first) {
+            it->second += (it + 1)->second;
+            free_.erase(it + 1);
+        }
+        if (it != free_.begin() && (it - 1)->first + (it - 1)->second == it->first) {
+            (it - 1)->second += it->second;
+            free_.erase(it);
+        }
+    }
+};
+}  // namespace
+
+void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P) {
+    const int32_t nt = S.nt;
+    const bool dist = S.nranks > 1;
+    auto is_xroot = [&](int32_t q) { return dist && S.kind[(size_t)q] != 2 && S.parent[(size_t)q] >= 0 && S.kind[(size_t)S.parent[(size_t)q]] == 2; };
+    P = NdMemoryPlan();
+    P.work_off.assign((size_t)nt, 0);
+    P.upd_off.assign((size_t)nt, 0);
+    P.lfac_off.assign((size_t)nt, 0);
+    P.ufac_off.assign((size_t)nt, 0);
+    P.acc_off.assign((size_t)nt, -1);
+    P.pacc_off.assign((size_t)nt, -1);
+    // ---- packed factors ----
+    for (int32_t t = 0; t < nt; ++t) {
+        if (S.kind[(size_t)t] == 3) continue;  // another rank's subtree root: only its update matrix and vector arrive here
+        const int64_t m = S.m[(size_t)t], ff = S.f[(size_t)t];
+        P.lfac_off[(size_t)t] = P.lfac_entries;
+        P.ufac_off[(size_t)t] = P.ufac_entries;
+        P.lfac_entries += ff * m;
+        P.ufac_entries += m * (ff - m);
+    }
+    // ---- slot rows of the upward sweep: push form unless a child's update vector arrives by all-gather (then the node pulls) ----
+    for (int32_t t = 0; t < nt; ++t) {
+        const int32_t c0 = S.child_ptr[(size_t)t], c1 = S.child_ptr[(size_t)t + 1];
+        bool pull = false;
+        for (int32_t cp = c0; cp < c1; ++cp) pull |= is_xroot(S.child_idx[(size_t)cp]);
+        if (c1 == c0 || pull || S.kind[(size_t)t] == 3) continue;
+        P.acc_off[(size_t)t] = P.acc_entries;
+        for (int32_t cp = c0; cp < c1; ++cp) P.pacc_off[(size_t)S.child_idx[(size_t)cp]] = P.acc_entries + (int64_t)(cp - c0) * S.f[(size_t)t];
+        P.acc_entries += (int64_t)(c1 - c0) * S.f[(size_t)t];
+    }
+    // ---- chunks: the nodes of a work level, larger pivot blocks first, cut where the working fronts would outgrow the arena ----
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+        int64_t sum = 0;
+        for (int32_t q = S.lvl_ptr[(size_t)l]; q < S.lvl_ptr[(size_t)l + 1]; ++q) {
+            const int64_t ff = S.f[(size_t)S.lvl_nodes[(size_t)q]];
+            sum += ff * ff;
+            P.max_front_entries = std::max(P.max_front_entries, ff * ff);
+        }
+        P.max_level_entries = std::max(P.max_level_entries, sum);
+    }
+    const int64_t budget = std::max(P.max_front_entries, budget_entries > 0 ? std::min(P.max_level_entries, budget_entries) : P.max_level_entries);
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+        int64_t used = 0;
+        for (int32_t q = S.lvl_ptr[(size_t)l]; q < S.lvl_ptr[(size_t)l + 1]; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)q];
+            const int64_t ff = S.f[(size_t)t];
+            if (q == S.lvl_ptr[(size_t)l] || used + ff * ff > budget) {
+                P.chunk_begin.push_back(q);
+                P.chunk_work.push_back(0);
+                P.chunk_exchange_before.push_back(dist && l == S.phase_b_level && q == S.lvl_ptr[(size_t)l]);
+                used = 0;
+            }
+            P.work_off[(size_t)t] = used;
+            used += ff * ff;
+            P.chunk_work.back() = used;
+            P.work_entries = std::max(P.work_entries, used);
+        }
+    }
+    P.chunk_begin.push_back(S.lvl_ptr.empty() ? 0 : S.lvl_ptr.back());
+    // ---- update arena ----
+    if (dist) {
+        std::vector<int64_t> use((size_t)S.nranks, 0);
+        auto owner_of = [&](int32_t q) { return (int32_t)(S.front_off[(size_t)q] / std::max<int64_t>(S.xfront_slot, 1)); };  // its slot of the logical layout
+        for (int32_t q = 0; q < nt; ++q)
+            if (is_xroot(q)) {
+                const int64_t b = S.f[(size_t)q] - S.m[(size_t)q];
+                use[(size_t)owner_of(q)] += b * b;
+            }
+        for (int64_t v : use) P.xupd_slot = std::max(P.xupd_slot, v);
+        std::fill(use.begin(), use.end(), 0);
+        for (int32_t q = 0; q < nt; ++q)
+            if (is_xroot(q)) {  // (same order, same sizes on every rank: the in-place all-gather moves slot r of rank r)
+                const int64_t b = S.f[(size_t)q] - S.m[(size_t)q];
+                const int32_t o = owner_of(q);
+                P.upd_off[(size_t)q] = P.xupd_slot * o + use[(size_t)o];
+                use[(size_t)o] += b * b;
+            }
+    }
+    ArenaPlan arena;
+    const int64_t base = P.xupd_slot * S.nranks;
+    for (size_t c = 0; c + 1 < P.chunk_begin.size(); ++c) {
+        for (int32_t q = P.chunk_begin[c]; q < P.chunk_begin[c + 1]; ++q) {  // blocks written by this chunk
+            const int32_t t = S.lvl_nodes[(size_t)q];
+            const int64_t b = S.f[(size_t)t] - S.m[(size_t)t];
+            if (b > 0 && !is_xroot(t)) P.upd_off[(size_t)t] = base + arena.alloc(b * b);
+        }
+        // blocks consumed by this chunk are free from the next chunk on.  (This chunk's own blocks were placed first: a block a
+        // parent reads in this chunk's extend-add must not be handed to a node that is saved in the same chunk.)
+        for (int32_t q = P.chunk_begin[c]; q < P.chunk_begin[c + 1]; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)q];
+            for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) {
+                const int32_t ch = S.child_idx[(size_t)cp];
+                const int64_t b = S.f[(size_t)ch] - S.m[(size_t)ch];
+                if (!is_xroot(ch)) arena.release(P.upd_off[(size_t)ch] - base, b * b);
+            }
+        }
+    }
+    P.upd_entries = std::max<int64_t>(base + arena.top, 1);
+}
+
 // ---- C-ABI: analysis only (host) -----------------------------------------------------------------------------------------
 struct lsa_nd_sym {
     NdSymbolic S;
@@ -828,6 +970,28 @@ int lsa_nd_sym_info(const lsa_nd_sym* h, int32_t* ntree, int32_t* nlevels, int32
     if (factor_entries) *factor_entries = S.factor_entries;
     if (front_entries) *front_entries = S.front_entries;
     if (flops) *flops = S.flops;
+    return LSA_OK;
+}
+
+int lsa_nd_sym_memory(const lsa_nd_sym* h, int32_t scalar_bytes, int64_t work_budget_bytes, int64_t* out, int64_t* upd_off, int64_t* work_off, int32_t* chunk_of) {
+    if (!h || !out || (scalar_bytes != 8 && scalar_bytes != 16)) return LSA_ERR_ARG;
+    const NdSymbolic& S = h->S;
+    if (S.order_only) return LSA_ERR_ARG;
+    NdMemoryPlan P;
+    nd_memory_plan(S, work_budget_bytes > 0 ? work_budget_bytes / scalar_bytes : 0, P);
+    out[0] = (P.lfac_entries + P.ufac_entries) * scalar_bytes;  // packed factors
+    out[1] = P.work_entries * scalar_bytes;                    // working fronts of the largest chunk
+    out[2] = P.upd_entries * scalar_bytes;                     // update arena (with the exchange region of a forest cut over ranks)
+    out[3] = P.xupd_slot * S.nranks * scalar_bytes;            // ... of which the exchange region
+    out[4] = P.acc_entries * 16 + 2 * S.u_off[(size_t)S.nt] * 16;  // sweep buffers: slot rows, update and boundary vectors (complex vectors)
+    out[5] = (int64_t)P.chunk_begin.size() - 1;                // chunks
+    out[6] = P.max_front_entries * scalar_bytes;               // the largest front
+    out[7] = (int64_t)(S.idx.size() + S.gell.size() + S.cmap.size()) * 4 + (int64_t)S.asm_src.size() * 12 + (int64_t)S.nt * 96 * 2;  // index tables
+    if (upd_off) std::copy(P.upd_off.begin(), P.upd_off.end(), upd_off);
+    if (work_off) std::copy(P.work_off.begin(), P.work_off.end(), work_off);
+    if (chunk_of)
+        for (size_t c = 0; c + 1 < P.chunk_begin.size(); ++c)
+            for (int32_t q = P.chunk_begin[c]; q < P.chunk_begin[c + 1]; ++q) chunk_of[(size_t)S.lvl_nodes[(size_t)q]] = (int32_t)c;
     return LSA_OK;
 }
 

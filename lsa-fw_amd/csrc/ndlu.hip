@@ -87,15 +87,27 @@ struct NdLevel {
 };
 
 template <typename T>
-__global__ void nd_maxabs2_kernel(int64_t nnz, const T* __restrict__ v, unsigned long long* __restrict__ out) {
+__global__ __launch_bounds__(256) void nd_maxabs2_kernel(int64_t nnz, const T* __restrict__ v, unsigned long long* __restrict__ out) {
+    // one atomic per workgroup (an atomic per wavefront on one address serialised: 165 us for 0.9 M entries)
+    __shared__ double wmax[4];
     double best = 0.0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nnz; i += stride) {
         const double a = s_abs2(v[i]);
         if (a == a && a > best) best = a;
+        else if (a != a) best = a;  // a NaN must reach the host (NaN > x is false: keep it by hand)
     }
-    for (int o = 32; o > 0; o >>= 1) best = fmax(best, __shfl_xor(best, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(best));
+    for (int o = 32; o > 0; o >>= 1) {
+        const double other = __shfl_xor(best, o);
+        best = (best != best) ? best : (other != other) ? other : fmax(best, other);
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) best = (best != best) ? best : (wmax[w] != wmax[w]) ? wmax[w] : fmax(best, wmax[w]);
+        // non-negative doubles order like their bit patterns; a NaN's pattern (0x7ff8...) is above every finite value's and infinity's
+        atomicMax(out, (unsigned long long)__double_as_longlong(best));
+    }
 }
 
 template <typename T>
@@ -863,40 +875,57 @@ __device__ __forceinline__ void push_down(const int32_t* __restrict__ ge, int32_
 // of the tree, where a few tall fronts must still be spread over the whole chip, 4 (128 rows) on levels of thin separators.
 // ORDERED: the vectors are in elimination order (own unknown r of the node = own0 + r), else through idx.
 // A root (no boundary) also starts the downward sweep: its rows are final, they go to its children's boundary vectors.
-template <typename MT, typename VT, int LPR, bool ORDERED>
+template <typename MT, typename VT, int LPR, bool ORDERED, int NP = 1>
 __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ lfac,
                                                      const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
                                                      const int32_t* __restrict__ cmap, const VT* __restrict__ rhs, VT* __restrict__ x,
                                                      VT* __restrict__ ubuf, VT* __restrict__ acc, VT* __restrict__ xb) {
+    // NP row pairs per sub-wave: NP * 512 / LPR rows per workgroup share one gather of the node's vector (NP = 1 everywhere:
+    // NP = 2 was measured on the widest level and does not pay)
     __shared__ VT vs[kCH];
+    constexpr int ROWS = NP * 512 / LPR;
     const NdNodeDev nd = lnodes[blockIdx.x];
-    const int32_t r0 = (int32_t)blockIdx.y * (512 / LPR);
+    const int32_t r0 = (int32_t)blockIdx.y * ROWS;
     const int32_t m = nd.m, f = nd.f;
     if (r0 >= f) return;
     const int32_t* ix = idx + nd.idx_off;
     const int32_t* ge = gell + nd.ge_off;
     const MT* L = lfac + nd.lfac_off;
     const int tid = threadIdx.x, sw = tid / LPR, sl = tid % LPR;
-    const int32_t ra = r0 + sw, rb = r0 + sw + 256 / LPR;
-    const MT* La = L + (size_t)min(ra, f - 1) * m;
-    const MT* Lb = L + (size_t)min(rb, f - 1) * m;
-    VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
-    // everything that depends only on the node record is requested first: the head of the two rows, what the children
-    // added to the update entries these rows produce, where those entries go
-    MT pa[4], pb[4];
-    row_pair_prefetch<LPR>(La, Lb, min(kCH, m), sl, pa, pb);
+    int32_t ra[NP], rb[NP];
+    const MT *La[NP], *Lb[NP];
+    VT acc0[NP], acc1[NP];
+    // everything that depends only on the node record is requested first: the head of the rows, what the children added to
+    // the update entries these rows produce, where those entries go
+    MT pa[NP][4], pb[NP][4];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        ra[p] = r0 + sw + p * (512 / LPR);
+        rb[p] = ra[p] + 256 / LPR;
+        La[p] = L + (size_t)min(ra[p], f - 1) * m;
+        Lb[p] = L + (size_t)min(rb[p], f - 1) * m;
+        acc0[p] = scalar_traits<VT>::zero();
+        acc1[p] = scalar_traits<VT>::zero();
+        row_pair_prefetch<LPR>(La[p], Lb[p], min(kCH, m), sl, pa[p], pb[p]);
+    }
     const bool push = nd.acc_off >= 0;
     const VT* slots = acc + (push ? nd.acc_off : 0);
-    VT ua = scalar_traits<VT>::zero(), ub = scalar_traits<VT>::zero();
-    int32_t ca = 0, cb = 0;
-    if (sl == 0) {
-        if (ra >= m && ra < f) {
-            ua = push ? slot_sum(slots, nd.nchild, f, ra, ua) : gather_updates(ge, nd.nchild, f, ra, ubuf, ua);
-            if (nd.pacc_off >= 0) ca = cmap[nd.cmap_off + ra - m];
-        }
-        if (rb >= m && rb < f) {
-            ub = push ? slot_sum(slots, nd.nchild, f, rb, ub) : gather_updates(ge, nd.nchild, f, rb, ubuf, ub);
-            if (nd.pacc_off >= 0) cb = cmap[nd.cmap_off + rb - m];
+    VT ua[NP], ub[NP];
+    int32_t ca[NP], cb[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        ua[p] = scalar_traits<VT>::zero();
+        ub[p] = scalar_traits<VT>::zero();
+        ca[p] = cb[p] = 0;
+        if (sl == 0) {
+            if (ra[p] >= m && ra[p] < f) {
+                ua[p] = push ? slot_sum(slots, nd.nchild, f, ra[p], ua[p]) : gather_updates(ge, nd.nchild, f, ra[p], ubuf, ua[p]);
+                if (nd.pacc_off >= 0) ca[p] = cmap[nd.cmap_off + ra[p] - m];
+            }
+            if (rb[p] >= m && rb[p] < f) {
+                ub[p] = push ? slot_sum(slots, nd.nchild, f, rb[p], ub[p]) : gather_updates(ge, nd.nchild, f, rb[p], ubuf, ub[p]);
+                if (nd.pacc_off >= 0) cb[p] = cmap[nd.cmap_off + rb[p] - m];
+            }
         }
     }
     for (int32_t c0 = 0; c0 < m; c0 += kCH) {
@@ -906,28 +935,33 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict
             vs[j] = push ? slot_sum(slots, nd.nchild, f, c0 + j, v) : gather_updates(ge, nd.nchild, f, c0 + j, ubuf, v);
         }
         __syncthreads();
-        if (c0 == 0) two_row_dot_prefetched<LPR>(La, Lb, vs, cn, sl, acc0, acc1, pa, pb);
-        else two_row_dot<LPR>(La + c0, Lb + c0, vs, cn, sl, acc0, acc1);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (c0 == 0) two_row_dot_prefetched<LPR>(La[p], Lb[p], vs, cn, sl, acc0[p], acc1[p], pa[p], pb[p]);
+            else two_row_dot<LPR>(La[p] + c0, Lb[p] + c0, vs, cn, sl, acc0[p], acc1[p]);
+        }
         __syncthreads();
     }
-    acc0 = lanes_sum<LPR>(acc0);
-    acc1 = lanes_sum<LPR>(acc1);
-    if (sl == 0) {
-        if (ra < m) {
-            x[ORDERED ? nd.own0 + ra : ix[ra]] = acc0;
-            if (f == m) push_down(ge, nd.nchild, f, ra, xb, acc0);
-        } else if (ra < f) {
-            const VT u = s_add(ua, acc0);
-            if (nd.pacc_off >= 0) acc[nd.pacc_off + ca] = u;
-            else ubuf[nd.u_off + (ra - m)] = u;
-        }
-        if (rb < m) {
-            x[ORDERED ? nd.own0 + rb : ix[rb]] = acc1;
-            if (f == m) push_down(ge, nd.nchild, f, rb, xb, acc1);
-        } else if (rb < f) {
-            const VT u = s_add(ub, acc1);
-            if (nd.pacc_off >= 0) acc[nd.pacc_off + cb] = u;
-            else ubuf[nd.u_off + (rb - m)] = u;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const VT s0 = lanes_sum<LPR>(acc0[p]), s1 = lanes_sum<LPR>(acc1[p]);
+        if (sl == 0) {
+            if (ra[p] < m) {
+                x[ORDERED ? nd.own0 + ra[p] : ix[ra[p]]] = s0;
+                if (f == m) push_down(ge, nd.nchild, f, ra[p], xb, s0);
+            } else if (ra[p] < f) {
+                const VT u = s_add(ua[p], s0);
+                if (nd.pacc_off >= 0) acc[nd.pacc_off + ca[p]] = u;
+                else ubuf[nd.u_off + (ra[p] - m)] = u;
+            }
+            if (rb[p] < m) {
+                x[ORDERED ? nd.own0 + rb[p] : ix[rb[p]]] = s1;
+                if (f == m) push_down(ge, nd.nchild, f, rb[p], xb, s1);
+            } else if (rb[p] < f) {
+                const VT u = s_add(ub[p], s1);
+                if (nd.pacc_off >= 0) acc[nd.pacc_off + cb[p]] = u;
+                else ubuf[nd.u_off + (rb[p] - m)] = u;
+            }
         }
     }
 }
@@ -1112,45 +1146,6 @@ int upload(lsa_ctx* ctx, const std::vector<U>& h, U** d) {
     return LSA_OK;
 }
 
-// first-fit allocator over [0, inf) with coalescing free list, run on the host over the chunk order: the offsets it hands out
-// are the update arena's layout (a block lives from its node's chunk to its parent's), its high-water mark the arena's size
-struct ArenaPlan {
-    std::vector<std::pair<int64_t, int64_t>> free_;  // (offset, size), sorted by offset
-    int64_t top = 0;                                  // high-water mark
-    int64_t alloc(int64_t size) {
-        if (size <= 0) return 0;
-        for (size_t i = 0; i < free_.size(); ++i)
-            if (free_[i].second >= size) {
-                const int64_t off = free_[i].first;
-                if (free_[i].second == size) free_.erase(free_.begin() + (int64_t)i);
-                else free_[i] = {off + size, free_[i].second - size};
-                return off;
-            }
-        if (!free_.empty() && free_.back().first + free_.back().second == top) {  // grow the block at the end
-            const int64_t off = free_.back().first;
-            top = off + size;
-            free_.pop_back();
-            return off;
-        }
-        const int64_t off = top;
-        top += size;
-        return off;
-    }
-    void release(int64_t off, int64_t size) {
-        if (size <= 0) return;
-        auto it = std::lower_bound(free_.begin(), free_.end(), std::make_pair(off, (int64_t)0));
-        it = free_.insert(it, {off, size});
-        if (it + 1 != free_.end() && it->first + it->second == (it + 1)->first) {
-            it->second += (it + 1)->second;
-            free_.erase(it + 1);
-        }
-        if (it != free_.begin() && (it - 1)->first + (it - 1)->second == it->first) {
-            (it - 1)->second += it->second;
-            free_.erase(it);
-        }
-    }
-};
-
 // device tables, the memory plan (packed factors, chunks of working fronts, update arena) and tile lists from the analysis
 int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     NdSymbolic& S = f->S;
@@ -1180,140 +1175,61 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         tiles.push_back(b);
         ++tl.count;
     };
-    auto is_xroot = [&](int32_t q) { return dist && S.kind[(size_t)q] != 2 && S.parent[(size_t)q] >= 0 && S.kind[(size_t)S.parent[(size_t)q]] == 2; };
-    // ---- packed factors, slot rows of the upward sweep ----
-    int64_t lrun = 0, urun = 0, arun = 0;
-    for (int32_t t = 0; t < nt; ++t) {  // every kept node, the other ranks' subtree roots included (they are children here)
-        NdNodeDev& nd = nodes[(size_t)t];
-        const int64_t m = S.m[(size_t)t], ff = S.f[(size_t)t], b = ff - m;
-        nd.front_off = 0;
-        nd.lfac_off = nd.ufac_off = 0;
-        if (S.kind[(size_t)t] != 3) {
-            nd.lfac_off = lrun;
-            nd.ufac_off = urun;
-            lrun += ff * m;
-            urun += m * b;
-        }
-        nd.upd_off = 0;
-        nd.u_off = S.u_off[(size_t)t];
-        nd.ge_off = S.ge_off[(size_t)t];
-        nd.acc_off = nd.pacc_off = -1;
-        nd.idx_off = (int32_t)S.idx_off[(size_t)t];
-        nd.cmap_off = S.cmap_off[(size_t)t];
-        nd.piv_off = S.piv_off[(size_t)t];
-        nd.own0 = m > 0 ? S.idx[(size_t)S.idx_off[(size_t)t]] : 0;
-        nd.m = (int32_t)m;
-        nd.f = (int32_t)ff;
-        nd.parent = S.parent[(size_t)t];
-        nd.nchild = S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t];
-    }
-    for (int32_t t = 0; t < nt; ++t) {
-        // push form unless a child's update vector arrives by all-gather (another rank's subtree root): then the node pulls
-        const int32_t c0 = S.child_ptr[(size_t)t], c1 = S.child_ptr[(size_t)t + 1];
-        bool pull = false;
-        for (int32_t cp = c0; cp < c1; ++cp) pull |= is_xroot(S.child_idx[(size_t)cp]);
-        if (c1 == c0 || pull || S.kind[(size_t)t] == 3) continue;
-        nodes[(size_t)t].acc_off = arun;
-        for (int32_t cp = c0; cp < c1; ++cp) nodes[(size_t)S.child_idx[(size_t)cp]].pacc_off = arun + (int64_t)(cp - c0) * S.f[(size_t)t];
-        arun += (int64_t)(c1 - c0) * S.f[(size_t)t];
-    }
-    f->lfac_entries = lrun;
-    f->ufac_entries = urun;
-    f->acc_entries = arun;
-    // ---- chunks: the nodes of a work level, larger pivot blocks first, cut where the working fronts would outgrow the arena ----
-    int64_t max_front = 1, max_level = 1;
-    for (int32_t l = 0; l < S.nlevels; ++l) {
-        int64_t sum = 0;
-        for (int32_t q = S.lvl_ptr[(size_t)l]; q < S.lvl_ptr[(size_t)l + 1]; ++q) {
-            const int64_t ff = S.f[(size_t)S.lvl_nodes[(size_t)q]];
-            sum += ff * ff;
-            max_front = std::max(max_front, ff * ff);
-        }
-        max_level = std::max(max_level, sum);
-    }
-    int64_t budget = max_level;
+    // ---- the memory plan (nd_symbolic.hip: host arithmetic on the analysis, also what lsa_nd_sym_memory reports) ----
+    int64_t budget = 0;
     {
         // a level is factored in one go while its fronts fit a quarter of what the packed factors leave free (LSA_ND_WORK_MB
         // overrides); a single front always has to fit
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
-        const int64_t after = (int64_t)free_b - (lrun + urun) * (int64_t)es;
-        int64_t cap = std::max<int64_t>(after / 4, (int64_t)256 << 20) / (int64_t)es;
-        if (const char* e = getenv("LSA_ND_WORK_MB")) cap = std::max<int64_t>(atoll(e), 1) * (1 << 20) / (int64_t)es;
-        budget = std::max(max_front, std::min(max_level, cap));
+        const int64_t after = (int64_t)free_b - S.factor_entries * (int64_t)es;
+        budget = std::max<int64_t>(after / 4, (int64_t)256 << 20) / (int64_t)es;
+        if (const char* e = getenv("LSA_ND_WORK_MB")) budget = std::max<int64_t>(atoll(e), 1) * (1 << 20) / (int64_t)es;
     }
+    NdMemoryPlan P;
+    nd_memory_plan(S, budget, P);
+    for (int32_t t = 0; t < nt; ++t) {  // every kept node, the other ranks' subtree roots included (they are children here)
+        NdNodeDev& nd = nodes[(size_t)t];
+        nd.front_off = P.work_off[(size_t)t];
+        nd.lfac_off = P.lfac_off[(size_t)t];
+        nd.ufac_off = P.ufac_off[(size_t)t];
+        nd.upd_off = P.upd_off[(size_t)t];
+        nd.u_off = S.u_off[(size_t)t];
+        nd.ge_off = S.ge_off[(size_t)t];
+        nd.acc_off = P.acc_off[(size_t)t];
+        nd.pacc_off = P.pacc_off[(size_t)t];
+        nd.idx_off = (int32_t)S.idx_off[(size_t)t];
+        nd.cmap_off = S.cmap_off[(size_t)t];
+        nd.piv_off = S.piv_off[(size_t)t];
+        nd.own0 = S.m[(size_t)t] > 0 ? S.idx[(size_t)S.idx_off[(size_t)t]] : 0;
+        nd.m = S.m[(size_t)t];
+        nd.f = S.f[(size_t)t];
+        nd.parent = S.parent[(size_t)t];
+        nd.nchild = S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t];
+    }
+    f->lfac_entries = P.lfac_entries;
+    f->ufac_entries = P.ufac_entries;
+    f->acc_entries = P.acc_entries;
+    f->work_entries = P.work_entries;
+    f->upd_entries = P.upd_entries;
+    f->xupd_slot = P.xupd_slot;
     f->chunks.clear();
-    std::vector<int32_t> chunk_nodes;  // node ids in chunk order
+    const std::vector<int32_t>& chunk_nodes = S.lvl_nodes;  // node ids in chunk order: the chunks cut the levels' lists
     std::vector<int32_t> chunk_of((size_t)nt, -1);
-    for (int32_t l = 0; l < S.nlevels; ++l) {
-        int64_t used = 0;
-        for (int32_t q = S.lvl_ptr[(size_t)l]; q < S.lvl_ptr[(size_t)l + 1]; ++q) {
-            const int32_t t = S.lvl_nodes[(size_t)q];
-            const int64_t ff = S.f[(size_t)t];
-            if (q == S.lvl_ptr[(size_t)l] || used + ff * ff > budget) {
-                NdChunk c;
-                c.node_begin = (int32_t)chunk_nodes.size();
-                c.exchange_before = dist && l == S.phase_b_level && q == S.lvl_ptr[(size_t)l];
-                f->chunks.push_back(c);
-                used = 0;
-            }
-            NdChunk& c = f->chunks.back();
-            nodes[(size_t)t].front_off = used;
-            used += ff * ff;
-            c.work_entries = used;
-            ++c.node_count;
-            c.max_m = std::max(c.max_m, S.m[(size_t)t]);
-            c.max_f = std::max(c.max_f, (int32_t)ff);
-            c.sorted_m.push_back(S.m[(size_t)t]);
-            chunk_of[(size_t)t] = (int32_t)f->chunks.size() - 1;
-            chunk_nodes.push_back(t);
+    for (size_t c = 0; c + 1 < P.chunk_begin.size(); ++c) {
+        NdChunk ch;
+        ch.node_begin = P.chunk_begin[c];
+        ch.node_count = P.chunk_begin[c + 1] - P.chunk_begin[c];
+        ch.work_entries = P.chunk_work[c];
+        ch.exchange_before = P.chunk_exchange_before[c] != 0;
+        for (int32_t q = 0; q < ch.node_count; ++q) {
+            const int32_t t = chunk_nodes[(size_t)ch.node_begin + q];
+            ch.max_m = std::max(ch.max_m, S.m[(size_t)t]);
+            ch.max_f = std::max(ch.max_f, S.f[(size_t)t]);
+            ch.sorted_m.push_back(S.m[(size_t)t]);
+            chunk_of[(size_t)t] = (int32_t)c;
         }
-    }
-    f->work_entries = 1;
-    for (const NdChunk& c : f->chunks) f->work_entries = std::max(f->work_entries, c.work_entries);
-    // ---- update arena: the subtree roots of the ranks in one slot per rank at its start (the exchange region of the in-place
-    // all-gather, laid out from what every rank knows: same order, same sizes), the rest by first fit over the chunk order ----
-    f->xupd_slot = 0;
-    if (dist) {
-        std::vector<int64_t> use((size_t)S.nranks, 0);
-        for (int32_t q = 0; q < nt; ++q)
-            if (is_xroot(q)) {
-                const int64_t b = S.f[(size_t)q] - S.m[(size_t)q];
-                const int32_t o = (int32_t)(S.front_off[(size_t)q] / std::max<int64_t>(S.xfront_slot, 1));  // owner: its slot of the logical layout
-                use[(size_t)o] += b * b;
-            }
-        for (int64_t v : use) f->xupd_slot = std::max(f->xupd_slot, v);
-        std::fill(use.begin(), use.end(), 0);
-        for (int32_t q = 0; q < nt; ++q)
-            if (is_xroot(q)) {
-                const int64_t b = S.f[(size_t)q] - S.m[(size_t)q];
-                const int32_t o = (int32_t)(S.front_off[(size_t)q] / std::max<int64_t>(S.xfront_slot, 1));
-                nodes[(size_t)q].upd_off = f->xupd_slot * o + use[(size_t)o];
-                use[(size_t)o] += b * b;
-            }
-    }
-    {
-        ArenaPlan arena;
-        const int64_t base = f->xupd_slot * S.nranks;
-        for (size_t ci = 0; ci < f->chunks.size(); ++ci) {
-            const NdChunk& c = f->chunks[ci];
-            for (int32_t q = 0; q < c.node_count; ++q) {  // blocks written by this chunk
-                const int32_t t = chunk_nodes[(size_t)c.node_begin + q];
-                const int64_t b = S.f[(size_t)t] - S.m[(size_t)t];
-                if (b > 0 && !is_xroot(t)) nodes[(size_t)t].upd_off = base + arena.alloc(b * b);
-            }
-            // blocks consumed by this chunk are free from the next chunk on.  (This chunk's own blocks were placed first: a
-            // block a parent reads in this chunk's extend-add must not be handed to a node that is saved in the same chunk.)
-            for (int32_t q = 0; q < c.node_count; ++q) {
-                const int32_t t = chunk_nodes[(size_t)c.node_begin + q];
-                for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) {
-                    const int32_t ch = S.child_idx[(size_t)cp];
-                    const int64_t b = S.f[(size_t)ch] - S.m[(size_t)ch];
-                    if (!is_xroot(ch)) arena.release(nodes[(size_t)ch].upd_off - base, b * b);
-                }
-            }
-        }
-        f->upd_entries = std::max<int64_t>(base + arena.top, 1);
+        f->chunks.push_back(std::move(ch));
     }
     // ---- assembly lists by chunk: front_buffer[work offset] = values[asm_src] ----
     {
@@ -1411,11 +1327,13 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         // thin separators (pivot blocks of a few dozen unknowns under fronts of a few hundred rows): the upward sweep reads
         // f short rows per node; four lanes per row pair and 128 rows per workgroup gather the node's vector 1/4 as often
         static const int32_t thin = getenv("LSA_ND_SWEEP_THIN") ? atoi(getenv("LSA_ND_SWEEP_THIN")) : 64;
+        // (64-row tiles -- NP = 2 of nd_fwd_kernel -- on the leaf level of the 500 k-unknown forest, 42 000 tiles: 900 us per solve
+        //  against 886 with 32-row tiles: no gain from sharing the gather, measured round 3)
         L.sweep_rows = tiles32 <= few ? 8 : (L.max_m <= thin && l > 0) ? 128 : kRT;
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
             L.fwd_tiles = std::max(L.fwd_tiles, (S.f[(size_t)t] + L.sweep_rows - 1) / L.sweep_rows);
-            const int32_t bwd_rows = L.sweep_rows == 8 ? 8 : kRT;  // (the downward sweep of a thin level has few, long rows: 32-row tiles)
+            const int32_t bwd_rows = L.sweep_rows == 8 ? 8 : kRT;  // (the downward sweep of a thin level has few, long rows: 32-row tiles; 32 as well where the upward sweep takes 64)
             if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.m[(size_t)t] + bwd_rows - 1) / bwd_rows);
         }
         if (L.fwd_tiles > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a front of more than %d rows is not supported", 65535 * 8);
@@ -1590,7 +1508,7 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
             LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_flag, 0, 4 * sizeof(int32_t), st));
             LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_maxabs, 0, sizeof(unsigned long long), st));
             if (S.nnz > 0) {
-                const int blocks = (int)std::min<int64_t>((S.nnz + 255) / 256, (int64_t)ctx->num_cu * 16);
+                const int blocks = (int)std::min<int64_t>((S.nnz + 255) / 256, (int64_t)ctx->num_cu * 2);
                 hipLaunchKernelGGL((nd_maxabs2_kernel<T>), dim3(blocks), dim3(256), 0, st, S.nnz, (const T*)C->val, f->d_maxabs);
             }
             unsigned long long mbits = 0;

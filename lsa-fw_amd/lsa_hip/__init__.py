@@ -142,6 +142,7 @@ SIGNATURES = {
     "lsa_nd_sym_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64),
                                        ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_DBL)]),
     "lsa_nd_sym_export": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    "lsa_nd_sym_memory": (ctypes.c_int, [_P, _I32, _I64, _P, _P, _P, _P]),
     "lsa_nd_sym_export_tables": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P]),
     "lsa_ndlu_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
     "lsa_ndlu_prepare": (ctypes.c_int, [_P, _P, ctypes.c_int, _I32, _P]),
@@ -596,6 +597,24 @@ class NdAnalysis:
                "level": np.empty(self.ntree, np.int32), "front_size": np.empty(self.ntree, np.int32), "idx": np.empty(self.index_entries, np.int32)}
         self._lib.lsa_nd_sym_export(self.handle, *[_ptr(out[k]) for k in ("perm", "node_start", "parent", "level", "front_size", "idx")])
         return out
+
+    def memory(self, scalar_bytes: int = 16, work_budget_bytes: int = 0, detail: bool = False) -> dict:
+        """Device memory a factorisation of this analysis allocates, in bytes (``lsa_nd_sym_memory``); with ``detail`` also the
+        per-node plan (update-arena and working-arena offsets in scalars, chunk of every node)."""
+        out = np.zeros(8, np.int64)
+        upd = np.zeros(self.ntree, np.int64) if detail else None
+        work = np.zeros(self.ntree, np.int64) if detail else None
+        chunk = np.full(self.ntree, -1, np.int32) if detail else None
+        rc = self._lib.lsa_nd_sym_memory(self.handle, int(scalar_bytes), int(work_budget_bytes), _ptr(out), None if upd is None else _ptr(upd),
+                                         None if work is None else _ptr(work), None if chunk is None else _ptr(chunk))
+        if rc != 0:
+            raise ValueError("lsa_nd_sym_memory: bad argument")
+        rec = {"factors": int(out[0]), "working_arena": int(out[1]), "update_arena": int(out[2]), "exchange_region": int(out[3]), "sweep_buffers": int(out[4]),
+               "chunks": int(out[5]), "largest_front": int(out[6]), "index_tables": int(out[7])}
+        rec["total"] = rec["factors"] + rec["working_arena"] + rec["update_arena"] + rec["sweep_buffers"] + rec["index_tables"]
+        if detail:
+            rec.update({"upd_off": upd, "work_off": work, "chunk_of": chunk})
+        return rec
 
     def export_tables(self) -> dict:
         """cmap, gptr, gidx, asm_dst, lvl_ptr, lvl_nodes (the tables the device kernels walk)."""

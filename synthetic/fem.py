@@ -506,6 +506,38 @@ def assemble_linearized_ns_3d(mesh: CubeMesh, re: float = 10.0, *, baseflow=duct
     return EigenSystem(A, M, np.flatnonzero(mask).astype(np.int32), dofs_p.astype(np.int32), ddofs.astype(np.int32), mesh, node_offset)
 
 
+def cube_pattern(n_cells: int) -> sp.csr_matrix:
+    """Sparsity pattern of :func:`assemble_linearized_ns_3d` on ``CubeMesh(n_cells)`` without the arithmetic (values all one):
+    two dofs are coupled iff their nodes share a tetrahedron (stored zeros included), same dof numbering.  What the pattern-only
+    analysis of the direct solver needs; minutes instead of hours at the size of BASELINE config 4 (58 cells: 4.9 M unknowns,
+    4.8e8 entries)."""
+    mesh = CubeMesh(n_cells)
+    tets = mesh.tetrahedra().astype(np.int64)
+    nn = mesh.n_nodes
+    keys = []
+    for a in range(10):  # node pairs sharing a tetrahedron, as sorted unique keys
+        keys.append(np.unique((tets[:, a][:, None] * nn + tets).ravel()))
+    key = np.unique(np.concatenate(keys))
+    del keys
+    na, nb = key // nn, key % nn
+    isv = mesh.is_vertex()
+    dpn = 3 + isv.astype(np.int64)  # dofs per node
+    node_offset = 3 * np.arange(nn, dtype=np.int64) + np.concatenate([[0], np.cumsum(isv)[:-1]])
+    n = int(3 * nn + isv.sum())
+    # node-level CSR (neighbours sorted), then every neighbour b expands into its dofs, every row of node a repeats that list
+    nptr = np.concatenate([[0], np.cumsum(np.bincount(na, minlength=nn))])
+    width = dpn[nb]
+    cptr = np.concatenate([[0], np.cumsum(width)])
+    cols_node = np.repeat(node_offset[nb] - cptr[:-1], width) + np.arange(cptr[-1])  # dofs of all neighbours, node row by node row
+    row_len_node = cptr[nptr[1:]] - cptr[nptr[:-1]]  # entries of one dof row of node a
+    rows_per_dof = np.repeat(row_len_node, dpn)
+    indptr = np.concatenate([[0], np.cumsum(rows_per_dof)])
+    start_node = np.repeat(cptr[nptr[:-1]], dpn)  # where the node's column list starts, per dof row
+    idx = np.repeat(start_node - indptr[:-1], rows_per_dof) + np.arange(indptr[-1])
+    indices = cols_node[idx].astype(np.int32)
+    return sp.csr_matrix((np.ones(len(indices), dtype=np.int8), indices, indptr.astype(np.int64 if indptr[-1] >= 2**31 else np.int32)), shape=(n, n))
+
+
 CUBE_CASES = {"C2k": 4, "C9k": 7, "C20k": 9, "C40k": 11, "C80k": 14, "C160k": 18, "C300k": 22, "C640k": 29, "C1M": 34, "C2M": 43, "C5M": 58}
 SIGMA_CUBE = -5.0  # shift of the 3D case: next to the least stable physical modes of the Re = 10 duct (-5.99, -6.00, -6.8, ...) and
 # away from the spurious lambda = 1 of the identity Dirichlet rows; real, so the factors are float64

@@ -121,3 +121,60 @@ def test_forest_cut_over_ranks_is_still_a_direct_solve(s5k, nranks):
     x = fp.rows.unpad_vector(xp)
     assert np.linalg.norm(Cp @ x - b) <= 1e-12 * np.linalg.norm(b)
     assert np.isnan(xp[fp.rows.pad_vector(np.ones(es.n)) == 0]).all()  # padding slots are never written
+
+
+@pytest.mark.parametrize("case,budget_mb,ranks", [("S5k", 0, 1), ("S5k", 1, 1), ("C2k", 1, 1), ("S5k", 1, 3)])
+def test_memory_plan_of_the_packed_factorisation(s5k, case, budget_mb, ranks):
+    """``lsa_nd_sym_memory``: the plan ``lsa_ndlu_create`` executes, computed on the host.  Packed factors = sum(m^2 + 2 m b); a
+    chunk's working fronts fit the budget (a single front always does) and do not overlap; an update matrix occupies its slot
+    of the arena from its node's chunk to its parent's, and no two live blocks overlap; with the forest cut over ranks the
+    subtree roots sit in the per-rank slots of the exchange region."""
+    es = fem.cube_case(case) if case.startswith("C") else s5k[0]
+    C = _shifted(es, fem.SIGMA_CUBE if case.startswith("C") else fem.SIGMA_RE50)
+    if ranks == 1:
+        ans = [lsa_hip.NdAnalysis(C, 64)]
+    else:
+        ex = lsa_hip.NdAnalysis(C, 64).export()
+        fp = sharding.partition_forest(ex["perm"], ex["node_start"], ex["parent"], ex["front_size"], ranks)
+        Cp = C[fp.order][:, fp.order].tocsr()
+        Cp.sort_indices()
+        tree = {"first": fp.first, "size": fp.size, "parent": fp.parent, "owner": fp.owner}
+        ans = [lsa_hip.NdAnalysis(sharding.pad_square(Cp, fp.rows), tree=tree, rank=r, nranks=ranks) for r in range(ranks)]
+    slots = set()
+    for an in ans:
+        sb = 16
+        mem = an.memory(sb, budget_mb << 20, detail=True)
+        t = an.export_tables()
+        m = np.diff(t["node_start"]).astype(np.int64)
+        f = t["front_size"].astype(np.int64)
+        b = f - m
+        kind, parent, chunk = t["kind"], t["parent"], mem["chunk_of"]
+        here = kind != 3
+        assert mem["factors"] == int((m * m + 2 * m * b)[here].sum()) * sb == an.factor_entries * sb
+        assert np.all(chunk[here] >= 0) and np.all(chunk[~here] == -1) and mem["chunks"] == chunk.max() + 1
+        assert mem["largest_front"] == int((f[here] ** 2).max()) * sb and mem["total"] > mem["factors"]
+        # working fronts: inside the arena, disjoint within a chunk, chunks within the budget unless a single front exceeds it
+        for c in range(mem["chunks"]):
+            nodes = np.flatnonzero(chunk == c)
+            order = nodes[np.argsort(mem["work_off"][nodes])]
+            ends = mem["work_off"][order] + f[order] ** 2
+            assert np.all(mem["work_off"][order][1:] >= ends[:-1]) and ends[-1] * sb <= mem["working_arena"]
+            if budget_mb and len(nodes) > 1:
+                assert ends[-1] * sb <= max(budget_mb << 20, mem["largest_front"])
+            assert len(set(t["level"][nodes])) == 1  # a chunk never mixes tree levels
+        assert np.all(np.diff(chunk[t["lvl_nodes"]]) >= 0)  # chunks follow the work order
+        # update matrices: alive from the node's chunk (a ghost root: from the start) to its parent's chunk
+        xroot = np.array([kind[q] != 2 and parent[q] >= 0 and kind[parent[q]] == 2 for q in range(len(kind))]) & (ranks > 1)
+        live = [(int(mem["upd_off"][q]), int(mem["upd_off"][q] + b[q] ** 2), int(chunk[q]) if chunk[q] >= 0 else -1, int(chunk[parent[q]]), q)
+                for q in range(len(kind)) if b[q] > 0 and parent[q] >= 0]
+        assert all(hi * sb <= mem["update_arena"] for _, hi, _, _, _ in live)
+        for i, (lo1, hi1, s1, e1, q1) in enumerate(live):
+            for lo2, hi2, s2, e2, q2 in live[i + 1:]:
+                if lo1 < hi2 and lo2 < hi1:  # same memory: the lifetimes must not meet
+                    assert e1 < s2 or e2 < s1, (q1, q2)
+        if ranks > 1:
+            assert mem["exchange_region"] > 0 and all(hi * sb <= mem["exchange_region"] for lo, hi, _, _, q in live if xroot[q])
+            slots.add(mem["exchange_region"])
+        else:
+            assert mem["exchange_region"] == 0
+    assert len(slots) <= 1  # every rank lays the exchange region out alike

@@ -13,7 +13,8 @@ last = rows[-n:]
 t0 = last[0][0]
 prev_end = None
 for s, e, k, g, w in last:
-    name = ("fwd" if "nd_fwd" in k else "bwd") + ("8" if ", 64>" in k else "32")
+    lpr = k.split("<")[1].split(",")[2].strip() if "<" in k else "16"
+    name = ("fwd" if "nd_fwd" in k else "bwd") + {"64": "8", "16": "32", "4": "128"}.get(lpr, "?")
     gap = 0 if prev_end is None else (s - prev_end) / 1e3
     print(f"{name:6s} wgs {g // w:7d}  {1e-3 * (e - s):8.2f} us  gap {gap:6.2f} us")
     prev_end = e

@@ -175,32 +175,97 @@ __device__ __forceinline__ unsigned long long pivot_key(double mag2, int32_t row
 // Columns are eliminated in blocks of kNB; inside a block in panels of W columns (W = 8 for pivot blocks of up to 2048 rows,
 // narrower for taller ones so that a thread's rows of the panel stay in registers).  Rows are never interchanged: a row
 // that has served as a pivot is excluded from later searches (rowq), the permutation is undone by nd_unperm_kernel.
-//   panel launch    one workgroup per node, thread per row (RPT rows per thread): eliminates the panel's W columns and
-//                   stages the pivot rows' values in the other columns OF THE BLOCK;
-//   block update    rank-W update of the block's other columns (16 columns x 256 rows per workgroup);
-//   after the block the pivot rows' values in all other columns are staged (nd_gj_stage_kernel) and one rank-kNB product
+// ONE launch per panel (nd_gj_fused_kernel), grid (node, 1 + kNB / 16):
+//   workgroup y = 0   thread per row (RPT rows per thread): first brings the panel's W columns up to date with the rank-W
+//                     update of the PREVIOUS panel of the block, then eliminates them;
+//   workgroups y >= 1 apply that previous panel's rank-W update to a tile of 16 of the block's other columns, all rows:
+//                     A[i, c] = (i was a pivot row of the previous panel ? 0 : A[i, c]) + W_prev[i, :] Y_prev[:, c],  Y_prev =
+//                     the previous panel's pivot rows in these columns, read before the tile is touched.
+// A workgroup owns its columns for all rows, and the columns of the previous panel are read-only in the launch: no staging
+// buffer, no second launch per panel (round 2: panel launch + block-update launch, 2 x 157 launches of ~12 us in the
+// factorisation of the 30 k-unknown case).  After the block's last panel one launch of the tiles alone finishes the block;
+// then the pivot rows' values in all other columns are staged (nd_gj_stage_kernel) and one rank-kNB product
 //                   A[:, J] = (pivot row ? 0 : A[:, J]) + Wb Yb  updates the rest (nd_gj_gemm_kernel, 64 x 64 tiles):
 // the columns outside a block are touched once per kNB pivots instead of once per 8 (the update of a 6 000-row pivot block
 // streamed 1.1 GB per 8 pivots, and its panel did not fit the registers of one workgroup at W = 8).
 constexpr int kNB = 32;
 
+// k0 < 0: no panel in this launch (the tiles finish the block);  kprev < 0: no previous panel to apply
 template <typename T, int NT, int RPT, int W>
-__global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
+__global__ __launch_bounds__(NT) void nd_gj_fused_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
                                                          T* __restrict__ front, int32_t* __restrict__ ipiv, int32_t* __restrict__ rowq,
-                                                         int32_t kb, int32_t k0, int32_t* __restrict__ flag, double tiny2, T* __restrict__ ysm) {
+                                                         int32_t kb, int32_t k0, int32_t kprev, int32_t* __restrict__ flag, double tiny2) {
     __shared__ unsigned long long skey[W];
     __shared__ T prow_s[2][W];
     __shared__ int32_t prows[W];
+    __shared__ T yprev[W][16];
+    __shared__ int32_t pprev[W];
     const int32_t t = lvl_nodes[blockIdx.x];
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, ld = nd.f;
+    T* a = front + nd.front_off;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int32_t wp = kprev >= 0 ? min(W, m - kprev) : 0;  // columns of the previous panel in this node
+    if (blockIdx.y > 0) {
+        // ---- tile of 16 block columns: the previous panel's rank-W update, all rows ----
+        if (wp <= 0) return;
+        const int32_t cb = ((int32_t)blockIdx.y - 1) * 16 + (tid & 15);
+        const int32_t c = kb + cb;
+        const bool mine = cb < kNB && c < m && !(c >= kprev && c < kprev + wp) && !(k0 >= 0 && c >= k0 && c < k0 + W);
+        if (tid < W) pprev[tid] = tid < wp ? ipiv[nd.piv_off + kprev + tid] : -1;
+        __syncthreads();
+        for (int e = tid; e < 16 * W; e += NT) {  // (the column of entry e is that of thread e & 15 = tid & 15: NT is a multiple of 16)
+            const int j = e >> 4;
+            yprev[j][e & 15] = (mine && j < wp) ? a[(size_t)pprev[j] * ld + c] : scalar_traits<T>::zero();
+        }
+        __syncthreads();
+        if (!mine) return;
+        T y[W];
+#pragma unroll
+        for (int j = 0; j < W; ++j) y[j] = yprev[j][tid & 15];
+        // four rows per trip, their loads issued together (a trip is a chain of dependent loads; with 64 threads a tile of a
+        // 64-row pivot block would otherwise walk 16 of them one after the other)
+        constexpr int RL = NT / 16;
+        for (int32_t i0 = tid >> 4; i0 < m; i0 += 4 * RL) {
+            T cur[4], mult[4][W];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int32_t i = i0 + u * RL;
+                const T* ai = a + (size_t)min(i, m - 1) * ld;
+                cur[u] = ai[c];
+#pragma unroll
+                for (int j = 0; j < W; ++j) mult[u][j] = j < wp ? ai[kprev + j] : scalar_traits<T>::zero();
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int32_t i = i0 + u * RL;
+                if (i >= m) break;
+                bool is_piv = false;
+#pragma unroll
+                for (int j = 0; j < W; ++j) is_piv |= (i == pprev[j]);
+                T acc = is_piv ? scalar_traits<T>::zero() : cur[u];
+#pragma unroll
+                for (int j = 0; j < W; ++j) fma_acc(acc, mult[u][j], y[j]);
+                a[(size_t)i * ld + c] = acc;
+            }
+        }
+        return;
+    }
+    // ---- the panel ----
+    if (k0 < 0) return;
     const int32_t w = min(W, m - k0);
     if (w <= 0) return;
-    T* a = front + nd.front_off;
     int32_t* piv = ipiv + nd.piv_off;
     int32_t* rq = rowq + nd.piv_off;
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid < W) skey[tid] = 0ull;
+    if (tid < W) {
+        skey[tid] = 0ull;
+        pprev[tid] = tid < wp ? piv[kprev + tid] : -1;
+    }
+    __syncthreads();
+    if (wp > 0 && tid < W * W) {  // the previous panel's pivot rows in this panel's columns, before anything is overwritten
+        const int j = tid / W, cc = tid % W;
+        yprev[j][cc] = (j < wp && cc < w) ? a[(size_t)pprev[j] * ld + k0 + cc] : scalar_traits<T>::zero();
+    }
     T r[RPT][W];
     bool used[RPT];
 #pragma unroll
@@ -211,6 +276,26 @@ __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restri
         for (int c = 0; c < W; ++c) r[q][c] = (i < m && c < w) ? a[(size_t)i * ld + k0 + c] : scalar_traits<T>::zero();
     }
     __syncthreads();
+    if (wp > 0) {
+#pragma unroll
+        for (int q = 0; q < RPT; ++q) {
+            const int32_t i = tid + NT * q;
+            if (i >= m) continue;
+            bool is_piv = false;
+#pragma unroll
+            for (int j = 0; j < W; ++j) is_piv |= (i == pprev[j]);
+            T mult[W];
+#pragma unroll
+            for (int j = 0; j < W; ++j) mult[j] = j < wp ? a[(size_t)i * ld + kprev + j] : scalar_traits<T>::zero();
+#pragma unroll
+            for (int c = 0; c < W; ++c) {
+                T acc = is_piv ? scalar_traits<T>::zero() : r[q][c];
+#pragma unroll
+                for (int j = 0; j < W; ++j) fma_acc(acc, mult[j], yprev[j][c]);
+                r[q][c] = c < w ? acc : scalar_traits<T>::zero();
+            }
+        }
+    }
 #pragma unroll
     for (int jj = 0; jj < W; ++jj) {
         if (jj >= w) break;
@@ -275,53 +360,6 @@ __global__ __launch_bounds__(NT) void nd_gj_panel_kernel(const int32_t* __restri
             for (int j = 0; j < W; ++j)
                 if (j < w) a[(size_t)i * ld + k0 + j] = r[q][j];
         }
-    }
-    // the pivot rows' values in the block's other columns (untouched by this launch), for the block update
-    __syncthreads();
-    const int32_t nbw = min(kNB, m - kb);
-    T* yb = ysm + (size_t)t * (8 * kNB);
-    for (int32_t e = tid; e < w * nbw; e += NT) {
-        const int32_t j = e / nbw, c = e - j * nbw;
-        yb[j * kNB + c] = a[(size_t)prows[j] * ld + kb + c];
-    }
-}
-
-// rank-w update of the block's other columns: A[i, c] = (i is one of the panel's pivot rows ? 0 : A[i, c]) + W[i, :] Y[:, c]
-// grid: (node of the level, 16-column tile of the block, 256-row tile)
-template <typename T, int W>
-__global__ __launch_bounds__(256) void nd_gj_block_update_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
-                                                                 T* __restrict__ front, const int32_t* __restrict__ ipiv, int32_t kb, int32_t k0,
-                                                                 const T* __restrict__ ysm) {
-    const int32_t t = lvl_nodes[blockIdx.x];
-    const NdNodeDev nd = nodes[t];
-    const int32_t m = nd.m, ld = nd.f;
-    const int32_t w = min(W, m - k0);
-    const int32_t r0 = (int32_t)blockIdx.z * 256;
-    const int tid = threadIdx.x;
-    const int32_t cb = (int32_t)blockIdx.y * 16 + (tid & 15);  // column inside the block
-    const int32_t c = kb + cb;
-    if (w <= 0 || r0 >= m || cb >= kNB || c >= m || (c >= k0 && c < k0 + w)) return;
-    T* a = front + nd.front_off;
-    const T* yb = ysm + (size_t)t * (8 * kNB);
-    int32_t pr[W];
-    T y[W];
-#pragma unroll
-    for (int j = 0; j < W; ++j) {
-        pr[j] = j < w ? ipiv[nd.piv_off + k0 + j] : -1;
-        y[j] = j < w ? yb[j * kNB + cb] : scalar_traits<T>::zero();
-    }
-    const int32_t r1 = min(m, r0 + 256);
-#pragma unroll 4
-    for (int32_t i = r0 + (tid >> 4); i < r1; i += 16) {
-        T* ai = a + (size_t)i * ld;
-        bool is_piv = false;
-#pragma unroll
-        for (int j = 0; j < W; ++j) is_piv |= (i == pr[j]);
-        T acc = is_piv ? scalar_traits<T>::zero() : ai[c];
-#pragma unroll
-        for (int j = 0; j < W; ++j)
-            if (j < w) fma_acc(acc, ai[k0 + j], y[j]);
-        ai[c] = acc;
     }
 }
 
@@ -1111,7 +1149,7 @@ struct lsa_ndlu {
     void *d_lfac = nullptr, *d_ufac = nullptr;  // packed factors (resident)
     void *d_work = nullptr, *d_upd = nullptr;   // working fronts of one chunk; live update matrices
     void *d_ubuf = nullptr, *d_xb = nullptr, *d_acc = nullptr;  // sweeps: update vectors (pull form), boundary vectors, slot rows (push form)
-    void *d_tmp = nullptr, *d_ybuf = nullptr, *d_ysm = nullptr;
+    void *d_tmp = nullptr, *d_ybuf = nullptr;
     int64_t lfac_entries = 0, ufac_entries = 0, work_entries = 0, upd_entries = 0, acc_entries = 0;
     int64_t xupd_slot = 0;                     // subtree-parallel: scalars per rank in the exchange region at the start of the update arena
     int32_t *d_cand[2] = {nullptr, nullptr};  // tournament pivoting: candidate rows, two buffers used in turn
@@ -1130,7 +1168,7 @@ void nd_free(lsa_ndlu* f) {
     if (!f) return;
     for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
                     (void*)f->d_chunk_nodes, (void*)f->d_asm_dst, (void*)f->d_asm_src, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_xflag, (void*)f->d_maxabs,
-                    f->d_lfac, f->d_ufac, f->d_work, f->d_upd, f->d_ubuf, f->d_xb, f->d_acc, f->d_tmp, f->d_ybuf, f->d_ysm, (void*)f->d_cand[0], (void*)f->d_cand[1], f->d_dinv})
+                    f->d_lfac, f->d_ufac, f->d_work, f->d_upd, f->d_ubuf, f->d_xb, f->d_acc, f->d_tmp, f->d_ybuf, (void*)f->d_cand[0], (void*)f->d_cand[1], f->d_dinv})
         if (p) (void)hipFree(p);
     if (f->ev_panel) (void)hipEventDestroy(f->ev_panel);
     if (f->ev_pivots) (void)hipEventDestroy(f->ev_pivots);
@@ -1368,7 +1406,6 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_xb, 0, ub, ctx->stream));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_tmp, nn * 16));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ybuf, nn * kNB * es));
-    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ysm, (size_t)std::max(nt, 1) * 8 * kNB * es));
     if (widest_tp > 0) {
         const size_t cand = ((size_t)S.n / kTRmin + (size_t)nt + 1) * kNB * sizeof(int32_t);
         LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[0], cand));
@@ -1399,15 +1436,20 @@ void launch_block(lsa_ctx* ctx, lsa_ndlu* f, const NdChunk& L, int32_t kb, doubl
         return (int32_t)(std::lower_bound(L.sorted_m.begin(), L.sorted_m.end(), k, std::greater<int32_t>()) - L.sorted_m.begin());
     };
     const int32_t kend = std::min(kb + kNB, L.max_m);
+    const bool others = std::min(kNB, L.max_m - kb) > W;  // the block has columns besides one panel
+    int32_t kprev = -1, active_prev = 0;
     for (int32_t k0 = kb; k0 < kend; k0 += W) {
         const int32_t active = active_at(k0);
         if (active == 0) break;
-        hipLaunchKernelGGL((nd_gj_panel_kernel<T, NT, RPT, W>), dim3(active), dim3(NT), 0, st, lv, f->d_nodes, front, f->d_ipiv, f->d_rowq, kb, k0, f->d_flag,
-                           tiny2, (T*)f->d_ysm);
-        if (std::min(kNB, L.max_m - kb) > W)  // the block has columns besides this panel
-            hipLaunchKernelGGL((nd_gj_block_update_kernel<T, W>), dim3(active, kNB / 16, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, front,
-                               f->d_ipiv, kb, k0, (const T*)f->d_ysm);
+        // (the tiles of this launch serve the nodes that had the previous panel: a superset of those that have this one)
+        hipLaunchKernelGGL((nd_gj_fused_kernel<T, NT, RPT, W>), dim3(std::max(active, active_prev), others && kprev >= 0 ? 1 + kNB / 16 : 1), dim3(NT), 0, st, lv,
+                           f->d_nodes, front, f->d_ipiv, f->d_rowq, kb, k0, kprev, f->d_flag, tiny2);
+        kprev = k0;
+        active_prev = active;
     }
+    if (others && kprev >= 0)  // the last panel's update of the block's other columns
+        hipLaunchKernelGGL((nd_gj_fused_kernel<T, NT, RPT, W>), dim3(active_prev, 1 + kNB / 16), dim3(NT), 0, st, lv, f->d_nodes, front, f->d_ipiv, f->d_rowq, kb,
+                           -1, kprev, f->d_flag, tiny2);
     if (L.max_m > kNB) {  // columns outside the block exist (in the larger nodes)
         const int32_t active = active_at(kb);
         hipLaunchKernelGGL((nd_gj_stage_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, kb,

@@ -710,6 +710,9 @@ def main() -> None:
         }
         if world == 1 and not args.no_other_pc:
             for name, fn in (("two_solves_in_flight", lambda: solves_in_flight(es, sigma, args, device)),
+                             # (three is the most one GPU takes: with four the solves' streams outnumber the hardware queues and
+                             #  the rate falls below that of two -- tools/micro/jobs_in_flight.py: 385 / 589 / 756 / 483 at J = 1..4)
+                             ("three_solves_in_flight", lambda: solves_in_flight(es, sigma, args, device, jobs=3)),
                              ("lu_apply", lambda: lu_apply_rate(es, sigma, device)),
                              ("sptrsv_roofline", lambda: sptrsv_roofline(args, device)),
                              ("pattern_3d", lambda: roofline_3d(args, device))):

@@ -101,6 +101,7 @@ void dissect(const Graph& g, int32_t leaf, std::vector<std::vector<int32_t>>& ow
     // so a loose bound buys small separators with a lopsided, deeper forest -- and every level of the forest is one dependent
     // launch per sweep of every solve.  Planar meshes: 40 (30 k unknowns: 10 levels instead of 12 for 4 % more factor
     // entries; 120 k: 13 instead of 16); 3D meshes, whose solves stream gigabytes per level: 30.  LSA_ND_BALANCE overrides.
+    const bool use_index_cut = !(getenv("LSA_ND_INDEX_CUT") && atoi(getenv("LSA_ND_INDEX_CUT")) == 0);
     const int64_t balance = getenv("LSA_ND_BALANCE") ? std::max(1, std::min(49, atoi(getenv("LSA_ND_BALANCE")))) : (g.ptr[(size_t)n] > 60 * (int64_t)n ? 30 : 40);
     auto emit = [&](std::vector<int32_t>&& verts, int32_t par) {
         own.push_back(std::move(verts));
@@ -206,6 +207,47 @@ void dissect(const Graph& g, int32_t leaf, std::vector<std::vector<int32_t>>& ow
                     touches = region[w] == rid && lev[w] == k + 1;
                 }
                 (touches ? sep : left).push_back(v);
+            }
+        }
+        if (use_index_cut) {
+            // Second candidate: cut the region's unknowns at the median of their INDICES; the separator is the lower half's
+            // side of the cut (its vertices with a neighbour in the upper half).  Meshes reach the library in numberings that
+            // keep neighbours close (lexicographic, or bandwidth-reducing: dolfinx reorders by default), and there an index cut
+            // is a plane across the shortest extent of the numbering's sweep -- while the level sets of a breadth-first search
+            // from a corner of a 3D box are L-shaped shells of up to twice a cross-section's size (the root separator of the
+            // 5 M-unknown cube: 82 731 unknowns against 44 500 of a coordinate plane).  The smaller separator wins, so the
+            // search-based cut still takes over wherever the index cut is poor (long thin regions cut along their length).
+            std::vector<int32_t> sorted(verts);
+            std::sort(sorted.begin(), sorted.end());
+            const int32_t midv = sorted[sorted.size() / 2];
+            int64_t nsep = 0, nlow = 0;
+            for (int32_t v : sorted) {
+                if (v >= midv) break;
+                ++nlow;
+                bool touches = false;
+                for (int64_t p = g.ptr[v]; p < g.ptr[(size_t)v + 1] && !touches; ++p) {
+                    const int32_t w = g.adj[(size_t)p];
+                    touches = region[w] == rid && w >= midv;
+                }
+                nsep += touches;
+            }
+            const int64_t nup = total - nlow;
+            if (nsep > 0 && nsep < (int64_t)sep.size() && std::min(nlow - nsep, nup) * 100 >= total * balance) {
+                sep.clear();
+                left.clear();
+                right.clear();
+                for (int32_t v : sorted) {
+                    if (v >= midv) {
+                        right.push_back(v);
+                        continue;
+                    }
+                    bool touches = false;
+                    for (int64_t p = g.ptr[v]; p < g.ptr[(size_t)v + 1] && !touches; ++p) {
+                        const int32_t w = g.adj[(size_t)p];
+                        touches = region[w] == rid && w >= midv;
+                    }
+                    (touches ? sep : left).push_back(v);
+                }
             }
         }
         const int32_t s = emit(std::move(sep), it.parent);

@@ -97,8 +97,9 @@ def main(argv: list[str] | None = None) -> None:
     ap.add_argument("--jobs", type=int, default=1,
                     help="Reynolds numbers in flight on the GPU at once (threads, one HIP context and stream set each). One "
                          "solve is a chain of dependent launches that leaves most of an MI355X idle: two in flight deliver "
-                         "1.5x the eigenpairs per second (DESIGN.md section 6), and the host-side loading and ordering of "
-                         "one case hides behind the GPU work of the other.")
+                         "1.5x, three 2x the eigenpairs per second; four oversubscribe the hardware queues and fall back "
+                         "below two (DESIGN.md section 6).  The host-side loading and ordering of one case hides behind the "
+                         "GPU work of the others.")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO)
     if args.synthesize:
@@ -115,7 +116,7 @@ def main(argv: list[str] | None = None) -> None:
 
         # every solve drives up to four streams; the runtime's default of four hardware queues per process would
         # serialise two solves on the same queues (read when the first HIP context is created)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(4 * args.jobs))
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # (more than eight queues per GPU slow everything down: DESIGN.md section 6)
         with ThreadPoolExecutor(max_workers=args.jobs) as pool:
             for fut in [pool.submit(solve_case, args.save_dir, re, target) for re, target in cases]:
                 fut.result()

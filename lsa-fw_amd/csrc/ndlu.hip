@@ -363,21 +363,31 @@ __global__ __launch_bounds__(NT) void nd_gj_fused_kernel(const int32_t* __restri
     }
 }
 
-// Yb[j][c] = A[pivot row of column kb + j][c] for the nb columns of the finished block: the rows the product below needs,
-// staged because that product overwrites them.  grid: (node, 256-column chunk)
+// Yb[j][c] = A[pivot row of column kb + j][c] for the kw columns of a finished block (or super-block, tournament path), columns
+// c in [c_lo, c_hi): the rows the product below needs, staged because that product overwrites them.
+// grid: (node, 256-column chunk of the window);  ycap = rows of staging space per unknown
 template <typename T>
 __global__ __launch_bounds__(256) void nd_gj_stage_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
-                                                          const T* __restrict__ front, const int32_t* __restrict__ ipiv, int32_t kb,
-                                                          T* __restrict__ ybuf) {
+                                                          const T* __restrict__ front, const int32_t* __restrict__ ipiv, int32_t kb, int32_t kw,
+                                                          int32_t ycap, int32_t c_lo, int32_t c_hi, T* __restrict__ ybuf) {
     const int32_t t = lvl_nodes[blockIdx.x];
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, ld = nd.f;
-    const int32_t nb = min(kNB, m - kb);
-    const int32_t c = (int32_t)blockIdx.y * 256 + threadIdx.x;
-    if (nb <= 0 || m <= kNB || c >= m) return;
+    const int32_t nb = min(kw, m - kb);
+    const int32_t c = c_lo + (int32_t)blockIdx.y * 256 + threadIdx.x;
+    if (nb <= 0 || m <= kNB || c >= min(m, c_hi)) return;
     const T* a = front + nd.front_off;
-    T* yb = ybuf + (size_t)kNB * nd.piv_off;
-    for (int32_t j = 0; j < nb; ++j) yb[(size_t)j * m + c] = a[(size_t)ipiv[nd.piv_off + kb + j] * ld + c];
+    T* yb = ybuf + (size_t)ycap * nd.piv_off;
+    const int32_t* pv = ipiv + nd.piv_off + kb;
+    int32_t j = 0;
+    for (; j + 4 <= nb; j += 4) {  // (independent loads, issued together)
+        const T v0 = a[(size_t)pv[j] * ld + c], v1 = a[(size_t)pv[j + 1] * ld + c], v2 = a[(size_t)pv[j + 2] * ld + c], v3 = a[(size_t)pv[j + 3] * ld + c];
+        yb[(size_t)j * m + c] = v0;
+        yb[(size_t)(j + 1) * m + c] = v1;
+        yb[(size_t)(j + 2) * m + c] = v2;
+        yb[(size_t)(j + 3) * m + c] = v3;
+    }
+    for (; j < nb; ++j) yb[(size_t)j * m + c] = a[(size_t)pv[j] * ld + c];
 }
 
 // the columns outside the finished block: A[i, c] = (i is a pivot row of the block ? 0 : A[i, c]) + sum_j Wb[i, j] Yb[j, c]
@@ -757,6 +767,214 @@ __global__ __launch_bounds__(256) void nd_gemm_kernel(const int32_t* __restrict_
             else *c = acc[i][j];
         }
     }
+}
+
+// The same three products on the matrix cores: v_mfma_f64_16x16x4_f64, one wavefront per 32 x 32 quarter of the 64 x 64 tile
+// (2 x 2 instruction tiles; complex scalars as real and imaginary planes, four instructions per complex tile product).
+// The vector kernel above reads 8 LDS values per 16 multiply-adds and is bound by the LDS array at about a third of the FP64
+// rate; here a k-step of 4 costs a wavefront 4 LDS reads for 4 (real) or 16 (complex) instructions of 64 cycles each.
+// Operand maps (cdna_hip_programming.md, "Fragment layout"): lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15]; result
+// register r of lane l is C[(l >> 4) + 4 r][l & 15].
+// LDS images: A row-major with a row of BK + 1 doubles (16 rows x 2 k per half-wave: 32 distinct bank pairs), B k-major with a
+// row of 64 + 16 doubles (two k-rows of a half-wave land 32 banks apart).  The next K-chunk's global loads are issued into
+// registers before the current chunk's products (one LDS buffer, two barriers per chunk).
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double plane_of(double v, int) { return v; }
+__device__ __forceinline__ double plane_of(cplx v, int p) { return p == 0 ? v.re : v.im; }
+
+template <typename T>
+struct MfmaTile {
+    static constexpr int BK = 16, LDAS = BK + 1, LDBS = kGT + 16, NPL = (int)(sizeof(T) / sizeof(double));
+    double As[NPL][kGT * LDAS];
+    double Bs[NPL][BK * LDBS];
+};
+
+// acc += A B over k in [0, K) for the 64 x 64 tile of a 256-thread workgroup: loadA(r, k) = A[tile row r][k], loadB(k, c) =
+// B[k][tile column c], both zero outside their matrix.  On return wavefront w holds rows 32 (w >> 1) .., columns 32 (w & 1) ..:
+// acc[plane][i][j][r] = C[32 (w >> 1) + 16 i + (lane >> 4) + 4 r][32 (w & 1) + 16 j + (lane & 15)]
+template <typename T, typename FA, typename FB>
+__device__ __forceinline__ void mfma_tile_product(int32_t K, FA loadA, FB loadB, MfmaTile<T>& sm, mfma_d4 (&acc)[MfmaTile<T>::NPL][2][2]) {
+    constexpr int BK = MfmaTile<T>::BK, LDAS = MfmaTile<T>::LDAS, LDBS = MfmaTile<T>::LDBS, NPL = MfmaTile<T>::NPL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1), l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[p][i][j] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+    // chunk staging: thread e = tid + 256 s;  A element (row e >> 4, k e & 15): 16 lanes along a row;  B element (k e >> 6, column e & 63)
+    T pa[4], pb[4];
+    auto gload = [&](int32_t kk) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int e = tid + 256 * s;
+            pa[s] = loadA(e >> 4, kk + (e & 15));
+            pb[s] = loadB(kk + (e >> 6), e & 63);
+        }
+    };
+    gload(0);
+    for (int32_t kk = 0; kk < K; kk += BK) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int e = tid + 256 * s;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                sm.As[p][(e >> 4) * LDAS + (e & 15)] = plane_of(pa[s], p);
+                sm.Bs[p][(e >> 6) * LDBS + (e & 63)] = plane_of(pb[s], p);
+            }
+        }
+        __syncthreads();
+        if (kk + BK < K) gload(kk + BK);
+#pragma unroll
+        for (int k4 = 0; k4 < BK; k4 += 4) {
+            if (kk + k4 >= K) break;  // (zero-filled beyond K: skipping is only cheaper)
+            double a[NPL][2], bb[NPL][2];
+#pragma unroll
+            for (int p = 0; p < NPL; ++p)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    a[p][i] = sm.As[p][(wr + 16 * i + l15) * LDAS + k4 + l4];
+                    bb[p][i] = sm.Bs[p][(k4 + l4) * LDBS + wc + 16 * i + l15];
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], bb[0][j], acc[0][i][j], 0, 0, 0);
+                    if constexpr (NPL == 2) {
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[NPL - 1][i], bb[NPL - 1][j], acc[0][i][j], 0, 0, 0);
+                        acc[NPL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][i], bb[NPL - 1][j], acc[NPL - 1][i][j], 0, 0, 0);
+                        acc[NPL - 1][i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[NPL - 1][i], bb[0][j], acc[NPL - 1][i][j], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T, int KIND>
+__global__ __launch_bounds__(256) void nd_gemm_mfma_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
+                                                           T* __restrict__ front, T* __restrict__ lfac, T* __restrict__ ufac) {
+    constexpr int NPL = MfmaTile<T>::NPL;
+    __shared__ MfmaTile<T> sm;
+    const int32_t t = tiles[2 * blockIdx.x], packed = tiles[2 * blockIdx.x + 1];
+    const int32_t tm = packed >> 16, tn = packed & 0xFFFF;
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, f = nd.f, b = f - m;
+    T* F = front + nd.front_off;
+    T* inv = lfac + nd.lfac_off;
+    T* S1 = inv + (size_t)m * m;
+    T* S2 = ufac + nd.ufac_off;
+    const T *A, *B;
+    T* C;
+    int32_t M, N, K, lda, ldb, ldc;
+    if (KIND == 0) {
+        A = F + (size_t)m * f, lda = f, B = inv, ldb = m, C = S1, ldc = m, M = b, N = m, K = m;
+    } else if (KIND == 1) {
+        A = S1, lda = m, B = F + m, ldb = f, C = F + (size_t)m * f + m, ldc = f, M = b, N = b, K = m;
+    } else {
+        A = inv, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = m, N = b, K = m;
+    }
+    const int32_t row0 = tm * kGT, col0 = tn * kGT;
+    mfma_d4 acc[NPL][2][2];
+    mfma_tile_product<T>(
+        K,
+        [&](int r, int32_t k) {
+            const int32_t gr = row0 + r;
+            return (gr < M && k < K) ? A[(size_t)gr * lda + k] : scalar_traits<T>::zero();
+        },
+        [&](int32_t k, int c) {
+            const int32_t gc = col0 + c;
+            return (k < K && gc < N) ? B[(size_t)k * ldb + gc] : scalar_traits<T>::zero();
+        },
+        sm, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1), l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int32_t gr = row0 + wr + 16 * i + l4 + 4 * r;
+            if (gr >= M) continue;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int32_t gc = col0 + wc + 16 * j + l15;
+                if (gc >= N) continue;
+                T v;
+                s_from(v, acc[0][i][j][r], acc[NPL - 1][i][j][r]);
+                T* c = C + (size_t)gr * ldc + gc;
+                if (KIND == 0) *c = s_sub(scalar_traits<T>::zero(), v);
+                else if (KIND == 1) *c = s_add(*c, v);
+                else *c = v;
+            }
+        }
+}
+
+// Gauss-Jordan, tournament path: the columns outside a finished group of kw <= kSB pivot columns [kb, kb + kw) of every node,
+//          A[i, c] = (i is a pivot row of the group ? 0 : A[i, c]) + sum_j W[i, j] Y[j, c],
+// W = the group's own columns (final), Y[j, :] = the row that was the pivot of column kb + j, staged BEFORE this launch
+// (nd_gj_stage_kernel; stride ycap rows per unknown).  The group is one block of kNB columns -- then the window is the rest of
+// its super-block -- or a whole super-block of kSB: the elimination of a block multiplies the matrix from the left by a
+// matrix that differs from the identity only in the columns of its pivot rows, so does the product over the blocks of a
+// super-block, and the super-block's own columns hold exactly those columns once its blocks have updated one another.  The
+// rank-kNB update of a 6 700-row pivot block streamed the block through HBM once per 32 pivots (4 flops per byte: 9 TFLOP/s);
+// at rank kSB = 128 the product is bound by the matrix cores.
+// grid: (node, 64-row tile, 64-column tile from ztile0).  Column windows as in nd_gj_gemm_kernel, whose invariant on rowq
+// holds here unchanged (rows that become pivots of a LATER block while this runs read as "not a pivot row of the group").
+constexpr int kSB = 128;
+template <typename T>
+__global__ __launch_bounds__(256) void nd_gj_update_kernel(const int32_t* __restrict__ lvl_nodes, const NdNodeDev* __restrict__ nodes,
+                                                           T* __restrict__ front, const int32_t* rowq, int32_t kb, int32_t kw,
+                                                           const T* __restrict__ ybuf, int32_t ycap, int32_t only_lo, int32_t only_hi,
+                                                           int32_t skip_lo, int32_t skip_hi, int32_t ztile0) {
+    constexpr int NPL = MfmaTile<T>::NPL;
+    __shared__ MfmaTile<T> sm;
+    const int32_t t = lvl_nodes[blockIdx.x];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, ld = nd.f;
+    const int32_t nb = min(kw, m - kb);
+    const int32_t row0 = (int32_t)blockIdx.y * kGT, col0 = ((int32_t)blockIdx.z + ztile0) * kGT;
+    if (nb <= 0 || row0 >= m || col0 >= m) return;
+    if (col0 >= kb && col0 + kGT <= kb + nb) return;  // tile inside the group
+    if (only_hi > only_lo && (col0 >= only_hi || col0 + kGT <= only_lo)) return;
+    if (col0 >= skip_lo && col0 + kGT <= skip_hi) return;
+    T* a = front + nd.front_off;
+    const T* yb = ybuf + (size_t)ycap * nd.piv_off;
+    const int32_t* rq = rowq + nd.piv_off;
+    mfma_d4 acc[NPL][2][2];
+    mfma_tile_product<T>(
+        nb,
+        [&](int r, int32_t k) {
+            const int32_t gr = row0 + r;
+            return (gr < m && k < nb) ? a[(size_t)gr * ld + kb + k] : scalar_traits<T>::zero();
+        },
+        [&](int32_t k, int c) {
+            const int32_t gc = col0 + c;
+            return (k < nb && gc < m) ? yb[(size_t)k * m + gc] : scalar_traits<T>::zero();
+        },
+        sm, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = 32 * (wave >> 1), wc = 32 * (wave & 1), l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int32_t gr = row0 + wr + 16 * i + l4 + 4 * r;
+            if (gr >= m) continue;
+            const int32_t q = rq[gr];
+            const bool is_piv = q >= kb && q < kb + nb;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int32_t gc = col0 + wc + 16 * j + l15;
+                if (gc >= m || (gc >= kb && gc < kb + nb)) continue;
+                if ((gc >= skip_lo && gc < skip_hi) || (only_hi > only_lo && (gc < only_lo || gc >= only_hi))) continue;
+                T v;
+                s_from(v, acc[0][i][j][r], acc[NPL - 1][i][j][r]);
+                T* cptr = a + (size_t)gr * ld + gc;
+                *cptr = is_piv ? v : s_add(*cptr, v);
+            }
+        }
 }
 
 // the update matrix leaves the working front for the update arena (tile = 16 rows of the b x b block)
@@ -1155,6 +1373,9 @@ struct lsa_ndlu {
     int32_t *d_cand[2] = {nullptr, nullptr};  // tournament pivoting: candidate rows, two buffers used in turn
     void* d_dinv = nullptr;                    // ... the inverted pivot tile of every node of the chunk being eliminated
     int32_t tp_min = 1 << 30;                  // chunks whose tallest pivot block has at least this many rows use it
+    int32_t sb_min = 1 << 30;                  // ... and from this many rows on, with super-blocks of kSB columns (nd_gj_update_kernel)
+    int32_t sb_cols = 128;                     // columns of a super-block (kSB; LSA_ND_SB_COLS, a multiple of 64, for measurements)
+    int32_t ycap = 32;                         // rows of d_ybuf per unknown: kNB, or sb_cols when a chunk works in super-blocks
     hipStream_t side = nullptr;                // ... the next block's tournament runs here, under the current block's update
     hipEvent_t ev_panel = nullptr, ev_pivots = nullptr;
     double seconds_analyse = 0.0, seconds_numeric = 0.0;
@@ -1193,6 +1414,11 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     {
         const char* e = getenv("LSA_ND_TP_MIN");
         f->tp_min = e && *e ? std::max(1, atoi(e)) : 384;
+        const char* sbm = getenv("LSA_ND_SB_MIN");
+        f->sb_min = std::max(f->tp_min, sbm && *sbm ? std::max(1, atoi(sbm)) : 1024);
+        f->ycap = kNB;
+        const char* sbc = getenv("LSA_ND_SB_COLS");
+        f->sb_cols = sbc && *sbc ? std::min(1024, std::max(kGT, atoi(sbc) / kGT * kGT)) : kSB;
     }
     // (the status word of the subtree-parallel form first: ranks agree on a failed set-up through it, lsa_ndlu_create_tree)
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_xflag, 4 * sizeof(int32_t) * (size_t)std::max(1, S.nranks)));
@@ -1326,6 +1552,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         begin_list(c.unperm);
         for (int32_t q = 0; q < c.node_count; ++q)
             for (int32_t r0 = 0; r0 < S.m[(size_t)node(q)]; r0 += 16) push(c.unperm, node(q), r0);
+        static const bool xcd_order = !(getenv("LSA_ND_XCD_ORDER") && atoi(getenv("LSA_ND_XCD_ORDER")) == 0);  // (A/B measurement aid)
         for (int kind = 0; kind < 3; ++kind) {
             begin_list(c.gemm[kind]);
             for (int32_t q = 0; q < c.node_count; ++q) {
@@ -1333,8 +1560,33 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
                 const int32_t m = S.m[(size_t)t], b = S.f[(size_t)t] - m;
                 if (b == 0) continue;
                 const int32_t M = kind == 2 ? m : b, N = kind == 0 ? m : b;
-                for (int32_t tm = 0; tm * kGT < M; ++tm)
-                    for (int32_t tn = 0; tn * kGT < N; ++tn) push(c.gemm[kind], t, (tm << 16) | tn);
+                const int32_t TM = (M + kGT - 1) / kGT, TN = (N + kGT - 1) / kGT;
+                if ((int64_t)TM * TN < 512 || !xcd_order) {
+                    for (int32_t tm = 0; tm < TM; ++tm)
+                        for (int32_t tn = 0; tn < TN; ++tn) push(c.gemm[kind], t, (tm << 16) | tn);
+                    continue;
+                }
+                // A large product: consecutive workgroups go to the 8 XCDs in turn (launch index mod 8 labels the workgroups
+                // that share an L2), and row-major order would hand every L2 one tile in eight of a dozen tile rows -- each
+                // workgroup then streams its own 64 x K and K x 64 panels, 8 flops per byte from beyond the L2.  Here the
+                // workgroups of one label stay inside one band of tile rows and walk it in super-tiles of 8 x 16 tiles (about
+                // what an XCD holds in flight): at any k they share 8 + 16 panel chunks instead of reading 2 x 128.
+                std::vector<int32_t> seq[8];
+                for (int x = 0; x < 8; ++x) {
+                    const int32_t r0 = (int32_t)((int64_t)TM * x / 8), r1 = (int32_t)((int64_t)TM * (x + 1) / 8);
+                    if (r1 <= r0) continue;
+                    const int32_t sh = std::min(r1 - r0, 8), sw = std::max(1, 128 / sh);
+                    for (int32_t rb = r0; rb < r1; rb += sh)
+                        for (int32_t cb = 0; cb < TN; cb += sw)
+                            for (int32_t r = rb; r < std::min(rb + sh, r1); ++r)
+                                for (int32_t cc = cb; cc < std::min(cb + sw, TN); ++cc) seq[x].push_back((r << 16) | cc);
+                }
+                size_t pos[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int64_t left = (int64_t)TM * TN; left > 0; --left) {
+                    int x = (int)(c.gemm[kind].count % 8);
+                    for (int tries = 0; tries < 8 && pos[x] >= seq[x].size(); ++tries) x = (x + 1) % 8;  // (a band ran out: help the next)
+                    push(c.gemm[kind], t, seq[x][pos[x]++]);
+                }
             }
         }
         begin_list(c.save);
@@ -1346,6 +1598,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
             return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a pivot block of %d rows exceeds the 16 384 the panel kernels hold in registers (LSA_ND_TP_MIN = %d)",
                                  c.max_m, f->tp_min);
         if (c.max_m >= f->tp_min) widest_tp = std::max(widest_tp, c.node_count);
+        if (c.max_m >= f->sb_min) f->ycap = f->sb_cols;
     }
     // ---- sweep levels ----
     f->levels.assign((size_t)S.nlevels, NdLevel());
@@ -1405,7 +1658,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
     LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_ubuf, 0, ub, ctx->stream));
     LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_xb, 0, ub, ctx->stream));
     LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_tmp, nn * 16));
-    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ybuf, nn * kNB * es));
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_ybuf, nn * (size_t)f->ycap * es));
     if (widest_tp > 0) {
         const size_t cand = ((size_t)S.n / kTRmin + (size_t)nt + 1) * kNB * sizeof(int32_t);
         LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_cand[0], cand));
@@ -1453,7 +1706,7 @@ void launch_block(lsa_ctx* ctx, lsa_ndlu* f, const NdChunk& L, int32_t kb, doubl
     if (L.max_m > kNB) {  // columns outside the block exist (in the larger nodes)
         const int32_t active = active_at(kb);
         hipLaunchKernelGGL((nd_gj_stage_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, kb,
-                           (T*)f->d_ybuf);
+                           kNB, kNB, 0, L.max_m, (T*)f->d_ybuf);
         const int32_t tiles = (L.max_m + kGT - 1) / kGT;
         hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, tiles), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb, (const T*)f->d_ybuf, 0, 0,
                            0, 0, 0);
@@ -1501,32 +1754,48 @@ int launch_level_tp(lsa_ctx* ctx, lsa_ndlu* f, const NdChunk& L, double tiny2) {
     // Measured: C300k 472 -> 438 ms, C160k 186 -> 183 ms; S500k, tallest pivot block 838 rows, 56 -> 59 ms without this limit)
     const int32_t ahead_min = getenv("LSA_ND_LOOKAHEAD_MIN") ? atoi(getenv("LSA_ND_LOOKAHEAD_MIN")) : 1024;
     const bool ahead = side != nullptr && L.max_m >= std::max(ahead_min, 2 * kNB + 1);
+    // super-blocks of kSB columns where the pivot blocks are large (see nd_gj_update_kernel); elsewhere a "super-block" is one block
+    const bool wide = L.max_m >= f->sb_min;
+    const int32_t sbw = wide ? f->sb_cols : kNB, ycap = f->ycap;
+    const int32_t tiles = (L.max_m + kGT - 1) / kGT;
+    auto stage = [&](int32_t active, int32_t k0, int32_t kw, int32_t c_lo, int32_t c_hi) {
+        hipLaunchKernelGGL((nd_gj_stage_kernel<T>), dim3(active, (c_hi - c_lo + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, k0, kw,
+                           ycap, c_lo, c_hi, (T*)f->d_ybuf);
+    };
+    auto update = [&](int32_t active, int32_t k0, int32_t kw, int32_t zt0, int32_t ztn, int32_t only_lo, int32_t only_hi, int32_t skip_lo, int32_t skip_hi) {
+        hipLaunchKernelGGL((nd_gj_update_kernel<T>), dim3(active, tiles, ztn), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, k0, kw, (const T*)f->d_ybuf,
+                           ycap, only_lo, only_hi, skip_lo, skip_hi, zt0);
+    };
     launch_tournament<T>(f, L, 0, tiny2, st);
-    for (int32_t kb = 0; kb < L.max_m; kb += kNB) {
-        const int32_t active = active_at(kb);
-        if (active == 0) break;
-        hipLaunchKernelGGL((nd_tp_colblock_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb,
-                           (const T*)f->d_dinv);
-        const int32_t next = kb + kNB;
+    for (int32_t sb0 = 0; sb0 < L.max_m; sb0 += sbw) {
+        const int32_t sb1 = std::min(sb0 + sbw, L.max_m);
+        if (active_at(sb0) == 0) break;
+        for (int32_t kb = sb0; kb < sb1; kb += kNB) {
+            const int32_t active = active_at(kb);
+            if (active == 0) break;
+            hipLaunchKernelGGL((nd_tp_colblock_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb,
+                               (const T*)f->d_dinv);
+            if (sb1 - sb0 > kNB) {  // the super-block's other columns (earlier blocks' included), so that its next block can be searched
+                stage(active, kb, kNB, sb0, sb1);
+                update(active, kb, kNB, sb0 / kGT, (sb1 + kGT - 1) / kGT - sb0 / kGT, sb0, sb1, 0, 0);
+                if (kb + kNB < sb1 && active_at(kb + kNB) > 0) launch_tournament<T>(f, L, kb + kNB, tiny2, st);
+            }
+        }
+        const int32_t active = active_at(sb0), next = sb1;
         const bool has_next = next < L.max_m && active_at(next) > 0;
-        if (L.max_m > kNB) {
-            hipLaunchKernelGGL((nd_gj_stage_kernel<T>), dim3(active, (L.max_m + 255) / 256), dim3(256), 0, st, lv, f->d_nodes, (const T*)front, f->d_ipiv, kb,
-                               (T*)f->d_ybuf);
-            const int32_t tiles = (L.max_m + kGT - 1) / kGT;
+        if (L.max_m > sb1 - sb0) {  // columns outside the super-block exist (in the larger nodes)
+            stage(active, sb0, sb1 - sb0, 0, L.max_m);
             if (has_next && ahead) {
-                hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, 1), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb, (const T*)f->d_ybuf,
-                                   next, next + kNB, 0, 0, next / kGT);
+                update(active, sb0, sb1 - sb0, next / kGT, 1, next, next + kNB, 0, 0);
                 LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_panel, st));
                 LSA_HIP_CHECK(ctx, hipStreamWaitEvent(side, f->ev_panel, 0));
                 launch_tournament<T>(f, L, next, tiny2, side);
                 LSA_HIP_CHECK(ctx, hipEventRecord(f->ev_pivots, side));
-                hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, tiles), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb,
-                                   (const T*)f->d_ybuf, 0, 0, next, next + kNB, 0);
+                update(active, sb0, sb1 - sb0, 0, tiles, 0, 0, next, next + kNB);
                 LSA_HIP_CHECK(ctx, hipStreamWaitEvent(st, f->ev_pivots, 0));
                 continue;
             }
-            hipLaunchKernelGGL((nd_gj_gemm_kernel<T>), dim3(active, tiles, tiles), dim3(256), 0, st, lv, f->d_nodes, front, f->d_rowq, kb, (const T*)f->d_ybuf,
-                               0, 0, 0, 0, 0);
+            update(active, sb0, sb1 - sb0, 0, tiles, 0, 0, 0, 0);
         }
         if (has_next) launch_tournament<T>(f, L, next, tiny2, st);
     }
@@ -1599,12 +1868,20 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
         if (L.unperm.count > 0)
             hipLaunchKernelGGL((nd_unperm_kernel<T>), dim3(L.unperm.count), dim3(256), 0, st, tl + 2 * L.unperm.off, f->d_nodes, (const T*)front, f->d_ipiv,
                                f->d_rowq, lfac);
-        if (L.gemm[0].count > 0)
-            hipLaunchKernelGGL((nd_gemm_kernel<T, 0>), dim3(L.gemm[0].count), dim3(256), 0, st, tl + 2 * L.gemm[0].off, f->d_nodes, front, lfac, ufac);
-        if (L.gemm[1].count > 0)
-            hipLaunchKernelGGL((nd_gemm_kernel<T, 1>), dim3(L.gemm[1].count), dim3(256), 0, st, tl + 2 * L.gemm[1].off, f->d_nodes, front, lfac, ufac);
-        if (L.gemm[2].count > 0)
-            hipLaunchKernelGGL((nd_gemm_kernel<T, 2>), dim3(L.gemm[2].count), dim3(256), 0, st, tl + 2 * L.gemm[2].off, f->d_nodes, front, lfac, ufac);
+        static const bool vector_gemm = getenv("LSA_ND_GEMM") && !strcmp(getenv("LSA_ND_GEMM"), "vector");  // (A/B measurement aid)
+#define LSA_ND_GEMM_LAUNCH(KIND)                                                                                                              \
+    if (L.gemm[KIND].count > 0) {                                                                                                             \
+        if (vector_gemm)                                                                                                                      \
+            hipLaunchKernelGGL((nd_gemm_kernel<T, KIND>), dim3(L.gemm[KIND].count), dim3(256), 0, st, tl + 2 * L.gemm[KIND].off, f->d_nodes,  \
+                               front, lfac, ufac);                                                                                            \
+        else                                                                                                                                  \
+            hipLaunchKernelGGL((nd_gemm_mfma_kernel<T, KIND>), dim3(L.gemm[KIND].count), dim3(256), 0, st, tl + 2 * L.gemm[KIND].off,         \
+                               f->d_nodes, front, lfac, ufac);                                                                                \
+    }
+        LSA_ND_GEMM_LAUNCH(0)
+        LSA_ND_GEMM_LAUNCH(1)
+        LSA_ND_GEMM_LAUNCH(2)
+#undef LSA_ND_GEMM_LAUNCH
         if (L.save.count > 0)
             hipLaunchKernelGGL((nd_save_update_kernel<T>), dim3(L.save.count), dim3(256), 0, st, tl + 2 * L.save.off, f->d_nodes, (const T*)front, upd);
     }

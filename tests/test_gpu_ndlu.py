@@ -294,3 +294,34 @@ def test_ndlu_lookahead_two_stream_path(hip_ctx, monkeypatch):
         xs.append(_solve(hip_ctx, f, b))
         assert np.linalg.norm(C @ xs[-1] - b) <= 1e-11 * np.linalg.norm(b)
     assert np.array_equal(xs[0], xs[1])
+
+
+@pytest.mark.parametrize("case,sigma,leaf", [("S30k", SIGMA, 600), ("C20k", -5.0 + 0.5j, 0), ("C9k", -5.0, 128)])
+def test_ndlu_super_blocks_of_128_pivot_columns(hip_ctx, monkeypatch, case, sigma, leaf):
+    """Large pivot blocks (1024 rows and more by default, ``LSA_ND_SB_MIN``) are inverted in super-blocks of 128 columns: rank-32
+    updates stay inside the super-block, everything outside it is updated once per 128 pivots by a product on the matrix
+    cores (``nd_gj_update_kernel``).  Forced onto small fronts here (partial last super-blocks, real and complex factors, with
+    and without the second-stream look-ahead): SuperLU's answer, and the look-ahead changes no bit."""
+    import lsa_hip
+    from oracle import fem
+
+    monkeypatch.setenv("LSA_ND_TP_MIN", "64")
+    monkeypatch.setenv("LSA_ND_SB_MIN", "130")
+    monkeypatch.setenv("LSA_ND_NO_CACHE", "1")
+    if case.startswith("C"):
+        es = fem.cube_case(case)
+        C = sp.csr_matrix((es.A.data - sigma * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+    else:
+        es, C = _shifted(case, sigma)
+    rng = np.random.default_rng(12)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    xref = spla.splu(sp.csc_matrix(C.astype(np.complex128))).solve(b)
+    xs = []
+    for ahead in ("100000", "131"):
+        monkeypatch.setenv("LSA_ND_LOOKAHEAD_MIN", ahead)
+        f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, C), leaf)
+        assert f.info()["max_front"] > 260  # (several super-blocks in the largest pivot blocks)
+        xs.append(_solve(hip_ctx, f, b))
+        assert np.linalg.norm(C @ xs[-1] - b) <= 1e-12 * np.linalg.norm(b)
+        assert np.linalg.norm(xs[-1] - xref) <= 1e-10 * np.linalg.norm(xref)
+    assert np.array_equal(xs[0], xs[1])

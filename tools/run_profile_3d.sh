@@ -4,7 +4,7 @@ cd /root/repo
 export TMPDIR=/tmp
 case=${1:-C300k}
 mkdir -p gpurun_out/r3_prof
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3_prof/$case -- python3 tools/bench_ndlu.py --case $case --refactors 2 > gpurun_out/r3_prof/$case.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3_prof/$case -- python3 tools/bench_ndlu.py --case $case --refactors ${2:-2} > gpurun_out/r3_prof/$case.log 2>&1
 f=$(find gpurun_out/r3_prof/$case -name '*kernel_stats.csv' | head -1)
 cp $f gpurun_out/r3_prof/${case}_kernel_stats.csv
 rm -rf gpurun_out/r3_prof/$case

@@ -267,8 +267,16 @@ extern "C" int lsa_csr_axpby(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* B, c
     if (A->n != B->n || A->nnz != B->nnz || A->ncols != B->ncols || A->row0 != B->row0)
         return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_csr_axpby: operands must share one sparsity pattern (n %d vs %d, nnz %lld vs %lld)",
                              A->n, B->n, (long long)A->nnz, (long long)B->nnz);
-    if (A->h_rp != B->h_rp || A->h_ci != B->h_ci)
-        return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_csr_axpby: operands must share one sparsity pattern (index arrays differ)");
+    if (!A->h_rp.same_object(B->h_rp) || !A->h_ci.same_object(B->h_ci)) {
+        // compared entry by entry once; from then on B shares A's host copy (and its hash), and the next call -- one per
+        // eigen-solve -- sees one object
+        if (A->h_rp != B->h_rp || A->h_ci != B->h_ci)
+            return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_csr_axpby: operands must share one sparsity pattern (index arrays differ)");
+        B->h_rp = A->h_rp;
+        B->h_ci = A->h_ci;
+        if (!A->h_hash) A->h_hash = B->h_hash ? B->h_hash : std::make_shared<uint64_t>(0);
+        B->h_hash = A->h_hash;
+    }
     if (out_dtype == LSA_F64 && (A->dtype != LSA_F64 || B->dtype != LSA_F64 || alpha[1] != 0.0 || beta[1] != 0.0))
         return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_csr_axpby: a real result needs real operands and real coefficients");
     lsa_mat* C = new lsa_mat();
@@ -283,6 +291,8 @@ extern "C" int lsa_csr_axpby(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* B, c
     C->owns_index = false;
     C->h_rp = A->h_rp;
     C->h_ci = A->h_ci;
+    if (!A->h_hash) A->h_hash = std::make_shared<uint64_t>(0);
+    C->h_hash = A->h_hash;
     C->val = nullptr;
     hipError_t e = hipMalloc(&C->val, (size_t)(C->nnz > 0 ? C->nnz : 1) * dtype_size(out_dtype));
     if (e != hipSuccess) {

@@ -495,7 +495,7 @@ int lsa_ilu_create(lsa_ctx* ctx, const lsa_mat* C, int levels, double shift_tol,
     pc->tmp_dtype = -1;
     pc->nshift = 0;
     pc->algo = 1;
-    int rc = symbolic_iluk(ctx, C->n, C->h_rp, C->h_ci, levels, pc->h_rp, pc->h_ci, pc->h_diag);
+    int rc = symbolic_iluk(ctx, C->n, C->h_rp.vec(), C->h_ci.vec(), levels, pc->h_rp, pc->h_ci, pc->h_diag);
     if (rc != LSA_OK) {
         delete pc;
         return rc;

@@ -2074,6 +2074,16 @@ int lsa_ndlu_refactor(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
     return rc;
 }
 
+// nd_pattern_hash of a matrix's host pattern, kept with the (shared) pattern
+static uint64_t mat_pattern_hash(const lsa_mat* P) {
+    if (!P->h_hash) P->h_hash = std::make_shared<uint64_t>(0);
+    if (*P->h_hash == 0) {
+        const uint64_t h = nd_pattern_hash(P->n, P->h_rp.data(), P->h_ci.data());
+        *P->h_hash = h ? h : 1;
+    }
+    return *P->h_hash;
+}
+
 // analysis + device tables + buffers for the pattern of P and factors of type `dtype`; taken from the context's cache
 // when the parked factorisation matches
 // (strict: the parked analysis must also have been made for the same set of constraint unknowns)
@@ -2100,7 +2110,7 @@ static int nd_symbolic_phase(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t 
         // (an analysis parked with the caller's tree -- lsa_ndlu_prepare_tree -- stands for its pattern whatever the leaf size)
         if (c->S.n == P->n && c->S.nnz == P->nnz && c->dtype == dtype && c->S.nranks == 1 && (c->S.tree_hash != 0 || c->S.leaf_size == leaf_size) &&
             (!strict || c->S.constraint_hash == want) &&
-            c->S.pattern_hash == nd_pattern_hash(P->n, P->h_rp.data(), P->h_ci.data())) {
+            c->S.pattern_hash == mat_pattern_hash(P)) {
             ctx->nd_cache = nullptr;
             c->seconds_analyse = 0.0;
             *out = c;
@@ -2229,7 +2239,7 @@ int lsa_ndlu_create_tree(lsa_ctx* ctx, const lsa_mat* C, int32_t ntree, const in
         mix(ctx->rank);
         mix(ctx->nranks);
         if (c->S.tree_hash == (h | 1ull) && c->S.n == C->n && c->S.nnz == C->nnz && c->dtype == C->dtype &&
-            c->S.pattern_hash == nd_pattern_hash(C->n, C->h_rp.data(), C->h_ci.data())) {
+            c->S.pattern_hash == mat_pattern_hash(C)) {
             f = c;
             ctx->nd_cache = nullptr;
             f->seconds_analyse = 0.0;

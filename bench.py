@@ -478,6 +478,12 @@ def main() -> None:
         _cpu_worker(args)
         return
 
+    # Standard output carries the ONE JSON line and nothing else: whatever a library prints there while the bench runs (gloo's
+    # connection banner in a rehearsal, a runtime's notices) is sent to standard error instead.
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -757,7 +763,7 @@ def main() -> None:
                                          else "slower than the exact LU by %.0fx" % (out["value"] / max(opc_rec["eigenpairs_per_s"], 1e-300)))
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
-        print(json.dumps(out), flush=True)
+        os.write(line_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

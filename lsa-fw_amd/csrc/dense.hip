@@ -176,13 +176,21 @@ __attribute__((target("avx2,fma"))) void rot_pair_avx2(int len, double* __restri
                                                        double* __restrict__ yi, double c, double sr, double si) {
     LSA_ROT_BODY
 }
+__attribute__((target("avx512f,avx512dq,fma"), min_vector_width(512))) void rot_pair_avx512(int len, double* __restrict__ xr, double* __restrict__ xi,
+                                                                                             double* __restrict__ yr, double* __restrict__ yi, double c,
+                                                                                             double sr, double si) {
+    LSA_ROT_BODY
+}
 #endif
 #undef LSA_ROT_BODY
 typedef void (*rot_pair_fn)(int, double*, double*, double*, double*, double, double, double);
 rot_pair_fn pick_rot_pair() {
 #if !defined(__HIP_DEVICE_COMPILE__)
     __builtin_cpu_init();
-    if (__builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) return rot_pair_avx2;
+    const char* isa = getenv("LSA_DENSE_ISA");  // "avx2" / "generic": measurement aid
+    const bool want512 = !isa || !strcmp(isa, "avx512"), want256 = want512 || !strcmp(isa, "avx2");
+    if (want512 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("fma")) return rot_pair_avx512;
+    if (want256 && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma")) return rot_pair_avx2;
 #endif
     return rot_pair_generic;
 }

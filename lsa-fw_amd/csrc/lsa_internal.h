@@ -159,7 +159,7 @@ struct lsa_mat {
     mutable int32_t* cbase = nullptr;
     mutable int ci16_state = 0;
     // row groups for the SpMV (built on first use): consecutive rows with one and the same column pattern (the unknowns of
-    // a mesh node) share their column indices and their gathers of x; grp_start[g] .. grp_start[g + 1] are the rows of
+    // a mesh node) share their column indices and their gathers of x; grp_start holds (first row, rows, first entry, entries per row) of
     // group g (at most 4).  grp_state: 0 = not tried, 1 = available, -1 = not worth it (mean group size < 1.5)
     mutable int32_t* grp_start = nullptr;
     mutable int32_t ngroups = 0;

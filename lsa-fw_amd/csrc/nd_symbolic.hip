@@ -1029,6 +1029,13 @@ int lsa_nd_sym_memory(const lsa_nd_sym* h, int32_t scalar_bytes, int64_t work_bu
     out[5] = (int64_t)P.chunk_begin.size() - 1;                // chunks
     out[6] = P.max_front_entries * scalar_bytes;               // the largest front
     out[7] = (int64_t)(S.idx.size() + S.gell.size() + S.cmap.size()) * 4 + (int64_t)S.asm_src.size() * 12 + (int64_t)S.nt * 96 * 2;  // index tables
+    {
+        // ... and the per-unknown staging of the elimination: pivot rows of a finished block (32 rows per unknown; 128 where the
+        // pivot blocks are inverted in super-blocks, from 1 024 rows on by default), pivot maps, one vector
+        int32_t max_m = 0;
+        for (int32_t t = 0; t < S.nt; ++t) max_m = std::max(max_m, S.m[(size_t)t]);
+        out[7] += (int64_t)S.n * ((max_m >= 1024 ? 128 : 32) * scalar_bytes + 8 + 16);
+    }
     if (upd_off) std::copy(P.upd_off.begin(), P.upd_off.end(), upd_off);
     if (work_off) std::copy(P.work_off.begin(), P.work_off.end(), work_off);
     if (chunk_of)

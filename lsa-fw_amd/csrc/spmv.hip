@@ -144,8 +144,25 @@ __global__ __launch_bounds__(256) void spmv_subwave16_kernel(int32_t n, const in
 // XCD: workgroup b runs on XCD b % 8 (observed dispatch order; speed only), each with its own L2.  With groups interleaved
 // over workgroups every XCD gathers the whole of x; here workgroup b takes the contiguous chunk of groups number
 // (b % 8) * (G / 8) + b / 8, so an XCD walks one eighth of the rows and touches one eighth of x (plus the band).
+// sum over the 16 lanes of a DPP row, returned to every lane of it (quad_perm, row_half_mirror, row_mirror)
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_mov(double v) {
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)bits & 0xFFFFFFFFull), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)bits >> 32), CTRL, 0xF, 0xF, false);
+    return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_row_mov<0xB1>(v);
+    v += dpp_row_mov<0x4E>(v);
+    v += dpp_row_mov<0x141>(v);
+    v += dpp_row_mov<0x140>(v);
+    return v;
+}
+__device__ __forceinline__ cplx row16_sum(cplx v) { return cplx{row16_sum(v.re), row16_sum(v.im)}; }
+
 template <typename MT, typename VT, int LPR, bool C16, bool XCD>
-__global__ __launch_bounds__(256) void spmv_group_kernel(int32_t ngroups, int32_t chunk, const int2* __restrict__ gstart,
+__global__ __launch_bounds__(256) void spmv_group_kernel(int32_t ngroups, int32_t chunk, const int4* __restrict__ gstart,
                                                          const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                          const uint16_t* __restrict__ ci16, const int32_t* __restrict__ cbase,
                                                          const MT* __restrict__ val, const VT* __restrict__ x, VT* __restrict__ y) {
@@ -159,9 +176,8 @@ __global__ __launch_bounds__(256) void spmv_group_kernel(int32_t ngroups, int32_
         gend = min((int64_t)ngroups, (vb + 1) * chunk);
     }
     for (; grp < gend; grp += stride) {
-        const int2 gr = gstart[grp];
-        const int32_t r0 = gr.x, g = gr.y;
-        const int32_t p0 = rp[r0], len = rp[r0 + 1] - p0;
+        const int4 gr = gstart[grp];  // (first row, rows, first entry, entries per row): one load, no second trip to the row pointers
+        const int32_t r0 = gr.x, g = gr.y, p0 = gr.z, len = gr.w;
         const VT* xr = x;
         if constexpr (C16) xr += cbase[r0];
         VT acc[4] = {scalar_traits<VT>::zero(), scalar_traits<VT>::zero(), scalar_traits<VT>::zero(), scalar_traits<VT>::zero()};
@@ -182,8 +198,11 @@ __global__ __launch_bounds__(256) void spmv_group_kernel(int32_t ngroups, int32_
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < g) {
+                if constexpr (LPR == 16) acc[k] = row16_sum(acc[k]);  // a sub-wave of 16 is a DPP row: no trip through the LDS crossbar
+                else {
 #pragma unroll
-                for (int m = LPR / 2; m > 0; m >>= 1) acc[k] = s_add(acc[k], shfl_xor_t<VT>(acc[k], m));
+                    for (int m = LPR / 2; m > 0; m >>= 1) acc[k] = s_add(acc[k], shfl_xor_t<VT>(acc[k], m));
+                }
             }
         }
         if (lane == 0) {
@@ -218,7 +237,7 @@ static bool ensure_groups(const lsa_mat* A) {
     if ((double)n / (double)ng < 1.5) return false;
     // (first row, rows) per group; optionally ordered by row length (LSA_SPMV_SORT=1): the four sub-waves of a wavefront then
     // walk rows of one length instead of waiting for the longest of four
-    std::vector<int32_t> pairs((size_t)ng * 2);
+    std::vector<int32_t> pairs((size_t)ng * 4);
     std::vector<int32_t> order((size_t)ng);
     for (int32_t q = 0; q < ng; ++q) order[(size_t)q] = q;
     if (const char* e = getenv("LSA_SPMV_SORT"))
@@ -227,8 +246,11 @@ static bool ensure_groups(const lsa_mat* A) {
                 return A->h_rp[(size_t)gs[(size_t)x] + 1] - A->h_rp[gs[(size_t)x]] > A->h_rp[(size_t)gs[(size_t)y] + 1] - A->h_rp[gs[(size_t)y]];
             });
     for (int32_t q = 0; q < ng; ++q) {
-        pairs[(size_t)2 * q] = gs[(size_t)order[(size_t)q]];
-        pairs[(size_t)2 * q + 1] = gs[(size_t)order[(size_t)q] + 1] - gs[(size_t)order[(size_t)q]];
+        const int32_t r0 = gs[(size_t)order[(size_t)q]];
+        pairs[(size_t)4 * q] = r0;
+        pairs[(size_t)4 * q + 1] = gs[(size_t)order[(size_t)q] + 1] - r0;
+        pairs[(size_t)4 * q + 2] = A->h_rp[r0];
+        pairs[(size_t)4 * q + 3] = A->h_rp[(size_t)r0 + 1] - A->h_rp[r0];
     }
     gs.swap(pairs);
     if (hipMalloc((void**)&A->grp_start, gs.size() * sizeof(int32_t)) != hipSuccess) return false;
@@ -331,15 +353,15 @@ static void launch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y, 
         if ((variant & 0x8000) && !c16 && A->ngroups >= 8 * 64) {
             const int G = ((gblocks + 7) / 8) * 8;
             const int32_t chunk = (A->ngroups + G - 1) / G;
-            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false, true>), dim3(G), dim3(threads), 0, ctx->stream, A->ngroups, chunk, (const int2*)A->grp_start, A->rp,
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false, true>), dim3(G), dim3(threads), 0, ctx->stream, A->ngroups, chunk, (const int4*)A->grp_start, A->rp,
                                A->ci, (const uint16_t*)nullptr, (const int32_t*)nullptr, (const MT*)A->val, (const VT*)x, (VT*)y);
             return;
         }
         if (c16)
-            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, true, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, 0, (const int2*)A->grp_start, A->rp,
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, true, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, 0, (const int4*)A->grp_start, A->rp,
                                A->ci, (const uint16_t*)A->ci16, (const int32_t*)A->cbase, (const MT*)A->val, (const VT*)x, (VT*)y);
         else
-            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, 0, (const int2*)A->grp_start, A->rp,
+            hipLaunchKernelGGL((spmv_group_kernel<MT, VT, LPR, false, false>), dim3(gblocks), dim3(threads), 0, ctx->stream, A->ngroups, 0, (const int4*)A->grp_start, A->rp,
                                A->ci, (const uint16_t*)nullptr, (const int32_t*)nullptr, (const MT*)A->val, (const VT*)x, (VT*)y);
         return;
     }

@@ -656,6 +656,88 @@ int k_multi_axpy(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64
     return check_launch(ctx, "multi_axpy");
 }
 
+// First projection and second dot product of CGS2 in ONE pass over the basis (long vectors: the basis does not fit the caches,
+// every pass streams j n scalars from HBM -- 0.43 ms of a 1.35 ms Arnoldi step at 500 k unknowns with four passes):
+//     w <- w - V h,      partial[c * ntiles + tile] = sum over the tile's 64 rows of conj(V[i, c]) w_i (updated).
+// Workgroup = 64 rows; wavefront q holds the columns q, q + 4, ... of those rows in registers (lane = row: 1 KB per load
+// instruction), adds up its share of V h, the four shares meet in LDS, and the columns still in registers give the dot products.
+template <typename T, int KMAX>
+__global__ __launch_bounds__(kThreads) void cgs_axpy_dot_kernel(int64_t n, int j, const T* __restrict__ V, int64_t ldv, const T* __restrict__ h,
+                                                                T* __restrict__ w, T* __restrict__ partial, int64_t ntiles) {
+    __shared__ T accs[4][64];
+    __shared__ T hs[4 * KMAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = threadIdx.x; c < j; c += kThreads) hs[c] = h[c];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+    const bool in = i < n;
+    T v[KMAX];
+    T acc = scalar_traits<T>::zero();
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int c = wave + 4 * k;
+        v[k] = (in && c < j) ? V[i + (int64_t)c * ldv] : scalar_traits<T>::zero();
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int c = wave + 4 * k;
+        if (c < j) fma_acc(acc, hs[c], v[k]);
+    }
+    accs[wave][lane] = acc;
+    __syncthreads();
+    T wi = scalar_traits<T>::zero();
+    if (in) wi = s_sub(w[i], s_add(s_add(accs[0][lane], accs[1][lane]), s_add(accs[2][lane], accs[3][lane])));
+    if (wave == 0 && in) w[i] = wi;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int c = wave + 4 * k;
+        if (c >= j) continue;  // (uniform over the wavefront)
+        T p = scalar_traits<T>::zero();
+        fma_conj_acc(p, v[k], wi);
+        p = wave_sum_dpp(p);
+        if (lane == 0) partial[(int64_t)c * ntiles + blockIdx.x] = p;
+    }
+}
+
+// h[c] = sum over thousands of tile partials: one workgroup of 1 024 threads per column (the one-wavefront form above walks
+// 7 900 partials of a 500 k-row vector in 123 dependent trips: 45 us), fixed order
+template <typename T>
+__global__ __launch_bounds__(1024) void multi_dot_finish_wide_kernel(int j, const T* __restrict__ partial, int64_t nchunks, T* __restrict__ h) {
+    __shared__ T sm[16];
+    const int c = blockIdx.x;
+    if (c >= j) return;
+    T acc = scalar_traits<T>::zero();
+    for (int64_t k = threadIdx.x; k < nchunks; k += 1024) acc = s_add(acc, partial[(int64_t)c * nchunks + k]);
+    acc = wave_sum_dpp(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        T t = sm[0];
+#pragma unroll
+        for (int q = 1; q < 16; ++q) t = s_add(t, sm[q]);
+        h[c] = t;
+    }
+}
+
+// w -= V h1 and h2 = V^H w (of the updated w) with one pass over V; returns 1 when the shape is not handled (nothing launched)
+int k_multi_axpy_dot(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, const void* h1_dev, void* w, void* h2_dev) {
+    if (j <= 0 || j > 128 || n <= 0) return 1;
+    const int64_t ntiles = (n + 63) / 64;
+    if (ntiles > 0x7FFFFFFF) return 1;
+    const size_t esz = dtype == LSA_C128 ? 16 : 8;
+    LSA_CHECK(lsa_ensure_scratch(ctx, (size_t)j * (size_t)ntiles * esz, 0));
+    DISPATCH_T(dtype, {
+        if (j <= 80)
+            hipLaunchKernelGGL((cgs_axpy_dot_kernel<T, 20>), dim3((unsigned)ntiles), dim3(kThreads), 0, ctx->stream, n, j, (const T*)V, ldv, (const T*)h1_dev,
+                               (T*)w, (T*)ctx->dscratch, ntiles);
+        else
+            hipLaunchKernelGGL((cgs_axpy_dot_kernel<T, 32>), dim3((unsigned)ntiles), dim3(kThreads), 0, ctx->stream, n, j, (const T*)V, ldv, (const T*)h1_dev,
+                               (T*)w, (T*)ctx->dscratch, ntiles);
+        hipLaunchKernelGGL((multi_dot_finish_wide_kernel<T>), dim3(j), dim3(1024), 0, ctx->stream, j, (const T*)ctx->dscratch, ntiles, (T*)h2_dev);
+    });
+    return check_launch(ctx, "multi_axpy_dot");
+}
+
 // columns of X (n x ncols, complex, column-major): canonical phase (largest entry real positive), unit 2-norm when `unit`;
 // imag2_dev[c] = sum_i Im(X[i, c])^2 afterwards.  Three launches for all columns.
 int k_columns_canonical(lsa_ctx* ctx, int64_t n, int ncols, void* X, int64_t ldx, int unit, double* imag2_dev) {

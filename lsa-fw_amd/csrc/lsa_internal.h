@@ -214,6 +214,7 @@ int k_axpy(lsa_ctx* ctx, int dtype, int64_t n, const double alpha[2], const void
 // h[c] = sum_i conj(V[i,c]) w[i], c < j   -> device array h (same dtype); V column-major with leading dim ldv
 int k_multi_dot(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, const void* w, void* h_dev);
 // w -= V h, and nrm2_dev[0] = ||w||^2 afterwards when nrm2_dev != null
+int k_multi_axpy_dot(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, const void* h1_dev, void* w, void* h2_dev);
 int k_multi_axpy(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, const void* h_dev, void* w,
                  double* nrm2_dev);
 // columns of X: canonical phase (largest entry real positive), unit norm when `unit`; imag2_dev[c] = sum Im(X[:, c])^2

@@ -60,8 +60,14 @@ int orthonormalize_enqueue(lsa_ctx* ctx, int dtype, int64_t n, const void* V, in
         if (frc <= 0) return frc;
     }
     LSA_CHECK(k_multi_dot(ctx, dtype, n, j, V, ldv, w, ow.h1));
-    LSA_CHECK(k_multi_axpy(ctx, dtype, n, j, V, ldv, ow.h1, w, nullptr));
-    LSA_CHECK(k_multi_dot(ctx, dtype, n, j, V, ldv, w, ow.h2));
+    // long vectors: the first projection and the second dot product share one pass over the basis (three passes instead of four)
+    static const bool three = !(getenv("LSA_KRYLOV_PASSES") && atoi(getenv("LSA_KRYLOV_PASSES")) == 4);
+    const int arc = three ? k_multi_axpy_dot(ctx, dtype, n, j, V, ldv, ow.h1, w, ow.h2) : 1;
+    if (arc < 0) return arc;
+    if (arc > 0) {
+        LSA_CHECK(k_multi_axpy(ctx, dtype, n, j, V, ldv, ow.h1, w, nullptr));
+        LSA_CHECK(k_multi_dot(ctx, dtype, n, j, V, ldv, w, ow.h2));
+    }
     LSA_CHECK(k_multi_axpy(ctx, dtype, n, j, V, ldv, ow.h2, w, ow.nrm2));
     LSA_CHECK(k_hess_column(ctx, dtype, j, ow.h1, ow.h2, ow.nrm2, hcol_dev));
     LSA_CHECK(k_scale_by_inv_norm(ctx, dtype, n, w, ow.nrm2, vnext));

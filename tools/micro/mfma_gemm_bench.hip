@@ -191,6 +191,9 @@ int main(int argc, char** argv) {
     run<2, 2, 1, true>("64x64 one buffer, XCD bands", A, B, C, M, N, K, hA, hB);
     run<2, 2, 2, false>("64x64 two buffers", A, B, C, M, N, K, hA, hB);
     run<4, 2, 1, false>("128x64 one buffer", A, B, C, M, N, K, hA, hB);
+    run<4, 2, 1, true>("128x64 one buffer, XCD bands", A, B, C, M, N, K, hA, hB);
+    run<2, 4, 1, true>("64x128 one buffer, XCD bands", A, B, C, M, N, K, hA, hB);
+    run<4, 2, 2, true>("128x64 two buffers, XCD bands", A, B, C, M, N, K, hA, hB);
     run<4, 4, 1, false>("128x128 one buffer", A, B, C, M, N, K, hA, hB);
     run<4, 4, 1, true>("128x128 one buffer, XCD bands", A, B, C, M, N, K, hA, hB);
     run<4, 4, 2, false>("128x128 two buffers", A, B, C, M, N, K, hA, hB);

@@ -1869,19 +1869,18 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
             hipLaunchKernelGGL((nd_unperm_kernel<T>), dim3(L.unperm.count), dim3(256), 0, st, tl + 2 * L.unperm.off, f->d_nodes, (const T*)front, f->d_ipiv,
                                f->d_rowq, lfac);
         static const bool vector_gemm = getenv("LSA_ND_GEMM") && !strcmp(getenv("LSA_ND_GEMM"), "vector");  // (A/B measurement aid)
-#define LSA_ND_GEMM_LAUNCH(KIND)                                                                                                              \
-    if (L.gemm[KIND].count > 0) {                                                                                                             \
-        if (vector_gemm)                                                                                                                      \
-            hipLaunchKernelGGL((nd_gemm_kernel<T, KIND>), dim3(L.gemm[KIND].count), dim3(256), 0, st, tl + 2 * L.gemm[KIND].off, f->d_nodes,  \
-                               front, lfac, ufac);                                                                                            \
-        else                                                                                                                                  \
-            hipLaunchKernelGGL((nd_gemm_mfma_kernel<T, KIND>), dim3(L.gemm[KIND].count), dim3(256), 0, st, tl + 2 * L.gemm[KIND].off,         \
-                               f->d_nodes, front, lfac, ufac);                                                                                \
-    }
-        LSA_ND_GEMM_LAUNCH(0)
-        LSA_ND_GEMM_LAUNCH(1)
-        LSA_ND_GEMM_LAUNCH(2)
-#undef LSA_ND_GEMM_LAUNCH
+        auto product = [&](auto kind) {
+            constexpr int KIND = decltype(kind)::value;
+            if (L.gemm[KIND].count == 0) return;
+            if (vector_gemm)
+                hipLaunchKernelGGL((nd_gemm_kernel<T, KIND>), dim3(L.gemm[KIND].count), dim3(256), 0, st, tl + 2 * L.gemm[KIND].off, f->d_nodes, front, lfac, ufac);
+            else
+                hipLaunchKernelGGL((nd_gemm_mfma_kernel<T, KIND>), dim3(L.gemm[KIND].count), dim3(256), 0, st, tl + 2 * L.gemm[KIND].off, f->d_nodes, front, lfac,
+                                   ufac);
+        };
+        product(std::integral_constant<int, 0>{});
+        product(std::integral_constant<int, 1>{});
+        product(std::integral_constant<int, 2>{});
         if (L.save.count > 0)
             hipLaunchKernelGGL((nd_save_update_kernel<T>), dim3(L.save.count), dim3(256), 0, st, tl + 2 * L.save.off, f->d_nodes, (const T*)front, upd);
     }

@@ -97,3 +97,49 @@ def test_which_policies_and_breakdown_through_the_library_loop(hip_ctx):
     v[[4, 9, 20]] = 1.0
     res = kb.solve(3, 1e-12, 50, 7, 0, sigma, v0=v)
     assert res.nconv >= 3 and helpers.match_nearest(d, res.lam).max() <= 1e-10  # every returned value is an eigenvalue
+
+
+_CGS_CHILD = r"""
+import json, sys
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/lsa-fw_amd", sys.argv[1] + "/tests"]
+import numpy as np
+from oracle import fem
+from Solver.eigen import EigenSolver, EigensolverConfig
+from Solver.utils import PreconditionerType, iSTType
+out = {}
+es = fem.cylinder_case("S5k")
+s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=8, atol=1e-10, ncv=40), check_hermitian=False)
+s.solver.set_st_type(iSTType.SINVERT); s.solver.set_st_pc_type(PreconditionerType.LU); s.solver.set_target(fem.SIGMA_RE50)
+pairs = s.solve()
+out["cylinder"] = {"lam": [[p[0].real, p[0].imag] for p in pairs], "res": float(s.solver.residuals()[:8].max()), "applies": s.solver.stats["op_applies"]}
+s.solver.release()
+K, M, _bnd = fem.assemble_membrane(24, 24)  # real symmetric pair: the float64 kernels
+s = EigenSolver(K, M, EigensolverConfig(num_eig=6, atol=1e-10, ncv=30), check_hermitian=False)
+s.solver.set_st_type(iSTType.SINVERT); s.solver.set_st_pc_type(PreconditionerType.LU); s.solver.set_target(0.0)
+pairs = s.solve()
+out["membrane"] = {"lam": [[p[0].real, p[0].imag] for p in pairs], "res": float(s.solver.residuals()[:6].max()), "applies": s.solver.stats["op_applies"]}
+print(json.dumps(out))
+"""
+
+
+def test_cgs2_kernel_per_stage_forms_agree_with_the_five_launch_form(tmp_path):
+    """The long-vector form of CGS2 (kernel per stage; from round 3 the first projection and the second dot product in one pass
+    over the basis, ``cgs_axpy_dot_kernel``) only runs by itself beyond 262 k unknowns.  Forced onto a 5 k-unknown case
+    (``LSA_KRYLOV_FUSED=0``; the switches are read once per process, hence child processes) with three and with four passes
+    over the basis: the eigenvalues of the default five-launch form to 1e-10, complex and float64 kernels."""
+    import os
+    import subprocess
+    import sys
+
+    root = str(Path(__file__).resolve().parents[1])
+    runs = {}
+    for name, env in (("default", {}), ("three_passes", {"LSA_KRYLOV_FUSED": "0"}), ("four_passes", {"LSA_KRYLOV_FUSED": "0", "LSA_KRYLOV_PASSES": "4"})):
+        p = subprocess.run([sys.executable, "-c", _CGS_CHILD, root], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        runs[name] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    for prob in ("cylinder", "membrane"):
+        ref = np.array([complex(a, b) for a, b in runs["default"][prob]["lam"]])
+        for name in ("three_passes", "four_passes"):
+            lam = np.array([complex(a, b) for a, b in runs[name][prob]["lam"]])
+            assert runs[name][prob]["res"] <= 1e-8
+            assert len(lam) == len(ref) and np.abs(lam - ref).max() <= 1e-10 * np.abs(ref).max(), (prob, name)

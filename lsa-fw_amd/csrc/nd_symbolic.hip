@@ -696,7 +696,16 @@ int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_siz
     // default is off; LSA_ND_TOP=<unknowns> turns it on.
     int32_t top_limit = 0;  // off: the longer Gauss-Jordan chain costs more than the launches it saves (S30k: + 10 ms per factorisation for - 11 us per solve)
     if (const char* e = getenv("LSA_ND_TOP")) top_limit = atoi(e);
-    if (top_limit > 0 && nt > 1) {
+    // Pairs of levels: a separator node at an even depth takes in the separators of its children (not their leaves) while the
+    // merged pivot block stays below `pair_limit` unknowns -- a four-way dissection with half as many levels, i.e. half as many
+    // dependent launches in both sweeps, for denser pivot blocks and a longer panel chain per level.
+    // On by default where the sweeps are bound by their launch chain (measured: 30 k unknowns, 19 -> 13 launches, 122 -> 96 us per
+    // apply for + 1.3 ms of factorisation, a solve 49.1 -> 45.6 ms; 38 k unknowns in 3D - 10 % per apply; 121 k unknowns - 9 %);
+    // from a few hundred thousand unknowns on the sweeps are bound by the bytes of the factors, which merging increases
+    // (504 k unknowns: + 10 % bytes, + 2 % time): off.  The limit keeps merged blocks on the panel path (below LSA_ND_TP_MIN = 512).
+    int32_t pair_limit = n <= 200000 ? 512 : 0;
+    if (const char* e = getenv("LSA_ND_PAIR")) pair_limit = atoi(e);
+    if ((top_limit > 0 || pair_limit > 0) && nt > 1) {
         std::vector<std::vector<int32_t>> kids((size_t)nt);
         std::vector<int32_t> height((size_t)nt, 0);
         for (int32_t t = nt - 1; t >= 0; --t)  // parents are created before their children
@@ -705,7 +714,20 @@ int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_siz
                 height[(size_t)par[(size_t)t]] = std::max(height[(size_t)par[(size_t)t]], height[(size_t)t] + 1);
             }
         std::vector<int32_t> into((size_t)nt, -1);  // node -> the root it is merged into
-        for (int32_t r = 0; r < nt; ++r) {
+        if (pair_limit > 0) {
+            std::vector<int32_t> depth((size_t)nt, 0);
+            for (int32_t t = 0; t < nt; ++t) depth[(size_t)t] = par[(size_t)t] >= 0 ? depth[(size_t)par[(size_t)t]] + 1 : 0;
+            for (int32_t t = 0; t < nt; ++t) {
+                if (into[(size_t)t] >= 0 || (depth[(size_t)t] & 1)) continue;
+                int64_t add = 0;
+                for (int32_t c : kids[(size_t)t])
+                    if (!kids[(size_t)c].empty()) add += (int64_t)own[(size_t)c].size();
+                if (add == 0 || (int64_t)own[(size_t)t].size() + add > pair_limit) continue;
+                for (int32_t c : kids[(size_t)t])
+                    if (!kids[(size_t)c].empty()) into[(size_t)c] = t;
+            }
+        }
+        for (int32_t r = 0; r < nt && top_limit > 0; ++r) {
             if (par[(size_t)r] >= 0) continue;
             int64_t cum = (int64_t)own[(size_t)r].size();
             std::vector<int32_t> layer{r};

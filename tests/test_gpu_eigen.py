@@ -493,8 +493,10 @@ def test_batched_arnoldi_steps_equal_one_step_at_a_time(hip_ctx, monkeypatch, ba
         out[b] = (H.copy(), kb.ritz_vectors(40, Y, False), op.stats())
     (H1, X1, s1), (Hb, Xb, sb) = out[1], out[batch]
     assert np.array_equal(H1, Hb) and np.array_equal(X1, Xb)
-    for key in ("op_applies", "spmv_calls", "sptrsv_calls", "gmres_iters", "max_rel_res"):
+    for key in ("op_applies", "spmv_calls", "sptrsv_calls", "gmres_iters"):
         assert s1[key] == sb[key], key
+    # (the b - C x check is summed per step by one reduction and per batch by another: equal to rounding, not bit for bit)
+    assert abs(s1["max_rel_res"] - sb["max_rel_res"]) <= 1e-3 * s1["max_rel_res"]
     assert s1["op_applies"] == 40 and s1["max_rel_res"] <= 1e-11
 
     # breakdown: the start vector spans a 3-dimensional invariant subspace of a diagonal pair

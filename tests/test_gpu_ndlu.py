@@ -200,7 +200,7 @@ def test_eigensolver_lu_variants_agree(hip_ctx):
 def test_ndlu_tournament_pivoting(hip_ctx, monkeypatch, case, sigma, leaf, tp_min):
     """Tall pivot blocks choose the 32 pivot rows of a column block by a tournament (local eliminations over 256 / 512
     rows, 8-way merges, the winners' tile inverted in LDS; ``LSA_ND_TP_MIN`` = the block height from which a level does so,
-    384 by default).  Forced onto small and mid-size fronts here -- one to three tournament rounds, partial last blocks,
+    512 by default).  Forced onto small and mid-size fronts here -- one to three tournament rounds, partial last blocks,
     real and complex factors, 2D and 3D patterns, the transposed sweeps -- the answers agree with SuperLU like those of the
     panel elimination, and zero diagonals (pressure rows) are pivoted around."""
     import lsa_hip

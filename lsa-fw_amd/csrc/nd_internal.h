@@ -4,9 +4,21 @@
 // subdomain or a separator) and has a boundary of b_t unknowns that belong to its ancestors; its front is the dense
 // (m_t + b_t)^2 matrix over idx_t = [own | boundary].  Nodes are numbered in post-order, so children precede parents.
 #pragma once
+#include <cstdlib>
 
 #include <cstdint>
 #include <vector>
+
+// leaf size of the dissection when the caller names none: 96 unknowns.  Measured inside eigen-solves (the factors compete with
+// the Krylov basis for the caches there; a loop of bare applies flatters large leaves): 30 k unknowns 45.1 / 44.2 / 46.0 / 46.4 /
+// 46.2 ms per solve at 64 / 96 / 128 / 192 / 256; 121 k unknowns 159 (96) against 165 ms (128); 504 k unknowns 326 against 328 ms;
+// the 3D cases indifferent.
+inline int32_t nd_default_leaf(int64_t n) {
+    if (const char* e = getenv("LSA_ND_LEAF"))  // (measurement aid)
+        if (atoi(e) > 0) return atoi(e);
+    (void)n;
+    return 96;
+}
 
 struct NdSymbolic {
     int32_t n = 0;

@@ -628,7 +628,7 @@ int nd_analyse(int32_t n, const int32_t* rp, const int32_t* ci, int32_t leaf_siz
     const Fail fail{err, errlen};
     if (!out) return fail(LSA_ERR_ARG, "nd_analyse: bad argument");
     if (int rc = check_pattern(n, rp, ci, fail)) return rc;
-    if (leaf_size <= 0) leaf_size = 128;
+    if (leaf_size <= 0) leaf_size = nd_default_leaf(n);
     NdSymbolic& S = *out;
     S = NdSymbolic();
     S.order_only = order_only;

@@ -2091,7 +2091,7 @@ static int nd_symbolic_phase(lsa_ctx* ctx, const lsa_mat* P, int dtype, int32_t 
     *out = nullptr;
     if (P->n != P->ncols || P->row0 != 0) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: needs a square, unsharded matrix");
     if ((int64_t)P->h_rp.size() != (int64_t)P->n + 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: the matrix has no host copy of its pattern");
-    if (leaf_size <= 0) leaf_size = 128;
+    if (leaf_size <= 0) leaf_size = nd_default_leaf(P->n);
     const double t0 = now_s();
     // same pattern as the parked factorisation: only the numbers change
     if (ctx->nd_cache) {

@@ -3,6 +3,7 @@ the two sweep kernels of the exact LU on S500k.  FETCH_SIZE is doubled as MI355X
 wide coalesced reads; counters are in KiB.  Prints a JSON record (profiles/rNN_spmv_traffic.json, rNN_lu_sweeps_traffic.json)."""
 import csv
 import json
+import re
 import sys
 from collections import defaultdict
 from pathlib import Path
@@ -16,7 +17,8 @@ def per_kernel(path, want):
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
             if any(w in name for w in want):
-                acc[name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")].append(float(r["Counter_Value"]))
+                m = re.search(r"((?:nd_|spmv_)\w+(?:<[^>]*>)?)", name)
+                acc[m.group(1) if m else name].append(float(r["Counter_Value"]))
     return acc
 
 

@@ -178,3 +178,26 @@ def test_memory_plan_of_the_packed_factorisation(s5k, case, budget_mb, ranks):
         else:
             assert mem["exchange_region"] == 0
     assert len(slots) <= 1  # every rank lays the exchange region out alike
+
+
+@pytest.mark.parametrize("case,sigma,constraints", [("S5k", fem.SIGMA_RE50, False), ("C2k", fem.SIGMA_CUBE, True)])
+def test_four_way_dissection_halves_the_levels_and_is_still_a_direct_solve(monkeypatch, case, sigma, constraints):
+    """Round 3: a separator node at an even depth takes in its children's separators (pivot block <= ``LSA_ND_PAIR`` unknowns,
+    512 by default up to 200 k unknowns).  Against the binary forest (``LSA_ND_PAIR=0``): fewer levels, somewhat more factor
+    entries, every unknown still owned once, and the table walk still solves the system."""
+    es = fem.cube_case(case) if case.startswith("C") else fem.cylinder_case(case)
+    C = _shifted(es, sigma)
+    flags = (C.diagonal() == 0) if constraints else None
+    got = {}
+    for name, env in (("binary", "0"), ("four_way", "512")):
+        monkeypatch.setenv("LSA_ND_PAIR", env)
+        an = lsa_hip.NdAnalysis(C, 48, constraint=flags)
+        ex = an.export()
+        assert np.array_equal(np.sort(ex["perm"]), np.arange(es.n))
+        em = Emulated(an.export_tables(), C.data)
+        b = np.random.default_rng(5).standard_normal(es.n).astype(C.dtype)
+        x = em.solve(b)
+        assert np.linalg.norm(C @ x - b) <= 1e-12 * np.linalg.norm(b)
+        got[name] = (an.nlevels, an.ntree, an.factor_entries, int(np.diff(ex["node_start"]).max()))
+    (l2, n2, e2, m2), (l4, n4, e4, m4) = got["binary"], got["four_way"]
+    assert l4 < l2 and n4 < n2 and e2 < e4 <= 1.6 * e2 and m4 <= 512 + 0 * m2

@@ -62,7 +62,7 @@ class LinearSolver:
                 try:
                     lsa_hip.NdLu(ctx, dA).solve(db, dx)
                 except lsa_hip.LsaError as exc:
-                    if exc.status != -8:  # only running out of device memory is answered by a leaner method
+                    if exc.status != lsa_hip.LSA_ERR_OOM:  # only running out of device memory is answered by a leaner method
                         raise
                     logger.warning("exact LU does not fit the device memory (%s); using ILU(%d)-GMRES", exc, ilu_levels)
                     p2 = pivot_safe_rcm(mat)

@@ -27,6 +27,9 @@ _STATUS_NAMES = {
     -8: "LSA_ERR_OOM",
 }
 
+# the status codes of include/lsa_hip.h by name (LSA_OK, LSA_ERR_ARG, ... LSA_ERR_OOM)
+globals().update({name: code for code, name in _STATUS_NAMES.items()})
+
 LIB_PATH = Path(os.environ.get("LSA_HIP_LIB", Path(__file__).resolve().parent / "liblsa_hip.so"))
 
 

@@ -48,7 +48,7 @@ logger = logging.getLogger(__name__)
 
 
 def synthesize(save_dir: Path, case: str) -> None:
-    """Write the synthetic (A, M) of oracle/fem.py for every Reynolds number of the sweep."""
+    """Write the synthetic (A, M) of synthetic/fem.py for every Reynolds number of the sweep."""
     sys.path.insert(0, str(ROOT))
     from synthetic import fem
 

@@ -1,7 +1,7 @@
 """Synthetic (A, M) generator (numpy, CPU): the deterministic inputs of tests, ``bench.py`` and the examples.
 
-Input generation only: no solver arithmetic.  The oracle (``oracle/``, the CPU checker) re-exports it as
-``oracle.fem``; the solver package ``lsa-fw_amd/Solver`` never imports it.
+Input generation only: no solver arithmetic.  Neither the oracle (``oracle/``, the CPU checker) nor the solver package
+``lsa-fw_amd/Solver`` contains it; both are fed from here.
 
 What it restates
 ----------------

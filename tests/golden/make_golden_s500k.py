@@ -14,7 +14,8 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT))
-from oracle import fem, shift_invert  # noqa: E402
+from oracle import shift_invert  # noqa: E402
+from synthetic import fem
 
 case = sys.argv[1] if len(sys.argv) > 1 else "S500k"
 t0 = time.time()

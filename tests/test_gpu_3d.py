@@ -26,7 +26,8 @@ def _solver(es, sigma, k, seed=0, atol=1e-10):
 
 
 def test_cube_c9k_matches_the_oracle():
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
 
     es = fem.cube_case("C9k")
     assert es.A.nnz / es.n > 80  # 3D Taylor-Hood rows: ~ 87 entries at this size (2D: ~ 30)
@@ -48,7 +49,7 @@ def test_cube_c9k_matches_the_oracle():
 
 
 def test_cube_c20k_matches_the_golden_fixture():
-    from oracle import fem
+    from synthetic import fem
 
     gold = json.loads((GOLDEN / "cube_c20k.json").read_text())
     es = fem.cube_case("C20k")
@@ -67,7 +68,7 @@ def test_cube_c40k_properties(hip_ctx):
     """Residuals, start-vector independence, and the nested-dissection LU as a direct solver on a 3D pattern (fronts of
     a few thousand unknowns: the two-rows-per-thread and the memory-resident panel instances)."""
     import lsa_hip
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cube_case("C40k")
     C = sp.csr_matrix((es.A.data - fem.SIGMA_CUBE * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
@@ -93,7 +94,7 @@ def test_cube_c40k_properties(hip_ctx):
 
 def test_spmv_on_the_3d_pattern(hip_ctx):
     import lsa_hip
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cube_case("C20k")
     C = sp.csr_matrix((es.A.data - (0.3 + 0.2j) * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)

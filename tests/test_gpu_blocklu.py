@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _ordered(case, sigma):
-    from oracle import fem
+    from synthetic import fem
     from Solver.utils import pivot_safe_rcm
 
     es = fem.cylinder_case(case)
@@ -139,7 +139,8 @@ def test_block_lu_reports_singular_block(hip_ctx):
 def test_eigensolver_with_lu_preconditioner_matches_oracle():
     """PreconditionerType.LU (the reference's own setting, .examples/eigenvalues.py:100): exact inner solves, one
     preconditioner apply per Arnoldi step, eigenvalues within 1e-8 of the oracle."""
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 

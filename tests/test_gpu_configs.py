@@ -37,7 +37,7 @@ def _solver(es, sigma, k, ncv, seed=0, atol=1e-10):
 
 @pytest.fixture(scope="module")
 def s30k_golden():
-    from oracle import fem
+    from synthetic import fem
 
     gold = json.loads((GOLDEN / "cylinder_s30k_k20.json").read_text())
     es = fem.cylinder_case("S30k")
@@ -66,7 +66,7 @@ def test_s30k_eigenvalues_match_the_golden_fixture(s30k_golden, k, ncv):
 def test_direct_adjoint_pair_re100(case):
     """BASELINE config 5: the structural-sensitivity pair at Re = 100 (Sensitivity/__init__.py:158-311) against the
     oracle's direct and adjoint eigenvalues; a is a left eigenvector scaled so that a^H M v = 1."""
-    from oracle import fem
+    from synthetic import fem
     from Sensitivity import EigenSensitivitySolver
 
     gold = json.loads((GOLDEN / "sensitivity_re100.json").read_text())
@@ -92,7 +92,7 @@ def test_refined_meshes_residuals_and_start_vector_independence(case):
     """BASELINE config 3 on one GPU: k = 20 at the Re = 50 target on the refined meshes.  The oracle needs minutes there,
     so parity is checked through properties: true residuals, every inner solve direct and verified, and the same twenty
     eigenvalues from two different start vectors."""
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cylinder_case(case)
     lams, vecs, ress = [], [], []
@@ -127,7 +127,7 @@ def test_moving_the_target_keeps_what_was_prepared():
     """A new target on the same (A, M) re-uses the context, the uploaded matrices, the ordering and the cached analysis
     (only the pattern of A - sigma M and the scalar type of its factors matter to them); the answers are those of a solver
     built at the new target from scratch.  Real <-> complex shifts change the factors' type and prepare anew."""
-    from oracle import fem
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
@@ -160,7 +160,7 @@ def test_moving_the_target_keeps_what_was_prepared():
 def test_s500k_eigenvalues_match_the_golden_fixture():
     """BASELINE config 3's workload (the 500 k-unknown cylinder pair, k = 20) on one GPU against the oracle's eigenvalues on
     the same assembled pair (``tests/golden/make_golden_s500k.py``: ten minutes of ARPACK + SuperLU on one core)."""
-    from oracle import fem
+    from synthetic import fem
 
     path = GOLDEN / "cylinder_s500k_k20.json"
     if not path.exists():

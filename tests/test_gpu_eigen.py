@@ -174,7 +174,8 @@ def test_repeated_eigenvalues(diagonal_matrix):  # :284-304
 def test_cylinder_eigenvalues_match_oracle(case, k, levels):
     """Leading k eigenvalues nearest sigma within rtol 1e-8 of the oracle (BASELINE.json north_star), vectors up to
     a complex phase, residuals of Solver/eigen2.py:48-56 below 1e-8."""
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
@@ -208,7 +209,8 @@ def test_cylinder_eigenvalues_match_oracle(case, k, levels):
 
 def test_real_shift_uses_real_factors():
     """sigma real and (A, M) real: C and its factors stay float64, eigenvalues still match the oracle."""
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import iSTType
 
@@ -227,7 +229,8 @@ def test_real_shift_uses_real_factors():
 
 def test_direct_adjoint_pair():
     """Sensitivity/__init__.py:158-311: lambda_adj = conj(lambda_dir) and a^H M v = 1."""
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
     from Sensitivity import EigenSensitivitySolver
 
     es = fem.cylinder_case("S2k")
@@ -251,7 +254,8 @@ def test_direct_adjoint_pair():
 def test_adjoint_solver_matches_the_explicit_transposes():
     """EigenSolver(adjoint=True) -- (A - conj(tau) M)^-H M^H on the factors of A - conj(tau) M -- finds the eigenpairs of the
     explicitly transposed pair (the reference's construction, Sensitivity/__init__.py:47-57) at the target tau."""
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
@@ -285,7 +289,8 @@ def test_reynolds_sweep_harness(tmp_path, monkeypatch, jobs):
     import importlib.util
     from pathlib import Path
 
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
 
     path = Path(__file__).resolve().parents[1] / "lsa-fw_amd" / "examples" / "eigenvalues.py"
     spec = importlib.util.spec_from_file_location("lsa_examples_eigenvalues", path)
@@ -305,7 +310,8 @@ def test_reynolds_sweep_harness(tmp_path, monkeypatch, jobs):
 def test_cayley_transform_matches_shift_invert():
     """iSTType.CAYLEY: OP = (A - sigma M)^-1 (A + nu M), theta = (lambda + nu) / (lambda - sigma); the eigenvalues nearest
     the target are those of shift-invert, for SLEPc's default antishift (nu = sigma) and for an explicit one."""
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
@@ -342,7 +348,7 @@ def test_vibrating_membrane_benchmark_published_values():
     import json
     from pathlib import Path
 
-    from oracle import fem
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import iEpsProblemType, iEpsWhich
 
@@ -366,7 +372,7 @@ def test_all_eigenvalues_in_an_interval():
     import json
     from pathlib import Path
 
-    from oracle import fem
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import iEpsProblemType, iEpsWhich
 
@@ -474,7 +480,7 @@ def test_batched_arnoldi_steps_equal_one_step_at_a_time(hip_ctx, monkeypatch, ba
     of the b - C x checks per batch, ``LSA_KRYLOV_BATCH``).  The same kernels run in the same order, so H, the basis and
     the counters are bit-identical to the one-step-at-a-time path; a breakdown inside a batch is reported at its step."""
     import lsa_hip
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cylinder_case("S2k")
     dA = lsa_hip.CsrMatrix.from_scipy(hip_ctx, es.A)
@@ -525,7 +531,7 @@ def test_ritz_vectors_leave_the_device_normalised_and_in_canonical_phase(hip_ctx
     host for every vector (``Solver/utils.py:280-291`` of the reference: the real build keeps the real part of a vector
     whose imaginary part is below 1e-6)."""
     import lsa_hip
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cylinder_case("S2k")
     dA = lsa_hip.CsrMatrix.from_scipy(hip_ctx, es.A)

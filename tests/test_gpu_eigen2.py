@@ -8,7 +8,8 @@ pytestmark = pytest.mark.gpu
 
 
 def test_projected_shift_invert_matches_oracle():
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
     from Solver.eigen2 import ArpackEigenSolver, ShiftInvertConfig, _compute_residuals
     from Solver.utils import iEpsWhich
 
@@ -34,7 +35,8 @@ def test_projected_shift_invert_matches_oracle():
 
 def test_projection_keeps_the_spectrum_of_the_full_problem():
     """M has no pressure columns, so P C^-1 M P and C^-1 M share their non-zero eigenvalues."""
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
     from Solver.eigen2 import ArpackEigenSolver, ShiftInvertConfig
 
     es = fem.cylinder_case("S2k")

@@ -22,13 +22,13 @@ def _solver(es, sigma, seed=0, st="sinvert", k=20):
 
 @pytest.fixture(scope="module")
 def s30k():
-    from oracle import fem
+    from synthetic import fem
 
     return fem.cylinder_case("S30k")
 
 
 def test_s30k_residuals_and_start_vector_independence(s30k):
-    from oracle import fem
+    from synthetic import fem
 
     sigma = fem.SIGMA_RE50
     lams = []
@@ -54,7 +54,7 @@ def test_s30k_residuals_and_start_vector_independence(s30k):
 
 
 def test_s30k_cayley_agrees_with_shift_invert(s30k):
-    from oracle import fem
+    from synthetic import fem
 
     sigma = fem.SIGMA_RE50
     a = _solver(s30k, sigma, k=10)
@@ -71,7 +71,7 @@ def test_s30k_cayley_agrees_with_shift_invert(s30k):
 def test_s30k_block_lu_round_trip(hip_ctx, s30k):
     """x -> C x (SpMV) -> C^-1 (block LU sweeps) returns x: the two hot kernels against each other at full size."""
     import lsa_hip
-    from oracle import fem
+    from synthetic import fem
     from Solver.utils import pivot_safe_rcm
 
     C = sp.csr_matrix((s30k.A.data - fem.SIGMA_RE50 * s30k.M.data, s30k.A.indices, s30k.A.indptr), shape=s30k.A.shape)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def case5k():
-    from oracle import fem
+    from synthetic import fem
 
     return fem.cylinder_case("S5k")
 
@@ -22,7 +22,8 @@ def case5k():
 @pytest.fixture(scope="module")
 def shifted5k(case5k):
     """(C, perm): complex C = A - sigma M of S5k in pivot-safe RCM ordering, host copy."""
-    from oracle import fem, kernels
+    from oracle import kernels
+    from synthetic import fem
     from Solver.utils import pivot_safe_rcm
 
     A, M = case5k.A, case5k.M
@@ -128,7 +129,8 @@ def test_spmv_transpose(hip_ctx, case5k):
 
 def test_axpby_same_pattern(hip_ctx, case5k):
     import lsa_hip
-    from oracle import fem, kernels
+    from oracle import kernels
+    from synthetic import fem
 
     dA = lsa_hip.CsrMatrix.from_scipy(hip_ctx, case5k.A)
     dM = lsa_hip.CsrMatrix.from_scipy(hip_ctx, case5k.M)

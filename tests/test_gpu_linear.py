@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def system():
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cylinder_case("S2k")
     C = sp.csr_matrix((es.A.data - 0.05 * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
@@ -40,7 +40,7 @@ def test_gmres_with_and_without_preconditioner(system):
     x = LinearSolver.solve(C, b, ksp_type=KSPType.GMRES, rtol=1e-11, pc=PreconditionerType.ILU)
     assert np.linalg.norm(C @ x.as_array() - b) <= 1e-10 * np.linalg.norm(b)
     # the reference's setting (no preconditioner) on an easy system: the mass matrix
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cylinder_case("S2k")
     u = es.dofs_u[:300]  # velocity-velocity mass block: SPD (the pressure rows of M are zero)

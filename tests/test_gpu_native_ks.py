@@ -18,7 +18,8 @@ def test_one_call_eigensolve_matches_the_s30k_golden_fixture(hip_ctx):
     """A consumer of include/lsa_hip.h: lsa_ctx_create -> lsa_csr_upload x 2 -> lsa_eigs_sinvert, nothing else (no ordering, no
     prepared analysis, no Python loop).  BASELINE config 2 at rtol 1e-8 against the oracle's eigenvalues."""
     import lsa_hip
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
 
     gold = json.loads((GOLDEN / "cylinder_s30k_k20.json").read_text())
     es = fem.cylinder_case("S30k")
@@ -41,7 +42,7 @@ def test_one_call_eigensolve_matches_the_s30k_golden_fixture(hip_ctx):
 def test_library_loop_equals_the_python_loop(monkeypatch, case, k, ncv):
     """Same start vector, same device kernels; only the dense algebra on the projected matrix differs (in-tree QR algorithm
     against LAPACK): same eigenvalues to 1e-10, same number of operator applies, eigenvectors equal up to rounding."""
-    from oracle import fem
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
@@ -103,7 +104,7 @@ _CGS_CHILD = r"""
 import json, sys
 sys.path[:0] = [sys.argv[1], sys.argv[1] + "/lsa-fw_amd", sys.argv[1] + "/tests"]
 import numpy as np
-from oracle import fem
+from synthetic import fem
 from Solver.eigen import EigenSolver, EigensolverConfig
 from Solver.utils import PreconditionerType, iSTType
 out = {}

@@ -12,7 +12,7 @@ SIGMA = 0.018 + 0.7379601143282424j
 
 
 def _shifted(case, sigma):
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cylinder_case(case)
     return es, sp.csr_matrix((es.A.data - sigma * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
@@ -177,7 +177,7 @@ def test_ndlu_refactor_and_cached_analysis(hip_ctx):
 
 def test_eigensolver_lu_variants_agree(hip_ctx):
     """The drop-in surface with both exact factorisations (lu='nd' default, lu='band'): same eigenvalues to 1e-10."""
-    from oracle import fem
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
@@ -204,7 +204,7 @@ def test_ndlu_tournament_pivoting(hip_ctx, monkeypatch, case, sigma, leaf, tp_mi
     real and complex factors, 2D and 3D patterns, the transposed sweeps -- the answers agree with SuperLU like those of the
     panel elimination, and zero diagonals (pressure rows) are pivoted around."""
     import lsa_hip
-    from oracle import fem
+    from synthetic import fem
 
     monkeypatch.setenv("LSA_ND_TP_MIN", str(tp_min))
     monkeypatch.setenv("LSA_ND_NO_CACHE", "1")
@@ -237,7 +237,7 @@ def test_ndlu_packed_factors_chunked_fronts_and_elimination_order(hip_ctx, monke
     handed back (sweeps without index lists).  Same answers as SuperLU and as the library's own dissection of the
     unpermuted matrix; the device buffers are smaller than the sum of the fronts."""
     import lsa_hip
-    from oracle import fem
+    from synthetic import fem
 
     monkeypatch.setenv("LSA_ND_NO_CACHE", "1")
     if work_mb:
@@ -280,7 +280,7 @@ def test_ndlu_lookahead_two_stream_path(hip_ctx, monkeypatch):
     """The tournament of the next column block on a second stream under the current block's rank-32 product (default: pivot
     blocks of 1024 rows and more), forced onto a small case: same factors as the one-stream order."""
     import lsa_hip
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cube_case("C9k")
     C = sp.csr_matrix((es.A.data - fem.SIGMA_CUBE * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
@@ -303,7 +303,7 @@ def test_ndlu_super_blocks_of_128_pivot_columns(hip_ctx, monkeypatch, case, sigm
     cores (``nd_gj_update_kernel``).  Forced onto small fronts here (partial last super-blocks, real and complex factors, with
     and without the second-stream look-ahead): SuperLU's answer, and the look-ahead changes no bit."""
     import lsa_hip
-    from oracle import fem
+    from synthetic import fem
 
     monkeypatch.setenv("LSA_ND_TP_MIN", "64")
     monkeypatch.setenv("LSA_ND_SB_MIN", "130")

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 def test_sharded_layout_single_rank_matches_oracle():
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
@@ -37,7 +38,7 @@ def test_sharded_layout_single_rank_matches_oracle():
 def test_two_rank_shards_reproduce_global_spmv(hip_ctx):
     import lsa_hip
     from lsa_hip import sharding
-    from oracle import fem
+    from synthetic import fem
 
     es = fem.cylinder_case("S5k")
     part = sharding.partition_rows(es.A.indptr, 2)
@@ -69,7 +70,7 @@ def _rank_main(rank: int, world: int, port: int, out_dir: str, case: str, pc: st
     sys.path[:0] = [str(root), str(root / "lsa-fw_amd"), str(root / "tests")]
     import torch.distributed as dist
 
-    from oracle import fem
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
@@ -104,7 +105,8 @@ def test_sharded_solve_with_several_ranks_on_one_gpu(tmp_path, world, pc, case):
 
     import torch.multiprocessing as mp
 
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -138,7 +140,8 @@ def test_sharded_3d_case_with_four_ranks_matches_the_single_gpu_solve(tmp_path):
 
     import torch.multiprocessing as mp
 
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
@@ -175,7 +178,7 @@ def _rank_adjoint(rank: int, world: int, port: int, out_dir: str) -> None:
     sys.path[:0] = [str(root), str(root / "lsa-fw_amd"), str(root / "tests")]
     import torch.distributed as dist
 
-    from oracle import fem
+    from synthetic import fem
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
 
@@ -202,7 +205,8 @@ def test_sharded_adjoint_solve(tmp_path, world):
 
     import torch.multiprocessing as mp
 
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

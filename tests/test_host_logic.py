@@ -11,7 +11,8 @@ import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
 import helpers
-from oracle import fem, shift_invert
+from oracle import shift_invert
+from synthetic import fem
 
 
 # ---- Krylov-Schur ----------------------------------------------------------------------------------------------------------

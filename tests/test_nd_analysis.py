@@ -13,7 +13,7 @@ import helpers  # noqa: F401  (sys.path)
 import lsa_hip
 from lsa_hip import sharding
 from nd_emulation import Emulated, EmulatedRanks
-from oracle import fem
+from synthetic import fem
 
 
 def _shifted(es, sigma):

@@ -14,7 +14,8 @@ import pytest
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-from oracle import fem, kernels, shift_invert
+from oracle import kernels, shift_invert
+from synthetic import fem
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 KNOWN = json.loads((GOLDEN / "reference_known_answers.json").read_text())
@@ -190,7 +191,8 @@ def test_ilu_with_full_fill_is_lu(small_pair):
 def test_projected_operator_of_eigen2_keeps_the_spectrum():
     """``Solver/eigen2.py:164-201`` zeroes the pressure dofs around every apply; M has no pressure columns, so the
     non-zero spectrum is that of the full problem and the vectors are the velocity parts."""
-    from oracle import fem, shift_invert
+    from oracle import shift_invert
+    from synthetic import fem
 
     es = fem.cylinder_case("S2k")
     sigma = fem.SIGMA_RE50

@@ -18,7 +18,7 @@ import scipy.sparse as sp
 
 import helpers  # noqa: F401  (sys.path)
 from lsa_hip import sharding
-from oracle import fem
+from synthetic import fem
 
 
 def test_partition_and_padded_layout():
@@ -62,7 +62,8 @@ def _worker(rank: int, world: int, port: int, out_dir: str) -> None:
 
     from lsa_hip import sharding as sh
     from lsa_hip.krylov_schur import krylov_schur
-    from oracle import fem as ofem, kernels
+    from oracle import kernels
+    from synthetic import fem as ofem
     from Solver.utils import _dist_rank_world, delay_zero_diagonal_rows, pivot_safe_rcm
     import helpers as hp
 

@@ -310,7 +310,8 @@ def cpu_baseline(es, sigma, args):
     best = max(runs, key=lambda r: r["eigenpairs_per_s"])
     slepc = _slepc_reference(es, sigma, args)
     out = {
-        "value": best["eigenpairs_per_s"], "unit": "eigenpairs/s", "cores": best["threads"], "kind": "port",
+        # (SuperLU and ARPACK are sequential: one core does the work; the BLAS pool size of the faster run is reported beside it)
+        "value": best["eigenpairs_per_s"], "unit": "eigenpairs/s", "cores": 1, "cores_used": 1, "blas_threads": best["threads"], "kind": "port",
         "sample": f"one full solve of the same {args.case} problem (k={args.k}, ncv={args.ncv}, tol={args.atol:g}) per thread count, scipy "
                   f"ARPACK+SuperLU: " + "; ".join(f"{r['threads']} BLAS thread(s) {r['seconds']:.1f} s (SuperLU factor {r['factor']:.1f} s, "
                                                   f"{r['applies']} applies)" for r in runs)
@@ -418,7 +419,7 @@ def run_sharded_children(args, rank: int, world: int, local_rank: int):
                 "MASTER_PORT": str(int(os.environ.get("MASTER_PORT", "29500")) + 37)})
     for var in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE"):
         env.pop(var, None)  # the child group has its own TCP store (rank 0's child hosts it)
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--sharded-child", "--gpus", str(world), "--steps", str(max(2, min(args.steps, 5))), "--warmup", "1",
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--sharded-child", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--case", args.sharded_case, "--k", str(args.k), "--ncv", str(args.ncv), "--atol", str(args.atol), "--no-roofline", "--no-cpu-baseline"]
     t0 = time.perf_counter()
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
@@ -503,7 +504,8 @@ def main() -> None:
         # leaving it to the backend's default of 10-30 minutes.
         from datetime import timedelta
 
-        pg_timeout = timedelta(seconds=120 if args.sharded_child else 300)  # (a child lives at most --sharded-timeout seconds anyway)
+        # (a child lives at most --sharded-timeout seconds; the parents wait for their children inside barriers of THEIR group)
+        pg_timeout = timedelta(seconds=120 if args.sharded_child else max(600.0, 2.0 * args.sharded_timeout + 120.0))
         if backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=pg_timeout)
         else:
@@ -554,9 +556,11 @@ def main() -> None:
             # build could reach: the first solve reads every step back (LSA_KRYLOV_BATCH=1), the second runs the batched
             # steps, and their eigenvalues must agree before anything is timed.
             os.environ["LSA_KRYLOV_BATCH"] = "1"
-            solver.solve()
+            try:
+                solver.solve()
+            finally:  # (left set after a failure, everything after it in this process would read every step back)
+                os.environ.pop("LSA_KRYLOV_BATCH", None)
             lam_one = np.array([solver.solver.get_eigenvalue(i) for i in range(solver.solver.get_num_converged())])
-            os.environ.pop("LSA_KRYLOV_BATCH")
             solver.solve()
             lam_bat = np.array([solver.solver.get_eigenvalue(i) for i in range(solver.solver.get_num_converged())])
             kk = min(len(lam_one), len(lam_bat), args.k)
@@ -763,6 +767,28 @@ def main() -> None:
                                          else "slower than the exact LU by %.0fx" % (out["value"] / max(opc_rec["eigenpairs_per_s"], 1e-300)))
             except Exception as exc:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if world > 1 and not sharded and isinstance(sharded_rec, dict) and "error" not in sharded_rec and sharded_rec.get("eigenpairs_per_s") \
+                and not sharded_rec.get("layout_note") and (sharded_rec.get("converged_per_solve") or 0) >= args.k:
+            # The layout BASELINE.json names for N > 1 is the headline once it has passed its own checks in this run (batched
+            # against stepwise Arnoldi steps, k converged pairs on their true residuals): ONE problem (config 3) over all ranks,
+            # strong scaling.  The replicas of the N = 1 workload measured above stay on the line as config.replicas.
+            out["config"]["replicas"] = {"eigenpairs_per_s": out["value"], "ms_per_step": out["ms_per_step"], "scaling": "weak",
+                                         "workload": out["config"]["workload"],
+                                         "note": f"every rank solves the {args.case} problem of the N = 1 line on its own GPU (no data-path collective)"}
+            out["value"] = sharded_rec["eigenpairs_per_s"]
+            out["ms_per_step"] = sharded_rec["ms_per_step"]
+            out["scaling"] = "strong"
+            out["config"]["workload"] = sharded_rec.get("workload")
+            out["config"]["layout"] = "sharded"
+            out["config"]["parallelism"] = sharded_rec.get("parallelism")
+            out["config"]["layout_note"] = (f"value = the sharded run of {args.sharded_case} over {world} ranks (config.sharded, measured by child processes "
+                                            "after its batched-vs-stepwise check passed); config.replicas = the N = 1 workload on every rank; "
+                                            "config.sharded.one_gpu_same_workload_eigenpairs_per_s is the one-GPU rate of the value's workload")
+        elif world > 1 and not sharded and not args.sharded_child:
+            out["config"]["layout_note"] = ((layout_note + "; ") if layout_note else "") + \
+                "value = independent replicas of the N = 1 workload, weak scaling WITHOUT communication: the sharded run did not produce a checked result (" + \
+                (str(sharded_rec.get("error") or sharded_rec.get("layout_note"))[:300] if isinstance(sharded_rec, dict) else "not run") + ")"
+            out["sharded_failed"] = True
         os.write(line_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()

@@ -61,6 +61,9 @@ typedef struct {
     int32_t backward_accepted; /* direct solves whose ||b - C x|| / ||b|| missed rtol but whose backward error
                                   ||b - C x|| / (||C||_F ||x||) is <= 1e-12: shifts next to an eigenvalue */
     int32_t analysis_reused; /* 1 if the exact LU found its pattern-only analysis prepared (lsa_ndlu_prepare) or cached in the context */
+    int32_t refined_solves;  /* direct solves that took a step of iterative refinement x += C^-1 (b - C x) because the first
+                                answer missed rtol (Solver/eigen2.py:178-189 checks the same residual) */
+    int32_t reserved0;
 } lsa_stats;
 
 /* ---- context ------------------------------------------------------------------------------------ */

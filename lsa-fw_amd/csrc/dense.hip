@@ -237,8 +237,8 @@ bool hessenberg_qr(int n, const Mat& H, const Mat& Q) {
             if (sub <= smlnum) break;
             double tst = abs1(h(l - 1, l - 1)) + abs1(h(l, l));
             if (tst == 0.0) {
-                if (l - 2 >= 0) tst += std::fabs(h(l - 1, l - 2).re);
-                if (l + 1 <= ihi) tst += std::fabs(h(l + 1, l).re);
+                if (l - 2 >= 0) tst += abs1(h(l - 1, l - 2));
+                if (l + 1 <= ihi) tst += abs1(h(l + 1, l));
             }
             if (sub <= ulp * tst) {
                 // (Ahues & Tisseur) a small subdiagonal next to diagonal entries of very different size
@@ -255,15 +255,17 @@ bool hessenberg_qr(int n, const Mat& H, const Mat& Q) {
             its = 0;
             continue;
         }
-        if (++its > 30 || ++total > 30 * n + 300) {
+        // (LAPACK's zlahqr allows 30 * max(10, n) sweeps per eigenvalue with an exceptional shift every tenth; giving up after 30
+        //  aborted whole eigen-solves on clustered projected matrices.  The subdiagonals are not kept real here: abs1, not .re)
+        if (++its > 30 * std::max(10, n) || ++total > 30 * std::max(10, n) * n) {
             ok = false;
             break;
         }
         Z shift;
-        if (its == 10) {
-            shift = h(l, l) + Z{0.75 * std::fabs(h(l + 1, l).re), 0.0};
-        } else if (its == 20) {
-            shift = h(ihi, ihi) + Z{0.75 * std::fabs(h(ihi, ihi - 1).re), 0.0};
+        if (its % 20 == 10) {
+            shift = h(l, l) + Z{0.75 * abs1(h(l + 1, l)), 0.0};
+        } else if (its % 20 == 0) {
+            shift = h(ihi, ihi) + Z{0.75 * abs1(h(ihi, ihi - 1)), 0.0};
         } else {
             // the eigenvalue of the trailing 2 x 2 block nearer to its last diagonal entry
             shift = h(ihi, ihi);

@@ -110,6 +110,14 @@ __global__ __launch_bounds__(256) void nd_maxabs2_kernel(int64_t nnz, const T* _
     }
 }
 
+// test aid (LSA_ND_TEST_PERTURB): every stored factor scalar times (1 + eps), so that a solve is wrong by about eps and the
+// operator layer's iterative refinement has something to do (tests/test_gpu_3d.py)
+template <typename T>
+__global__ void nd_scale_kernel(int64_t count, T* __restrict__ v, double factor) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride) v[i] = s_mul(factor, v[i]);
+}
+
 template <typename T>
 __global__ void nd_assemble_kernel(int64_t count, const T* __restrict__ val, const int32_t* __restrict__ src, const int64_t* __restrict__ dst,
                                    T* __restrict__ front) {
@@ -1829,7 +1837,9 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
             if (!std::isfinite(max2)) return lsa_set_error(ctx, LSA_ERR_NONFINITE, "lsa_ndlu: the matrix holds non-finite values");
             return LSA_OK;
         };
-        rc0 = k_agree_status(ctx, head());
+        // (agreed on over the ranks THIS factorisation is split over: a rank-local factorisation on a multi-rank context --
+        //  a rank's diagonal block, a retry only one rank takes -- must not enter a collective the others are not in)
+        rc0 = S.nranks > 1 ? k_agree_status(ctx, head()) : head();
         if (rc0 != LSA_OK) return rc0;
     }
     // (1e-15 * max|C|)^2: rounding level.  A shift next to an eigenvalue (the adjoint problem of the reference is shifted exactly at
@@ -1919,6 +1929,14 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
                              "candidate pivot %.3e against max|C| = %.3e (threshold 1e-15 max|C|); the matrix is singular, or needs pivoting "
                              "across fronts",
                              t, S.m[(size_t)t], S.f[(size_t)t], S.level[(size_t)t], hflag[2], std::sqrt(mag2), std::sqrt(max2));
+    }
+    if (const char* pe = getenv("LSA_ND_TEST_PERTURB")) {
+        const double eps = atof(pe);
+        if (eps != 0.0 && f->ufac_entries > 0) {
+            const int blocks = (int)std::min<int64_t>((f->ufac_entries + 255) / 256, (int64_t)ctx->num_cu * 16);
+            hipLaunchKernelGGL((nd_scale_kernel<T>), dim3(blocks), dim3(256), 0, st, f->ufac_entries, ufac, 1.0 + eps);
+            LSA_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        }
     }
     return LSA_OK;
 }

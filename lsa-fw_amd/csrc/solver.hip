@@ -222,6 +222,27 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, PcRef pc, int dtype, const void* b
         beta0 = std::sqrt(((const double*)ctx->pinned)[0]);
         bnorm = std::sqrt(((const double*)ctx->pinned)[1]);
         use_x0 = true;
+        // Iterative refinement before any looser judgement: the residual b - C x is on the device already (W.w), one more
+        // pair of sweeps and one product give x += C^-1 (b - C x).  Large 3D factorisations leave ||b - C x|| / ||b|| at 1e-11
+        // (growth over tens of thousands of pivots per front); one step brings that to rounding level.  Repeated while it
+        // helps (at most twice); what is left after that is the conditioning of C itself (a shift next to an eigenvalue).
+        for (int pass = 0; pass < 2 && beta0 > rtol * bnorm && std::isfinite(beta0) && bnorm > 0.0; ++pass) {
+            LSA_CHECK(pc_global(ctx, pc, C->row0, n, dtype, W.w, W.z));
+            const double one[2] = {1.0, 0.0};
+            LSA_CHECK(k_axpy(ctx, dtype, n, one, W.z, x));
+            LSA_CHECK(spmv_global(ctx, C, dtype, x, W.z, pc.adjoint));
+            LSA_CHECK(k_residual_norms(ctx, dtype, n, b, W.z, W.w, W.ow.nrm2));
+            LSA_HIP_CHECK(ctx, hipMemcpyAsync(ctx->pinned, W.ow.nrm2, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+            const double before = beta0;
+            beta0 = std::sqrt(((const double*)ctx->pinned)[0]);
+            if (st) {
+                st->sptrsv_calls += 2;
+                ++st->spmv_calls;
+                if (pass == 0) ++st->refined_solves;
+            }
+            if (!(beta0 < 0.5 * before)) break;  // no longer helping: x is as good as these factors make it
+        }
         if (beta0 > rtol * bnorm && pc.normF > 0.0 && std::isfinite(beta0)) {
             // A direct solve is judged by its backward error.  For a shift next to an eigenvalue ||x|| >> ||b|| / ||C|| and
             // ||b - C x|| / ||b|| cannot go below eps ||C|| ||x|| / ||b||, whatever the solver (the reference shifts the
@@ -436,6 +457,7 @@ struct lsa_op {
     bool gw_ready;
     void* t;  // device temp vector (complex)
     double* keep = nullptr;  // device 0/1 mask of the projected operator (lsa_op_set_projection), or null
+    bool refine = false;     // queued Arnoldi steps carry one step of iterative refinement (set the first time a direct solve misses rtol)
     lsa_stats st;
 };
 
@@ -927,6 +949,15 @@ static int krylov_enqueue_step(lsa_ctx* ctx, lsa_krylov* k, int32_t j, int32_t s
     pcr.adjoint = op->adjoint;
     LSA_CHECK(pc_global(ctx, pcr, op->Kfac->row0, op->n, dtype, rhs, k->w));
     LSA_CHECK(spmv_global(ctx, op->Kfac, dtype, k->w, op->gw.z, op->adjoint));
+    if (op->refine) {
+        // y += C^-1 (t - C y): the factors of a large 3D problem leave 1e-11 of the right-hand side behind, this step takes it to
+        // rounding level (the norms this residual pass leaves in the check slot are overwritten by the final check below)
+        LSA_CHECK(k_residual_norms(ctx, dtype, op->n, rhs, op->gw.z, op->gw.w, k->checks + 2 * (size_t)slot));
+        LSA_CHECK(pc_global(ctx, pcr, op->Kfac->row0, op->n, dtype, op->gw.w, op->gw.z));
+        const double one[2] = {1.0, 0.0};
+        LSA_CHECK(k_axpy(ctx, dtype, op->n, one, op->gw.z, k->w));
+        LSA_CHECK(spmv_global(ctx, op->Kfac, dtype, k->w, op->gw.z, op->adjoint));
+    }
     void* hcol_dev = (char*)k->Hdev + (size_t)slot * (size_t)(k->ncv + 2) * 16;
     static const bool fuse = !(getenv("LSA_KRYLOV_FUSED") && atoi(getenv("LSA_KRYLOV_FUSED")) == 0);
     if (fuse) {
@@ -1001,16 +1032,23 @@ int lsa_krylov_extend(lsa_ctx* ctx, lsa_krylov* k, int32_t j0, int32_t j1, void*
             for (int32_t s = 0; s < nb; ++s, ++accepted) {
                 const double beta0 = std::sqrt(chk[2 * s]), bnorm = std::sqrt(chk[2 * s + 1]);
                 if (!(beta0 <= rtol * bnorm)) {
-                    // this solve needs the slower judgement (backward error, refinement) of the one-step path, and so will
-                    // its neighbours: the rest of the life of this basis runs one step at a time
+                    if (!op->refine && std::isfinite(beta0)) {
+                        // a direct solve missed rtol: from here on every queued step carries one refinement step (large 3D
+                        // factors; the steps of this batch from s on are queued again)
+                        op->refine = true;
+                        break;
+                    }
+                    // refined and still short of rtol: this solve needs the judgement of the one-step path (backward error
+                    // next to an eigenvalue, GMRES), and so will its neighbours: the rest of this basis runs one step at a time
                     k->pipeline = false;
                     break;
                 }
                 const cplx* hc = (const cplx*)(host + (size_t)s * colb);
                 for (int32_t i = 0; i <= j + s + 1; ++i) k->hcol[i] = zc(hc[i].re, hc[i].im);
                 ++op->st.op_applies;
-                op->st.spmv_calls += op->Kmul ? 2 : 1;
-                op->st.sptrsv_calls += 2;
+                op->st.spmv_calls += (op->Kmul ? 2 : 1) + (op->refine ? 1 : 0);
+                op->st.sptrsv_calls += op->refine ? 4 : 2;
+                if (op->refine) ++op->st.refined_solves;
                 op->st.last_rel_res = bnorm > 0.0 ? beta0 / bnorm : 0.0;
                 op->st.max_rel_res = std::max(op->st.max_rel_res, op->st.last_rel_res);
                 const int what = take_column(j + s, k->hcol.data());

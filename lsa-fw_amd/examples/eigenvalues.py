@@ -61,33 +61,34 @@ def synthesize(save_dir: Path, case: str) -> None:
 
 
 def solve_case(save_dir: Path, re: float, target: complex) -> Path | None:
-    """One Reynolds number: load (A, M), shift-invert at the tabulated target, write sigma (reference ``:66-107``)."""
-    case_dir = save_dir / f"reynolds_{re:.1f}"
-    mat_dir = case_dir / "matrices"
-    A_path, M_path = mat_dir / "A.mtx", mat_dir / "M.mtx"
-    if not A_path.exists() or not M_path.exists():
-        logger.warning("Skipping Re = %.1f: missing matrices in '%s'", re, mat_dir)
+    """One Reynolds number of the sweep: read the MatrixMarket pair, shift-invert at the tabulated target with the exact LU
+    as inner solver, store the selected eigenvalue as ``"<real> <imag>"`` (the call sequence of the reference's loop body,
+    ``.examples/eigenvalues.py:61-107``; same file names and output format, so its post-processing reads these results)."""
+    root = save_dir / f"reynolds_{re:.1f}"
+    files = {name: root / "matrices" / f"{name}.mtx" for name in ("A", "M")}
+    absent = [str(path) for path in files.values() if not path.exists()]
+    if absent:
+        logger.warning("Re %.1f left out, no such file: %s", re, ", ".join(absent))
         return None
-    logger.info("[Re=%.1f] Loading matrices from '%s'", re, mat_dir)
-    A = iPETScMatrix.from_path(A_path)
-    A.assemble()
-    M = iPETScMatrix.from_path(M_path)
-    M.assemble()
-    logger.info("[Re=%.1f] A: shape=%s, nnz=%d, norm=%.3e", re, A.shape, A.nonzero_entries, A.norm)
-    logger.info("[Re=%.1f] M: shape=%s, nnz=%d, norm=%.3e", re, M.shape, M.nonzero_entries, M.norm)
+    pair = {}
+    for name, path in files.items():
+        mat = iPETScMatrix.from_path(path)
+        mat.assemble()
+        logger.info("Re %.1f: %s read from %s: %d x %d, %d stored entries, Frobenius norm %.3e", re, name, path, *mat.shape, mat.nonzero_entries, mat.norm)
+        pair[name] = mat
 
-    cfg = EigensolverConfig(num_eig=_NUM_EIG, atol=_ATOL)
-    es = EigenSolver(A, M, cfg=cfg, check_hermitian=False)
-    es.solver.set_st_type(iSTType.SINVERT)
-    es.solver.set_target(target)
-    es.solver.set_st_pc_type(PreconditionerType.LU)
-    es.solver.solve()
-    sigma = es.solver.get_eigenvalue(_EIG_INDEX)
-    out_path = case_dir / f"sigma_eig{_EIG_INDEX}.txt"
-    out_path.write_text(f"{sigma.real} {sigma.imag}\n", encoding="utf-8")
-    logger.info("[Re=%.1f] Wrote sigma to '%s'", re, out_path)
-    es.solver.release()
-    return out_path
+    eigensolver = EigenSolver(pair["A"], pair["M"], cfg=EigensolverConfig(num_eig=_NUM_EIG, atol=_ATOL), check_hermitian=False)
+    eps = eigensolver.solver
+    eps.set_st_type(iSTType.SINVERT)
+    eps.set_target(target)
+    eps.set_st_pc_type(PreconditionerType.LU)
+    eps.solve()
+    value = eps.get_eigenvalue(_EIG_INDEX)
+    result_file = root / f"sigma_eig{_EIG_INDEX}.txt"
+    result_file.write_text(f"{value.real} {value.imag}\n", encoding="utf-8")
+    logger.info("Re %.1f: eigenvalue %d nearest %s is %s -> %s", re, _EIG_INDEX, target, value, result_file)
+    eps.release()
+    return result_file
 
 
 def main(argv: list[str] | None = None) -> None:

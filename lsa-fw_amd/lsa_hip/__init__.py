@@ -55,6 +55,8 @@ class lsa_stats(ctypes.Structure):
         ("pc_fallback", ctypes.c_int32),
         ("backward_accepted", ctypes.c_int32),
         ("analysis_reused", ctypes.c_int32),
+        ("refined_solves", ctypes.c_int32),
+        ("reserved0", ctypes.c_int32),
     ]
 
 

@@ -38,7 +38,7 @@ def test_library_is_in_tree_and_built_for_gfx950():
 
 
 def test_struct_layouts_match_header():
-    assert ctypes.sizeof(lsa_hip.lsa_stats) == 4 * 8 + 4 * 8 + 4 * 4
+    assert ctypes.sizeof(lsa_hip.lsa_stats) == 4 * 8 + 4 * 8 + 6 * 4
     # int32, (pad), double, double, int32, int32, int32, (pad), double[2] -> 56 bytes with natural alignment
     # (csrc/solver.hip static_asserts the same number on the C side)
     assert ctypes.sizeof(lsa_hip.lsa_op_options) == 56

@@ -106,3 +106,73 @@ def test_spmv_on_the_3d_pattern(hip_ctx):
     dC.matvec(lsa_hip.DeviceVector.from_numpy(hip_ctx, x), dy)
     ref = C @ x
     assert np.linalg.norm(dy.numpy() - ref) <= 1e-13 * np.linalg.norm(ref)
+
+
+def test_iterative_refinement_is_taken_and_helps(monkeypatch):
+    """One step x += C^-1 (b - C x) before any looser acceptance (csrc/solver.hip, the check of Solver/eigen2.py:178-189).  The
+    factors are spoilt on purpose (every U scalar times 1 + 1e-7, LSA_ND_TEST_PERTURB): a bare solve is then wrong by ~1e-7, far
+    above ksp_rtol; with refinement every inner solve reaches rounding level again, nothing is accepted on its backward error
+    and the eigenvalues are those of the clean factorisation."""
+    from synthetic import fem
+
+    es = fem.cube_case("C80k")
+    s = _solver(es, fem.SIGMA_CUBE, 10)
+    clean = np.array([p[0] for p in s.solve()])
+    st0 = dict(s.solver.stats)
+    s.solver.release()
+    assert len(clean) == 10 and st0["gmres_iters"] == 0
+    monkeypatch.setenv("LSA_ND_TEST_PERTURB", "1e-7")
+    s = _solver(es, fem.SIGMA_CUBE, 10)
+    lam = np.array([p[0] for p in s.solve()])
+    st = dict(s.solver.stats)
+    res = s.solver.residuals()[:10]
+    s.solver.release()
+    print("clean:", {k: st0[k] for k in ("refined_solves", "backward_accepted", "max_rel_res", "op_applies")},
+          "\nspoilt factors:", {k: st[k] for k in ("refined_solves", "backward_accepted", "max_rel_res", "op_applies", "gmres_iters")})
+    assert st["refined_solves"] >= st["op_applies"] - 1 > 0  # every apply took the refinement step (queued steps carry it once the first check failed)
+    assert st["backward_accepted"] == 0 and st["gmres_iters"] == 0
+    assert st["max_rel_res"] <= 1e-12  # after ONE step: (1e-7)^2 of the right-hand side, i.e. rounding level
+    assert len(lam) == 10 and res.max() <= 1e-8
+    for r in clean:
+        assert np.min(np.abs(lam - r)) <= 1e-8 * abs(r)
+
+
+def test_cube_c300k_properties(hip_ctx):
+    """BASELINE config 4's discretisation where its own kernels dominate (286 k unknowns, fronts of ~ 10 k rows): tournament
+    pivoting, super-blocks of 128 pivot columns and the matrix-core products are what factor this problem.  Properties that
+    need no oracle: true residuals, start-vector independence, real against complex shift-invert at the same target, exact
+    inner solves."""
+    import lsa_hip
+    from synthetic import fem
+
+    es = fem.cube_case("C300k")
+    lams = {}
+    for tag, sigma, seed in (("real", fem.SIGMA_CUBE, 0), ("real, other start", fem.SIGMA_CUBE, 3), ("complex", complex(fem.SIGMA_CUBE) + 0.02j, 0)):
+        s = _solver(es, sigma, 10, seed=seed)
+        pairs = s.solve()
+        st = dict(s.solver.stats)
+        res = s.solver.residuals()[:10]
+        s.solver.release()
+        print(tag, {k: st.get(k) for k in ("op_applies", "gmres_iters", "refined_solves", "backward_accepted", "max_rel_res", "seconds_factor")})
+        assert len(pairs) >= 10 and res.max() <= 1e-8
+        assert st["gmres_iters"] == 0 and st["pc_fallback"] == 0 and st["backward_accepted"] == 0
+        lams[tag] = np.array([p[0] for p in pairs[:10]])
+    for r in lams["real"]:
+        assert np.min(np.abs(lams["real, other start"] - r)) <= 1e-8 * abs(r)
+    # the factorisation by itself: pivot blocks far beyond LSA_ND_TP_MIN (512) and LSA_ND_SB_MIN (1024) rows, i.e. the tournament,
+    # the super-blocks of 128 pivot columns and the matrix-core updates are what produced these factors; a direct solve with them
+    ctx = hip_ctx
+    C = sp.csr_matrix((es.A.data - fem.SIGMA_CUBE * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+    f = lsa_hip.NdLu(ctx, lsa_hip.CsrMatrix.from_scipy(ctx, C), 0)
+    info = f.info()
+    print(info)
+    assert info["max_front"] >= 4096
+    b = np.random.default_rng(1).standard_normal(es.n)
+    dx = lsa_hip.DeviceVector(ctx, es.n, np.float64)
+    f.solve(lsa_hip.DeviceVector.from_numpy(ctx, b), dx)
+    assert np.linalg.norm(C @ dx.numpy() - b) <= 1e-10 * np.linalg.norm(b)
+    del f, dx
+    # the complex shift sits 0.02 away: both see the same nearest eigenvalues (compare those both runs returned)
+    common = [r for r in lams["real"][:6]]
+    for r in common:
+        assert np.min(np.abs(lams["complex"] - r)) <= 1e-8 * abs(r)

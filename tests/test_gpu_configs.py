@@ -117,7 +117,8 @@ def test_refined_meshes_residuals_and_start_vector_independence(case):
     pick = np.array([int(np.argmin(np.abs(lams[1] - r))) for r in lams[0]])
     d = np.abs(lams[1][pick] - lams[0]) / np.abs(lams[0])
     kappa = helpers.eigenvalue_condition_numbers(es, lams[0], vecs[0])
-    bound = np.maximum(1e-8, C_BOUND * kappa * (ress[0] + ress[1][pick]))
+    # (capped: for kappa ~ 1e11 the perturbation bound alone would allow differences of order one; measured 4e-15 ... 5e-8)
+    bound = np.minimum(np.maximum(1e-8, C_BOUND * kappa * (ress[0] + ress[1][pick])), 1e-6)
     print(f"{case}: kappa {np.array2string(kappa, precision=1)}\n differences {np.array2string(d, precision=1)}\n bounds {np.array2string(bound, precision=1)}")
     assert np.all(np.isfinite(kappa)) and np.all(d <= bound), (d, bound)
     assert d[:10].max() <= 1e-8
@@ -182,7 +183,8 @@ def test_s500k_eigenvalues_match_the_golden_fixture():
     # for second-order terms.  1e-8 is asserted wherever that bound allows it, and on the ten nearest the target in any case.
     C_BOUND = 4.0
     kappa, res_ref = np.array(gold["kappa"]), np.array(gold["residuals"])
-    bound = np.maximum(1e-8, C_BOUND * kappa * (res_gpu + res_ref))
+    # (capped at 1e-6: the six outermost modes have kappa up to 2.4e11; measured gaps 1e-7 ... 4e-7, the oracle's own, see below)
+    bound = np.minimum(np.maximum(1e-8, C_BOUND * kappa * (res_gpu + res_ref)), 1e-6)
     print("relative differences to the oracle:", np.array2string(diff, precision=1), "\nbounds:", np.array2string(bound, precision=1),
           "\nkappa:", np.array2string(kappa, precision=1))
     assert np.all(diff <= bound), (diff, bound)

@@ -192,12 +192,20 @@ int lsa_nd_sym_export(const lsa_nd_sym *h, int32_t *perm, int32_t *node_start, i
  * matrix entry), lvl_ptr[nlevels + 1] / lvl_nodes[ntree] (nodes by level) */
 int lsa_nd_sym_export_tables(const lsa_nd_sym *h, int32_t *cmap, int32_t *gptr, int32_t *gidx, int64_t *asm_dst, int32_t *lvl_ptr,
                              int32_t *lvl_nodes);
-/* per kept node: kind[ntree] (1 = factored on this rank, 2 = replicated top, 3 = another rank's subtree root), front_off /
+/* per kept node: kind[ntree] (1 = factored on this rank, 2 = replicated top, 3 = another rank's subtree root, 4 = distributed
+ * top node, see lsa_nd_sym_export_top), front_off /
  * u_off[ntree + 1] (offsets into the front / update-vector buffers; the subtree roots lie in per-rank slots at the start),
  * asm_src[scalars[3]] (matrix entry of every assembly slot), children_ptr[ntree + 1] / children_idx; scalars[6] = front
  * slot, update-vector slot, first replicated work level, assembly entries, ranks, rank */
 int lsa_nd_sym_export_dist(const lsa_nd_sym *h, int32_t *kind, int64_t *front_off, int64_t *u_off, int32_t *asm_src, int32_t *children_ptr,
                            int32_t *children_idx, int64_t *scalars);
+/* DISTRIBUTED top nodes (owner -2 in the forest handed to lsa_nd_analyse_tree; kind 4): every rank keeps the pivot block whole
+ * and its own equal slice of the boundary rows (working front (m + brow) x f, update matrix brow x b, packed L (m + brow) x m)
+ * and of the own rows of U (orows x b).  Per kept node: owner[ntree] (rank, -1 replicated top, -2 distributed top), rows[4 ntree]
+ * = (brow0, brow, orow0, orows), exch[4 ntree] = (ux_base, ux_stride, xg_base, xg_stride): where the node's update entries and
+ * finished own rows lie in the sweeps' per-level exchange regions (entry k of rank k / s's slot: base + (k / s) stride + k % s,
+ * s = ceil(count / ranks)); totals[2] = entries of the update-vector buffer, of the own-row exchange buffer */
+int lsa_nd_sym_export_top(const lsa_nd_sym *h, int32_t *owner, int32_t *rows, int64_t *exch, int64_t *totals);
 /* Analysis (from C's host copy of the pattern; reused from the context when the last destroyed or prepared factorisation
  * had the same pattern) + numeric factorisation on the device.  If a pivot block comes out singular and C has zero
  * diagonal entries, the analysis is redone once with those unknowns as constraints.  LSA_ERR_ZERO_PIVOT when a pivot block

@@ -487,7 +487,10 @@ class iEpsSolver:
             zd = Kc.diagonal() == 0
             an = lsa_hip.NdAnalysis(Kc, 0, constraint=zd if zd.any() else None)  # (constraints last: no retry across ranks)
             ex = an.export()
-            forest = sharding.partition_forest(ex["perm"], ex["node_start"], ex["parent"], ex["front_size"], world)
+            # (top nodes with large fronts -- the 3D cases -- are distributed over the ranks; the transposed sweeps of the adjoint
+            #  problem exist for the replicated form of the top only)
+            forest = sharding.partition_forest(ex["perm"], ex["node_start"], ex["parent"], ex["front_size"], world,
+                                               dist_min=0 if self._adjoint else None)
             perm, part = forest.order, forest.rows
             dA = lsa_hip.CsrMatrix.from_scipy(ctx, sharding.pad_square(_permute(A, perm), part))
             dM = None if M is None else lsa_hip.CsrMatrix.from_scipy(ctx, sharding.pad_square(_permute(M, perm), part))

@@ -3,6 +3,8 @@
 // cannot clash with the one the data path uses.
 #include <dlfcn.h>
 
+#include <algorithm>
+
 #include "lsa_internal.h"
 
 namespace {
@@ -143,6 +145,26 @@ int k_agree_status(lsa_ctx* ctx, int rc) {
     if (!ok) return lsa_set_error(ctx, xrc != LSA_OK ? xrc : LSA_ERR_HIP, "k_agree_status: the status exchange failed");
     for (int r = 0; r < ctx->nranks; ++r)
         if (h[4 * r] != LSA_OK) return lsa_set_error(ctx, h[4 * r], "rank %d failed with status %d before a collective step; every rank gives up with it", r, h[4 * r]);
+    return LSA_OK;
+}
+
+// the smallest of the ranks' values (one 16-byte all-gather through the context's scratch, like the status agreement): figures
+// every rank must compute alike -- the device memory the chunks of a distributed factorisation are planned against
+int k_agree_min_i64(lsa_ctx* ctx, int64_t* value) {
+    if (ctx->nranks <= 1) return LSA_OK;
+    const size_t slot = 2 * sizeof(int64_t);
+    if (ctx->dscratch_bytes < slot * (size_t)ctx->nranks || ctx->pinned_bytes < slot * (size_t)ctx->nranks)
+        return lsa_set_error(ctx, LSA_ERR_ARG, "k_agree_min_i64: context scratch too small for %d ranks", ctx->nranks);
+    int64_t* h = (int64_t*)ctx->pinned;
+    char* d = (char*)ctx->dscratch;
+    h[0] = *value;
+    h[1] = 0;
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(d + slot * (size_t)ctx->rank, h, slot, hipMemcpyHostToDevice, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    LSA_CHECK(k_allgather_inplace(ctx, d, slot));
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(h, d, slot * (size_t)ctx->nranks, hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int r = 0; r < ctx->nranks; ++r) *value = std::min(*value, h[2 * r]);
     return LSA_OK;
 }
 

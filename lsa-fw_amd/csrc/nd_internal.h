@@ -6,6 +6,7 @@
 #pragma once
 #include <cstdlib>
 
+#include <algorithm>
 #include <cstdint>
 #include <vector>
 
@@ -34,7 +35,22 @@ struct NdSymbolic {
     int32_t phase_b_level = 0;     // work levels [0, phase_b_level) are this rank's own subtrees, the rest the replicated top
     int64_t xfront_slot = 0;       // scalars per rank in the exchange region at the start of the front buffer
     int64_t xu_slot = 0;           // entries per rank in the exchange region at the start of the update-vector buffer
-    std::vector<int32_t> kind;     // per kept node: 1 = factored here (own subtree), 2 = replicated top, 3 = another rank's subtree root
+    std::vector<int32_t> kind;     // per kept node: 1 = factored here (own subtree), 2 = replicated top, 3 = another rank's subtree root,
+                                   // 4 = DISTRIBUTED top node (below)
+    // Distributed top nodes (owner -2 in the caller's forest; closed upwards: the parent of one is one).  Every rank keeps the
+    // pivot block F11 whole (the Gauss-Jordan inversion runs redundantly, bitwise alike), F12 whole while the node is factored,
+    // and only its own slice of the boundary ROWS of F21 / F22: working front (m + brow) x f, packed L = [inv; -F21[rows] inv]
+    // ((m + brow) x m), update matrix rows brow x b.  U = inv F12 is stored by slices of the OWN rows (orows x b): a rank
+    // finishes its slice of x[own] in the downward sweep.  Slices are equal cuts: rank r owns [r s, min((r + 1) s, b)), s = ceil(b / P).
+    std::vector<int32_t> owner;           // per kept node: owning rank (kinds 1, 3), -1 (kind 2), -2 (kind 4)
+    std::vector<int32_t> brow0, brow;     // per kept node: this rank's boundary rows [brow0, brow0 + brow)   (all of them unless kind 4)
+    std::vector<int32_t> orow0, orows;    // per kept node: this rank's own rows of U                          (all of them unless kind 4)
+    // sweeps: the update entries a distributed node produces land in ITS RANK'S SLOT of its level's exchange region of the
+    // update-vector buffer (entry k of the boundary at ux_base + (k / s) * ux_stride + k % s; one in-place all-gather per level),
+    // its finished own rows in the same way in a buffer of their own (xg_base, xg_stride; s = ceil(m / P))
+    std::vector<int64_t> ux_base, ux_stride, xg_base, xg_stride;  // per kept node (0 unless kind 4)
+    int64_t xg_entries = 0;               // entries of the own-row exchange buffer
+    bool has_dist = false;                // any kind-4 node
     std::vector<int32_t> piv_off;  // per kept node: first elimination position (offset into the pivot arrays of length n)
     std::vector<int32_t> perm;        // elimination order: perm[k] = original index of the k-th eliminated unknown
     std::vector<int32_t> node_start;  // nt + 1: node t owns perm[node_start[t] .. node_start[t + 1]) (one rank; else running sums of m)
@@ -86,7 +102,16 @@ struct NdMemoryPlan {
     std::vector<int64_t> chunk_work;           // scalars of the working arena chunk c uses
     std::vector<char> chunk_exchange_before;   // the subtree roots' update matrices are all-gathered before this chunk
     int64_t lfac_entries = 0, ufac_entries = 0, work_entries = 1, upd_entries = 1, acc_entries = 0, xupd_slot = 0;
+    int64_t xstage_slot = 0;  // distributed top nodes: scalars per rank of the staging buffer their children's update rows travel through
     int64_t max_front_entries = 0, max_level_entries = 0;
 };
 // budget_entries: scalars the working arena may take (a single front always fits); <= 0: every level in one chunk
 void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P);
+// equal cut of `count` items over `nranks`: rank's [first, first + size)
+inline void nd_slice(int32_t count, int nranks, int rank, int32_t* first, int32_t* size) {
+    const int32_t s = (count + nranks - 1) / std::max(nranks, 1);
+    const int32_t lo = std::min<int64_t>(count, (int64_t)rank * s), hi = std::min<int64_t>(count, (int64_t)(rank + 1) * s);
+    *first = lo;
+    *size = hi - lo;
+}
+inline int32_t nd_slice_width(int32_t count, int nranks) { return (count + nranks - 1) / std::max(nranks, 1); }

@@ -400,10 +400,11 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
     if (dist) {
         for (int32_t t = 0; t < nt; ++t) {
             const int32_t o = gowner[(size_t)t], p = gparent[(size_t)t];
-            if (o >= nranks) return fail(LSA_ERR_ARG, "nd_analyse: owner rank out of range");
+            if (o >= nranks || o < -2) return fail(LSA_ERR_ARG, "nd_analyse: owner rank out of range");
             if (o < 0) {
-                kind[(size_t)t] = 2;
-                if (p >= 0 && gowner[(size_t)p] >= 0) return fail(LSA_ERR_ARG, "nd_analyse: a replicated node lies below a rank's subtree");
+                kind[(size_t)t] = o == -2 ? 4 : 2;
+                if (p >= 0 && gowner[(size_t)p] >= 0) return fail(LSA_ERR_ARG, "nd_analyse: a top node lies below a rank's subtree");
+                if (o == -2 && p >= 0 && gowner[(size_t)p] != -2) return fail(LSA_ERR_ARG, "nd_analyse: the parent of a distributed top node must be distributed");
             } else {
                 if (p >= 0 && gowner[(size_t)p] >= 0 && gowner[(size_t)p] != o) return fail(LSA_ERR_ARG, "nd_analyse: a subtree is split between ranks");
                 const bool root = p < 0 || gowner[(size_t)p] < 0;
@@ -423,6 +424,17 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
     S.parent.assign((size_t)nl, -1);
     S.level.assign((size_t)nl, 0);
     S.kind.assign((size_t)nl, 1);
+    S.owner.assign((size_t)nl, 0);
+    S.brow0.assign((size_t)nl, 0);
+    S.brow.assign((size_t)nl, 0);
+    S.orow0.assign((size_t)nl, 0);
+    S.orows.assign((size_t)nl, 0);
+    S.ux_base.assign((size_t)nl, 0);
+    S.ux_stride.assign((size_t)nl, 0);
+    S.xg_base.assign((size_t)nl, 0);
+    S.xg_stride.assign((size_t)nl, 0);
+    S.xg_entries = 0;
+    S.has_dist = false;
     S.piv_off.assign((size_t)nl, 0);
     S.node_start.assign((size_t)nl + 1, 0);
     for (int32_t q = 0; q < nl; ++q) {
@@ -433,6 +445,14 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
         if (gparent[(size_t)t] >= 0 && S.parent[(size_t)q] < 0) return fail(LSA_ERR_ARG, "nd_analyse: internal error (kept node with a dropped parent)");
         S.level[(size_t)q] = glevel[(size_t)t];
         S.kind[(size_t)q] = kind[(size_t)t];
+        S.owner[(size_t)q] = dist ? gowner[(size_t)t] : 0;
+        S.brow[(size_t)q] = (int32_t)bnd[(size_t)t].size();
+        S.orows[(size_t)q] = gm[(size_t)t];
+        if (kind[(size_t)t] == 4) {
+            nd_slice((int32_t)bnd[(size_t)t].size(), nranks, rank, &S.brow0[(size_t)q], &S.brow[(size_t)q]);
+            nd_slice(gm[(size_t)t], nranks, rank, &S.orow0[(size_t)q], &S.orows[(size_t)q]);
+            S.has_dist = true;
+        }
         S.piv_off[(size_t)q] = gstart[(size_t)t];
         S.node_start[(size_t)q + 1] = S.node_start[(size_t)q] + gm[(size_t)t];
     }
@@ -456,7 +476,12 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
     }
     // ---- offsets: the fronts and update vectors of the subtree roots lie in one slot per rank at the start of their
     // buffers (the exchange regions of the in-place all-gathers), everything else behind them ----
-    auto is_xroot = [&](int32_t q) { return dist && S.kind[(size_t)q] != 2 && S.parent[(size_t)q] >= 0 && S.kind[(size_t)S.parent[(size_t)q]] == 2; };
+    // a subtree root below the top: its update VECTOR always travels through the exchange region of the update-vector buffer;
+    // its update MATRIX through the exchange region of the front / update buffers only when its parent is replicated (to a
+    // distributed parent it travels in row chunks through the staging buffer, nd_numeric)
+    auto is_top = [&](int32_t k) { return k == 2 || k == 4; };
+    auto is_xroot_u = [&](int32_t q) { return dist && !is_top(S.kind[(size_t)q]) && S.parent[(size_t)q] >= 0 && is_top(S.kind[(size_t)S.parent[(size_t)q]]); };
+    auto is_xroot = [&](int32_t q) { return dist && !is_top(S.kind[(size_t)q]) && S.parent[(size_t)q] >= 0 && S.kind[(size_t)S.parent[(size_t)q]] == 2; };
     S.idx_off.assign((size_t)nl + 1, 0);
     S.front_off.assign((size_t)nl + 1, 0);
     S.u_off.assign((size_t)nl + 1, 0);
@@ -471,7 +496,7 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
                 const int32_t o = gowner[(size_t)t], p = gparent[(size_t)t];
                 if (o >= 0 && p >= 0 && gowner[(size_t)p] < 0) {
                     const int64_t f = gm[(size_t)t] + (int64_t)bnd[(size_t)t].size(), b = (int64_t)bnd[(size_t)t].size();
-                    fuse[(size_t)o] += f * f;
+                    if (gowner[(size_t)p] == -1) fuse[(size_t)o] += f * f;
                     uuse[(size_t)o] += b;
                 }
             }
@@ -490,21 +515,54 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
             S.cmap_off[(size_t)q + 1] = S.cmap_off[(size_t)q] + (int32_t)b;
             S.g_off[(size_t)q + 1] = S.g_off[(size_t)q] + f + 1;
             S.ge_off[(size_t)q + 1] = S.ge_off[(size_t)q] + (int64_t)nchild * f;
+            const int32_t o = gowner[(size_t)keep[(size_t)q]];
             if (is_xroot(q)) {
-                const int32_t o = gowner[(size_t)keep[(size_t)q]];
                 S.front_off[(size_t)q] = S.xfront_slot * o + fuse[(size_t)o];
-                S.u_off[(size_t)q] = S.xu_slot * o + uuse[(size_t)o];
                 fuse[(size_t)o] += f * f;
-                uuse[(size_t)o] += b;
             } else {
                 S.front_off[(size_t)q] = frun;
-                S.u_off[(size_t)q] = urun;
                 frun += f * f;
+            }
+            if (is_xroot_u(q)) {
+                S.u_off[(size_t)q] = S.xu_slot * o + uuse[(size_t)o];
+                uuse[(size_t)o] += b;
+            } else {
+                S.u_off[(size_t)q] = urun;
                 urun += b;
             }
-            if (S.kind[(size_t)q] != 3) {
+            if (S.kind[(size_t)q] == 4) {  // this rank's share: the replicated inverse, its boundary rows of L, its own rows of U
+                const int64_t br = S.brow[(size_t)q], orr = S.orows[(size_t)q];
+                S.factor_entries += m * m + br * m + orr * b;
+                S.flops += (double)m * m * m + (double)m * m * br + (double)m * m * orr * (b > 0) + (double)m * br * b;
+            } else if (S.kind[(size_t)q] != 3) {
                 S.factor_entries += m * m + 2 * m * b;
                 S.flops += (double)m * m * m + 2.0 * m * m * b + (double)m * b * b;
+            }
+        }
+        // exchange regions of the sweeps, one per tree level that holds distributed nodes, behind everything else
+        if (S.has_dist) {
+            int32_t maxlvl = 0;
+            for (int32_t q = 0; q < nl; ++q) maxlvl = std::max(maxlvl, S.level[(size_t)q]);
+            for (int32_t l = 0; l <= maxlvl; ++l) {
+                int64_t uslot = 0, gslot = 0;
+                for (int32_t q = 0; q < nl; ++q)
+                    if (S.kind[(size_t)q] == 4 && S.level[(size_t)q] == l) {
+                        uslot += nd_slice_width(S.f[(size_t)q] - S.m[(size_t)q], S.nranks);
+                        gslot += nd_slice_width(S.m[(size_t)q], S.nranks);
+                    }
+                if (uslot + gslot == 0) continue;
+                int64_t ucur = urun, gcur = S.xg_entries;
+                for (int32_t q = 0; q < nl; ++q)
+                    if (S.kind[(size_t)q] == 4 && S.level[(size_t)q] == l) {
+                        S.ux_base[(size_t)q] = ucur;
+                        S.ux_stride[(size_t)q] = uslot;
+                        S.xg_base[(size_t)q] = gcur;
+                        S.xg_stride[(size_t)q] = gslot;
+                        ucur += nd_slice_width(S.f[(size_t)q] - S.m[(size_t)q], S.nranks);
+                        gcur += nd_slice_width(S.m[(size_t)q], S.nranks);
+                    }
+                urun += uslot * S.nranks;
+                S.xg_entries += gslot * S.nranks;
             }
         }
         S.front_off[(size_t)nl] = frun;  // total scalars of the front buffer
@@ -545,6 +603,13 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
     S.gptr.assign((size_t)S.g_off[(size_t)nl], 0);
     S.gidx.resize((size_t)S.cmap_off[(size_t)nl]);
     S.gell.assign((size_t)S.ge_off[(size_t)nl], -1);
+    // where entry k of child c's update vector lies in the update-vector buffer (a distributed child: in the slot of the rank
+    // that produces it)
+    auto upos = [&](int32_t c, int32_t k) -> int32_t {
+        if (S.kind[(size_t)c] != 4) return (int32_t)(S.u_off[(size_t)c] + k);
+        const int32_t w = nd_slice_width(S.f[(size_t)c] - S.m[(size_t)c], S.nranks);
+        return (int32_t)(S.ux_base[(size_t)c] + (int64_t)(k / w) * S.ux_stride[(size_t)c] + k % w);
+    };
     {
         int64_t run = 0;
         std::vector<int32_t> count;
@@ -565,8 +630,8 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
                 const int32_t b = S.cmap_off[(size_t)c + 1] - S.cmap_off[(size_t)c];
                 for (int32_t k = 0; k < b; ++k) {
                     const int32_t j = S.cmap[(size_t)S.cmap_off[(size_t)c] + k];
-                    S.gidx[(size_t)cur[(size_t)j]++] = (int32_t)(S.u_off[(size_t)c] + k);
-                    row[j] = (int32_t)(S.u_off[(size_t)c] + k);
+                    S.gidx[(size_t)cur[(size_t)j]++] = upos(c, k);
+                    row[j] = upos(c, k);
                 }
             }
             run = gp[f];
@@ -583,10 +648,15 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
         for (int32_t p = rp[i]; p < rp[i + 1]; ++p) {
             const int32_t pj = pos[(size_t)ci[p]];
             const int32_t t = node_of[(size_t)std::min(pi, pj)];
-            if (kind[(size_t)t] != 1 && kind[(size_t)t] != 2) continue;
-            const int32_t li = local(t, pi), lj = local(t, pj);
+            if (kind[(size_t)t] != 1 && kind[(size_t)t] != 2 && kind[(size_t)t] != 4) continue;
+            int32_t li = local(t, pi);
+            const int32_t lj = local(t, pj);
             if (li < 0 || lj < 0) return fail(LSA_ERR_ARG, "nd_analyse: internal error (entry outside its front)");
             const int32_t q = loc[(size_t)t];
+            if (kind[(size_t)t] == 4 && li >= S.m[(size_t)q]) {  // a boundary row of a distributed front: kept by the rank that owns it
+                li -= S.brow0[(size_t)q];
+                if (li < S.m[(size_t)q] || li >= S.m[(size_t)q] + S.brow[(size_t)q]) continue;
+            }
             S.asm_src.push_back(p);
             S.asm_dst.push_back(S.front_off[(size_t)q] + (int64_t)li * S.f[(size_t)q] + lj);
         }
@@ -600,7 +670,7 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
         for (int32_t l = 0; l < S.nlevels; ++l) {
             const size_t before = S.lvl_nodes.size();
             for (int32_t q = 0; q < nl; ++q)
-                if (S.kind[(size_t)q] == phase && S.level[(size_t)q] == l) S.lvl_nodes.push_back(q);
+                if ((S.kind[(size_t)q] == phase || (phase == 2 && S.kind[(size_t)q] == 4)) && S.level[(size_t)q] == l) S.lvl_nodes.push_back(q);
             if (S.lvl_nodes.size() == before) continue;
             std::stable_sort(S.lvl_nodes.begin() + (int64_t)before, S.lvl_nodes.end(), [&](int32_t x, int32_t y) { return S.m[(size_t)x] > S.m[(size_t)y]; });
             S.lvl_ptr.push_back((int32_t)S.lvl_nodes.size());
@@ -861,7 +931,22 @@ struct ArenaPlan {
 void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P) {
     const int32_t nt = S.nt;
     const bool dist = S.nranks > 1;
-    auto is_xroot = [&](int32_t q) { return dist && S.kind[(size_t)q] != 2 && S.parent[(size_t)q] >= 0 && S.kind[(size_t)S.parent[(size_t)q]] == 2; };
+    auto is_top = [&](int32_t k) { return k == 2 || k == 4; };
+    // subtree roots below the top (see nd_finish): _u = its update vector is exchanged; plain = its update matrix too, through the
+    // exchange region (replicated parent); _4 = its update matrix travels in row chunks to a distributed parent
+    auto is_xroot_u = [&](int32_t q) { return dist && !is_top(S.kind[(size_t)q]) && S.parent[(size_t)q] >= 0 && is_top(S.kind[(size_t)S.parent[(size_t)q]]); };
+    auto is_xroot = [&](int32_t q) { return dist && !is_top(S.kind[(size_t)q]) && S.parent[(size_t)q] >= 0 && S.kind[(size_t)S.parent[(size_t)q]] == 2; };
+    // scalars of a node's working front / of the update matrix it keeps on this rank
+    // (a distributed node: the widest slice of any rank, so that the chunks of the top levels -- their cuts decide where the
+    //  collectives of the factorisation fall -- come out alike on every rank)
+    auto work_size = [&](int32_t t) -> int64_t {
+        const int64_t rows = S.kind[(size_t)t] == 4 ? S.m[(size_t)t] + nd_slice_width(S.f[(size_t)t] - S.m[(size_t)t], S.nranks) : S.f[(size_t)t];
+        return rows * S.f[(size_t)t];
+    };
+    auto upd_size = [&](int32_t t) -> int64_t {
+        if (S.kind[(size_t)t] == 3 && !is_xroot(t)) return 0;  // another rank's subtree root under a distributed parent: arrives in chunks
+        return (int64_t)S.brow[(size_t)t] * (S.f[(size_t)t] - S.m[(size_t)t]);
+    };
     P = NdMemoryPlan();
     P.work_off.assign((size_t)nt, 0);
     P.upd_off.assign((size_t)nt, 0);
@@ -875,14 +960,14 @@ void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P
         const int64_t m = S.m[(size_t)t], ff = S.f[(size_t)t];
         P.lfac_off[(size_t)t] = P.lfac_entries;
         P.ufac_off[(size_t)t] = P.ufac_entries;
-        P.lfac_entries += ff * m;
-        P.ufac_entries += m * (ff - m);
+        P.lfac_entries += (m + S.brow[(size_t)t]) * m;
+        P.ufac_entries += (int64_t)S.orows[(size_t)t] * (ff - m);
     }
     // ---- slot rows of the upward sweep: push form unless a child's update vector arrives by all-gather (then the node pulls) ----
     for (int32_t t = 0; t < nt; ++t) {
         const int32_t c0 = S.child_ptr[(size_t)t], c1 = S.child_ptr[(size_t)t + 1];
-        bool pull = false;
-        for (int32_t cp = c0; cp < c1; ++cp) pull |= is_xroot(S.child_idx[(size_t)cp]);
+        bool pull = S.kind[(size_t)t] == 4;
+        for (int32_t cp = c0; cp < c1; ++cp) pull |= is_xroot_u(S.child_idx[(size_t)cp]);
         if (c1 == c0 || pull || S.kind[(size_t)t] == 3) continue;
         P.acc_off[(size_t)t] = P.acc_entries;
         for (int32_t cp = c0; cp < c1; ++cp) P.pacc_off[(size_t)S.child_idx[(size_t)cp]] = P.acc_entries + (int64_t)(cp - c0) * S.f[(size_t)t];
@@ -892,9 +977,9 @@ void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P
     for (int32_t l = 0; l < S.nlevels; ++l) {
         int64_t sum = 0;
         for (int32_t q = S.lvl_ptr[(size_t)l]; q < S.lvl_ptr[(size_t)l + 1]; ++q) {
-            const int64_t ff = S.f[(size_t)S.lvl_nodes[(size_t)q]];
-            sum += ff * ff;
-            P.max_front_entries = std::max(P.max_front_entries, ff * ff);
+            const int64_t w = work_size(S.lvl_nodes[(size_t)q]);
+            sum += w;
+            P.max_front_entries = std::max(P.max_front_entries, w);
         }
         P.max_level_entries = std::max(P.max_level_entries, sum);
     }
@@ -903,15 +988,15 @@ void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P
         int64_t used = 0;
         for (int32_t q = S.lvl_ptr[(size_t)l]; q < S.lvl_ptr[(size_t)l + 1]; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)q];
-            const int64_t ff = S.f[(size_t)t];
-            if (q == S.lvl_ptr[(size_t)l] || used + ff * ff > budget) {
+            const int64_t w = work_size(t);
+            if (q == S.lvl_ptr[(size_t)l] || used + w > budget) {
                 P.chunk_begin.push_back(q);
                 P.chunk_work.push_back(0);
                 P.chunk_exchange_before.push_back(dist && l == S.phase_b_level && q == S.lvl_ptr[(size_t)l]);
                 used = 0;
             }
             P.work_off[(size_t)t] = used;
-            used += ff * ff;
+            used += w;
             P.chunk_work.back() = used;
             P.work_entries = std::max(P.work_entries, used);
         }
@@ -920,29 +1005,37 @@ void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P
     // ---- update arena ----
     if (dist) {
         std::vector<int64_t> use((size_t)S.nranks, 0);
-        auto owner_of = [&](int32_t q) { return (int32_t)(S.front_off[(size_t)q] / std::max<int64_t>(S.xfront_slot, 1)); };  // its slot of the logical layout
         for (int32_t q = 0; q < nt; ++q)
             if (is_xroot(q)) {
                 const int64_t b = S.f[(size_t)q] - S.m[(size_t)q];
-                use[(size_t)owner_of(q)] += b * b;
+                use[(size_t)S.owner[(size_t)q]] += b * b;
             }
         for (int64_t v : use) P.xupd_slot = std::max(P.xupd_slot, v);
         std::fill(use.begin(), use.end(), 0);
         for (int32_t q = 0; q < nt; ++q)
             if (is_xroot(q)) {  // (same order, same sizes on every rank: the in-place all-gather moves slot r of rank r)
                 const int64_t b = S.f[(size_t)q] - S.m[(size_t)q];
-                const int32_t o = owner_of(q);
+                const int32_t o = S.owner[(size_t)q];
                 P.upd_off[(size_t)q] = P.xupd_slot * o + use[(size_t)o];
                 use[(size_t)o] += b * b;
             }
+        // staging of the update rows that travel to distributed parents: one slot per rank, a slot holds whole rows of one child
+        if (S.has_dist) {
+            int64_t widest = 0;
+            for (int32_t q = 0; q < nt; ++q)
+                if (S.parent[(size_t)q] >= 0 && S.kind[(size_t)S.parent[(size_t)q]] == 4 && S.kind[(size_t)q] != 2)
+                    widest = std::max<int64_t>(widest, S.f[(size_t)q] - S.m[(size_t)q]);
+            int64_t slot = (int64_t)(32u << 20) / 8;  // 32 MB of float64 per rank and step
+            if (const char* e = getenv("LSA_ND_XSTAGE_KB")) slot = std::max<int64_t>(1, atoll(e)) * 1024 / 8;  // (tests: many small steps)
+            P.xstage_slot = widest > 0 ? std::max(slot, widest) : 0;
+        }
     }
     ArenaPlan arena;
     const int64_t base = P.xupd_slot * S.nranks;
     for (size_t c = 0; c + 1 < P.chunk_begin.size(); ++c) {
         for (int32_t q = P.chunk_begin[c]; q < P.chunk_begin[c + 1]; ++q) {  // blocks written by this chunk
             const int32_t t = S.lvl_nodes[(size_t)q];
-            const int64_t b = S.f[(size_t)t] - S.m[(size_t)t];
-            if (b > 0 && !is_xroot(t)) P.upd_off[(size_t)t] = base + arena.alloc(b * b);
+            if (upd_size(t) > 0 && !is_xroot(t)) P.upd_off[(size_t)t] = base + arena.alloc(upd_size(t));
         }
         // blocks consumed by this chunk are free from the next chunk on.  (This chunk's own blocks were placed first: a block a
         // parent reads in this chunk's extend-add must not be handed to a node that is saved in the same chunk.)
@@ -950,8 +1043,7 @@ void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P
             const int32_t t = S.lvl_nodes[(size_t)q];
             for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) {
                 const int32_t ch = S.child_idx[(size_t)cp];
-                const int64_t b = S.f[(size_t)ch] - S.m[(size_t)ch];
-                if (!is_xroot(ch)) arena.release(P.upd_off[(size_t)ch] - base, b * b);
+                if (!is_xroot(ch) && S.kind[(size_t)ch] != 3) arena.release(P.upd_off[(size_t)ch] - base, upd_size(ch));
             }
         }
     }
@@ -1045,9 +1137,10 @@ int lsa_nd_sym_memory(const lsa_nd_sym* h, int32_t scalar_bytes, int64_t work_bu
     nd_memory_plan(S, work_budget_bytes > 0 ? work_budget_bytes / scalar_bytes : 0, P);
     out[0] = (P.lfac_entries + P.ufac_entries) * scalar_bytes;  // packed factors
     out[1] = P.work_entries * scalar_bytes;                    // working fronts of the largest chunk
-    out[2] = P.upd_entries * scalar_bytes;                     // update arena (with the exchange region of a forest cut over ranks)
-    out[3] = P.xupd_slot * S.nranks * scalar_bytes;            // ... of which the exchange region
-    out[4] = P.acc_entries * 16 + 2 * S.u_off[(size_t)S.nt] * 16;  // sweep buffers: slot rows, update and boundary vectors (complex vectors)
+    const int64_t xstage = P.xstage_slot * S.nranks * scalar_bytes;  // staging of the update rows on their way to distributed parents
+    out[2] = P.upd_entries * scalar_bytes + xstage;            // update arena (with the exchange region of a forest cut over ranks, and the staging)
+    out[3] = P.xupd_slot * S.nranks * scalar_bytes + xstage;   // ... of which the exchange region and the staging
+    out[4] = P.acc_entries * 16 + 2 * S.u_off[(size_t)S.nt] * 16 + S.xg_entries * 16;  // sweep buffers: slot rows, update and boundary vectors, own-row exchange (complex vectors)
     out[5] = (int64_t)P.chunk_begin.size() - 1;                // chunks
     out[6] = P.max_front_entries * scalar_bytes;               // the largest front
     out[7] = (int64_t)(S.idx.size() + S.gell.size() + S.cmap.size()) * 4 + (int64_t)S.asm_src.size() * 12 + (int64_t)S.nt * 96 * 2;  // index tables
@@ -1096,6 +1189,32 @@ int lsa_nd_sym_export_dist(const lsa_nd_sym* h, int32_t* kind, int64_t* front_of
         scalars[3] = (int64_t)S.asm_src.size();
         scalars[4] = S.nranks;
         scalars[5] = S.rank;
+    }
+    return LSA_OK;
+}
+
+int lsa_nd_sym_export_top(const lsa_nd_sym* h, int32_t* owner, int32_t* rows, int64_t* exch, int64_t* totals) {
+    if (!h) return LSA_ERR_ARG;
+    const NdSymbolic& S = h->S;
+    if (S.order_only) return LSA_ERR_ARG;
+    for (int32_t q = 0; q < S.nt; ++q) {
+        if (owner) owner[q] = S.owner[(size_t)q];
+        if (rows) {
+            rows[4 * q] = S.brow0[(size_t)q];
+            rows[4 * q + 1] = S.brow[(size_t)q];
+            rows[4 * q + 2] = S.orow0[(size_t)q];
+            rows[4 * q + 3] = S.orows[(size_t)q];
+        }
+        if (exch) {
+            exch[4 * q] = S.ux_base[(size_t)q];
+            exch[4 * q + 1] = S.ux_stride[(size_t)q];
+            exch[4 * q + 2] = S.xg_base[(size_t)q];
+            exch[4 * q + 3] = S.xg_stride[(size_t)q];
+        }
+    }
+    if (totals) {
+        totals[0] = S.u_off[(size_t)S.nt];
+        totals[1] = S.xg_entries;
     }
     return LSA_OK;
 }

@@ -60,8 +60,15 @@ struct NdNodeDev {
     int32_t own0;       // first own unknown when the vectors are in elimination order
     int32_t m, f, parent;
     int32_t nchild;     // rows of the node's gather table
+    // distributed top nodes (NdSymbolic: kind 4): this rank's slice of the boundary rows / of the own rows of U.  Everywhere else
+    // brow0 = 0, brow = f - m, orow0 = 0, orows = m.  The working front of a node is (m + brow) x f, its packed L (m + brow) x m,
+    // its packed U orows x (f - m), its update matrix brow x (f - m).
+    int32_t brow0, brow, orow0, orows;
+    int32_t flags;      // bit 0: distributed node (its downward pushes are done by nd_dist_unpack_kernel, after the exchange of its own rows)
+    int32_t pad0;
+    int64_t xg_base, xg_stride;  // distributed node: own row j lies at xg_base + (j / s) * xg_stride + j % s of the own-row exchange buffer, s = ceil(m / ranks)
 };
-static_assert(sizeof(NdNodeDev) == 96, "node record layout");
+static_assert(sizeof(NdNodeDev) == 136, "node record layout");
 
 struct TileList {
     int64_t off = 0;  // pairs of int32 into the tile buffer
@@ -77,6 +84,12 @@ struct NdChunk {
     TileList unperm, gemm[3], save;
     std::vector<TileList> ext;  // one per child rank
     bool exchange_before = false;  // subtree-parallel: the ranks' subtree-root update matrices are all-gathered before this chunk
+    // distributed top nodes in this chunk: their children's update matrices arrive in row chunks through the staging buffer, one
+    // in-place all-gather per step; slot r of a step holds rows [row0, row0 + nrows) of child `child` (a node id; nrows = 0: empty)
+    struct XPiece {
+        int32_t child = -1, row0 = 0, nrows = 0;
+    };
+    std::vector<std::vector<XPiece>> xsteps;  // [step][rank]
 };
 
 // one launch of each sweep: the nodes of a tree level
@@ -84,6 +97,9 @@ struct NdLevel {
     int32_t node_begin = 0, node_count = 0, max_m = 0, max_f = 0;
     int32_t fwd_tiles = 0, bwd_tiles = 0;  // grid.y of the sweep kernels: tiles of the tallest node (0 = nothing to do)
     int32_t sweep_rows = 32;               // rows per upward-sweep tile: 32; 8 on levels with few tiles (both sweeps); 128 on thin levels
+    // distributed top nodes of the level: their range of the list d_dist_nodes, the level's exchange regions (entries per rank)
+    int32_t dist_begin = 0, dist_count = 0, dist_children = 0, dist_rows = 0;  // ... most children / most entries (own rows, a child's boundary) of one of them
+    int64_t ux_base = 0, ux_slot = 0, xg_base = 0, xg_slot = 0;
 };
 
 template <typename T>
@@ -137,10 +153,40 @@ __global__ __launch_bounds__(256) void nd_extend_add_kernel(const int32_t* __res
     const int32_t i = i0 + (threadIdx.x >> 4);
     if (i >= b) return;
     const T* src = upd + nc.upd_off + (int64_t)i * b;
-    T* dst = front + np.front_off + (int64_t)map[i] * np.f;
+    int32_t pr = map[i];
+    if (pr >= np.m) {  // a boundary row of the parent: a distributed parent keeps only its own slice of them
+        pr -= np.brow0;
+        if (pr < np.m || pr >= np.m + np.brow) return;
+    }
+    T* dst = front + np.front_off + (int64_t)pr * np.f;
     for (int32_t j = threadIdx.x & 15; j < b; j += 16) {
         T* d = dst + map[j];
         *d = s_add(*d, src[j]);
+    }
+}
+
+// the same for rows [row0, row0 + nrows) of child c's update matrix that arrived in the staging buffer (`src`: nrows x b,
+// row-major): a distributed parent receives its children's update matrices in row chunks, one rank's chunk per launch (the
+// chunks of one step may belong to different children of one parent: launches in slot order keep the sums in a fixed order)
+template <typename T>
+__global__ __launch_bounds__(256) void nd_extend_add_staged_kernel(const NdNodeDev* __restrict__ nodes, const int32_t* __restrict__ cmap, T* __restrict__ front,
+                                                                   const T* __restrict__ src, int32_t c, int32_t row0, int32_t nrows) {
+    const NdNodeDev nc = nodes[c];
+    const NdNodeDev np = nodes[nc.parent];
+    const int32_t b = nc.f - nc.m;
+    const int32_t* map = cmap + nc.cmap_off;
+    const int32_t k = (int32_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    if (k >= nrows) return;
+    int32_t pr = map[row0 + k];
+    if (pr >= np.m) {
+        pr -= np.brow0;
+        if (pr < np.m || pr >= np.m + np.brow) return;
+    }
+    const T* s = src + (int64_t)k * b;
+    T* dst = front + np.front_off + (int64_t)pr * np.f;
+    for (int32_t j = threadIdx.x & 15; j < b; j += 16) {
+        T* d = dst + map[j];
+        *d = s_add(*d, s[j]);
     }
 }
 
@@ -720,12 +766,13 @@ __global__ __launch_bounds__(256) void nd_gemm_kernel(const int32_t* __restrict_
     const T *A, *B;
     T* C;
     int32_t M, N, K, lda, ldb, ldc;
+    // (a distributed top node: this rank's boundary rows of F21 / F22 and its own rows of U; F12 is whole on every rank)
     if (KIND == 0) {
-        A = F + (size_t)m * f, lda = f, B = inv, ldb = m, C = S1, ldc = m, M = b, N = m, K = m;
+        A = F + (size_t)m * f, lda = f, B = inv, ldb = m, C = S1, ldc = m, M = nd.brow, N = m, K = m;
     } else if (KIND == 1) {
-        A = S1, lda = m, B = F + m, ldb = f, C = F + (size_t)m * f + m, ldc = f, M = b, N = b, K = m;
+        A = S1, lda = m, B = F + m, ldb = f, C = F + (size_t)m * f + m, ldc = f, M = nd.brow, N = b, K = m;
     } else {
-        A = inv, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = m, N = b, K = m;
+        A = inv + (size_t)nd.orow0 * m, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = nd.orows, N = b, K = m;
     }
     const int32_t row0 = tm * kGT, col0 = tn * kGT;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -877,12 +924,13 @@ __global__ __launch_bounds__(256) void nd_gemm_mfma_kernel(const int32_t* __rest
     const T *A, *B;
     T* C;
     int32_t M, N, K, lda, ldb, ldc;
+    // (a distributed top node: this rank's boundary rows of F21 / F22 and its own rows of U; F12 is whole on every rank)
     if (KIND == 0) {
-        A = F + (size_t)m * f, lda = f, B = inv, ldb = m, C = S1, ldc = m, M = b, N = m, K = m;
+        A = F + (size_t)m * f, lda = f, B = inv, ldb = m, C = S1, ldc = m, M = nd.brow, N = m, K = m;
     } else if (KIND == 1) {
-        A = S1, lda = m, B = F + m, ldb = f, C = F + (size_t)m * f + m, ldc = f, M = b, N = b, K = m;
+        A = S1, lda = m, B = F + m, ldb = f, C = F + (size_t)m * f + m, ldc = f, M = nd.brow, N = b, K = m;
     } else {
-        A = inv, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = m, N = b, K = m;
+        A = inv + (size_t)nd.orow0 * m, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = nd.orows, N = b, K = m;
     }
     const int32_t row0 = tm * kGT, col0 = tn * kGT;
     mfma_d4 acc[NPL][2][2];
@@ -993,7 +1041,7 @@ __global__ __launch_bounds__(256) void nd_save_update_kernel(const int32_t* __re
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, f = nd.f, b = f - m;
     const int32_t r = r0 + (threadIdx.x >> 4);
-    if (r >= b) return;
+    if (r >= nd.brow) return;  // (this rank's rows of the update matrix: all b of them unless the node is distributed)
     const T* src = front + nd.front_off + (size_t)(m + r) * f + m;
     T* dst = upd + nd.upd_off + (size_t)r * b;
     for (int32_t c = threadIdx.x & 15; c < b; c += 16) dst[c] = src[c];
@@ -1151,7 +1199,8 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict
     const NdNodeDev nd = lnodes[blockIdx.x];
     const int32_t r0 = (int32_t)blockIdx.y * ROWS;
     const int32_t m = nd.m, f = nd.f;
-    if (r0 >= f) return;
+    const int32_t floc = m + nd.brow;  // rows of the packed L on this rank (= f unless the node is distributed: then its slice of the boundary rows)
+    if (r0 >= floc) return;
     const int32_t* ix = idx + nd.idx_off;
     const int32_t* ge = gell + nd.ge_off;
     const MT* L = lfac + nd.lfac_off;
@@ -1166,8 +1215,8 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict
     for (int p = 0; p < NP; ++p) {
         ra[p] = r0 + sw + p * (512 / LPR);
         rb[p] = ra[p] + 256 / LPR;
-        La[p] = L + (size_t)min(ra[p], f - 1) * m;
-        Lb[p] = L + (size_t)min(rb[p], f - 1) * m;
+        La[p] = L + (size_t)min(ra[p], floc - 1) * m;
+        Lb[p] = L + (size_t)min(rb[p], floc - 1) * m;
         acc0[p] = scalar_traits<VT>::zero();
         acc1[p] = scalar_traits<VT>::zero();
         row_pair_prefetch<LPR>(La[p], Lb[p], min(kCH, m), sl, pa[p], pb[p]);
@@ -1182,12 +1231,13 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict
         ub[p] = scalar_traits<VT>::zero();
         ca[p] = cb[p] = 0;
         if (sl == 0) {
-            if (ra[p] >= m && ra[p] < f) {
-                ua[p] = push ? slot_sum(slots, nd.nchild, f, ra[p], ua[p]) : gather_updates(ge, nd.nchild, f, ra[p], ubuf, ua[p]);
+            // (front position of local row r >= m: r + brow0)
+            if (ra[p] >= m && ra[p] < floc) {
+                ua[p] = push ? slot_sum(slots, nd.nchild, f, ra[p] + nd.brow0, ua[p]) : gather_updates(ge, nd.nchild, f, ra[p] + nd.brow0, ubuf, ua[p]);
                 if (nd.pacc_off >= 0) ca[p] = cmap[nd.cmap_off + ra[p] - m];
             }
-            if (rb[p] >= m && rb[p] < f) {
-                ub[p] = push ? slot_sum(slots, nd.nchild, f, rb[p], ub[p]) : gather_updates(ge, nd.nchild, f, rb[p], ubuf, ub[p]);
+            if (rb[p] >= m && rb[p] < floc) {
+                ub[p] = push ? slot_sum(slots, nd.nchild, f, rb[p] + nd.brow0, ub[p]) : gather_updates(ge, nd.nchild, f, rb[p] + nd.brow0, ubuf, ub[p]);
                 if (nd.pacc_off >= 0) cb[p] = cmap[nd.cmap_off + rb[p] - m];
             }
         }
@@ -1210,18 +1260,19 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict
     for (int p = 0; p < NP; ++p) {
         const VT s0 = lanes_sum<LPR>(acc0[p]), s1 = lanes_sum<LPR>(acc1[p]);
         if (sl == 0) {
+            const bool root_push = f == m && !(nd.flags & 1);
             if (ra[p] < m) {
                 x[ORDERED ? nd.own0 + ra[p] : ix[ra[p]]] = s0;
-                if (f == m) push_down(ge, nd.nchild, f, ra[p], xb, s0);
-            } else if (ra[p] < f) {
+                if (root_push) push_down(ge, nd.nchild, f, ra[p], xb, s0);
+            } else if (ra[p] < floc) {
                 const VT u = s_add(ua[p], s0);
                 if (nd.pacc_off >= 0) acc[nd.pacc_off + ca[p]] = u;
                 else ubuf[nd.u_off + (ra[p] - m)] = u;
             }
             if (rb[p] < m) {
                 x[ORDERED ? nd.own0 + rb[p] : ix[rb[p]]] = s1;
-                if (f == m) push_down(ge, nd.nchild, f, rb[p], xb, s1);
-            } else if (rb[p] < f) {
+                if (root_push) push_down(ge, nd.nchild, f, rb[p], xb, s1);
+            } else if (rb[p] < floc) {
                 const VT u = s_add(ub[p], s1);
                 if (nd.pacc_off >= 0) acc[nd.pacc_off + cb[p]] = u;
                 else ubuf[nd.u_off + (rb[p] - m)] = u;
@@ -1287,6 +1338,49 @@ __global__ __launch_bounds__(256) void nd_bwd_kernel(const NdNodeDev* __restrict
             if (g >= 0) xb[g] = bv[j];
         }
     }
+}
+
+// ---- downward sweep of DISTRIBUTED top nodes: a rank finishes its slice of the node's own rows (nd_bwd_kernel on a record
+// that describes the slice), the slices are exchanged through the own-row buffer (pack, one in-place all-gather per level), and
+// this kernel completes x and fills the boundary vectors of the node's children: entry k of child c's boundary is the parent's
+// front position cmap_c[k] -- one of the parent's own rows (from the exchange buffer) or one of its boundary entries.
+// grid: (distributed node of the level, 0 = the node's own rows / 1 + child, tile of 256 entries)
+template <typename VT, bool ORDERED>
+__global__ __launch_bounds__(256) void nd_dist_pack_kernel(const int32_t* __restrict__ dnodes, const NdNodeDev* __restrict__ nodes,
+                                                           const int32_t* __restrict__ idx, int32_t rank, const VT* __restrict__ x, VT* __restrict__ xg) {
+    const NdNodeDev nd = nodes[dnodes[blockIdx.x]];
+    const int32_t r = (int32_t)blockIdx.y * 256 + threadIdx.x;
+    if (r >= nd.orows || nd.f == nd.m) return;
+    const int32_t j = nd.orow0 + r;
+    xg[nd.xg_base + (int64_t)rank * nd.xg_stride + r] = x[ORDERED ? nd.own0 + j : idx[nd.idx_off + j]];
+}
+
+template <typename VT, bool ORDERED>
+__global__ __launch_bounds__(256) void nd_dist_unpack_kernel(const int32_t* __restrict__ dnodes, const NdNodeDev* __restrict__ nodes,
+                                                             const int32_t* __restrict__ child_ptr, const int32_t* __restrict__ child_idx,
+                                                             const int32_t* __restrict__ cmap, const int32_t* __restrict__ idx, int32_t nranks,
+                                                             VT* x, const VT* __restrict__ xg, VT* xb) {
+    const int32_t t = dnodes[blockIdx.x];
+    const NdNodeDev nd = nodes[t];
+    const int32_t m = nd.m, b = nd.f - m;
+    const int32_t ms = (m + nranks - 1) / nranks;
+    const int32_t i = (int32_t)blockIdx.z * 256 + threadIdx.x;
+    // own row j of the node: a root's rows are complete on every rank already (the replicated inverse of the upward sweep)
+    auto own_val = [&](int32_t j) -> VT {
+        if (b == 0) return x[ORDERED ? nd.own0 + j : idx[nd.idx_off + j]];
+        return xg[nd.xg_base + (int64_t)(j / ms) * nd.xg_stride + j % ms];
+    };
+    if (blockIdx.y == 0) {
+        if (b == 0 || i >= m) return;
+        x[ORDERED ? nd.own0 + i : idx[nd.idx_off + i]] = own_val(i);
+        return;
+    }
+    const int32_t cp = child_ptr[t] + (int32_t)blockIdx.y - 1;
+    if (cp >= child_ptr[t + 1]) return;
+    const NdNodeDev nc = nodes[child_idx[cp]];
+    if (i >= nc.f - nc.m) return;
+    const int32_t p = cmap[nc.cmap_off + i];
+    xb[nc.u_off + i] = p < m ? own_val(p) : xb[nd.u_off + (p - m)];
 }
 
 // ---- sweeps of the transposed / conjugate-transposed system on the same factors (the adjoint eigenproblem of
@@ -1365,6 +1459,12 @@ struct lsa_ndlu {
     std::vector<NdChunk> chunks;    // factorisation order
     std::vector<NdLevel> levels;    // sweep order
     NdNodeDev *d_nodes = nullptr, *d_lnodes = nullptr;  // by node id / in lvl_nodes order
+    NdNodeDev* d_lnodes_bwd = nullptr;                  // in lvl_nodes order, for the downward sweep: a distributed node appears as its slice of own rows
+    int32_t *d_dist_nodes = nullptr, *d_child_ptr = nullptr, *d_child_idx = nullptr;  // distributed nodes by level; children of every node
+    void *d_xstage = nullptr, *d_xg = nullptr;          // staging of update rows on their way to distributed parents; own-row exchange buffer of the sweeps
+    int64_t xstage_slot = 0;                            // scalars per rank of d_xstage
+    std::vector<int64_t> h_upd_off;                     // per node: its update matrix in the update arena (host copy of the plan)
+    int64_t chunk_node_upd_off(int32_t t) const { return h_upd_off[(size_t)t]; }
     int32_t* d_gell = nullptr;
     int32_t *d_idx = nullptr, *d_cmap = nullptr, *d_tiles = nullptr, *d_chunk_nodes = nullptr;
     int64_t* d_asm_dst = nullptr;
@@ -1395,6 +1495,8 @@ namespace {
 
 void nd_free(lsa_ndlu* f) {
     if (!f) return;
+    for (void* p : {(void*)f->d_lnodes_bwd, (void*)f->d_dist_nodes, (void*)f->d_child_ptr, (void*)f->d_child_idx, f->d_xstage, f->d_xg})
+        if (p) (void)hipFree(p);
     for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
                     (void*)f->d_chunk_nodes, (void*)f->d_asm_dst, (void*)f->d_asm_src, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_xflag, (void*)f->d_maxabs,
                     f->d_lfac, f->d_ufac, f->d_work, f->d_upd, f->d_ubuf, f->d_xb, f->d_acc, f->d_tmp, f->d_ybuf, (void*)f->d_cand[0], (void*)f->d_cand[1], f->d_dinv})
@@ -1414,7 +1516,9 @@ int upload(lsa_ctx* ctx, const std::vector<U>& h, U** d) {
 }
 
 // device tables, the memory plan (packed factors, chunks of working fronts, update arena) and tile lists from the analysis
-int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
+// free_agreed: > 0 = the device memory every rank of a forest cut over ranks has free (the smallest of them): with distributed
+// top nodes the chunks of the top levels carry collectives and must come out alike on every rank
+int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
     NdSymbolic& S = f->S;
     const int32_t nt = S.nt;
     const size_t es = esize(f->dtype);
@@ -1456,6 +1560,8 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
         const int64_t after = (int64_t)free_b - S.factor_entries * (int64_t)es;
         budget = std::max<int64_t>(after / 4, (int64_t)256 << 20) / (int64_t)es;
+        // (distributed top nodes: a figure every rank computes alike -- a sixth of the smallest free memory of all ranks)
+        if (S.has_dist) budget = std::max<int64_t>((free_agreed > 0 ? free_agreed : (int64_t)free_b) / 6, (int64_t)256 << 20) / (int64_t)es;
         if (const char* e = getenv("LSA_ND_WORK_MB")) budget = std::max<int64_t>(atoll(e), 1) * (1 << 20) / (int64_t)es;
     }
     NdMemoryPlan P;
@@ -1478,7 +1584,17 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         nd.f = S.f[(size_t)t];
         nd.parent = S.parent[(size_t)t];
         nd.nchild = S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t];
+        nd.brow0 = S.brow0[(size_t)t];
+        nd.brow = S.brow[(size_t)t];
+        nd.orow0 = S.orow0[(size_t)t];
+        nd.orows = S.orows[(size_t)t];
+        nd.flags = S.kind[(size_t)t] == 4 ? 1 : 0;
+        nd.pad0 = 0;
+        nd.xg_base = S.xg_base[(size_t)t];
+        nd.xg_stride = S.xg_stride[(size_t)t];
     }
+    f->xstage_slot = P.xstage_slot;
+    f->h_upd_off = P.upd_off;
     f->lfac_entries = P.lfac_entries;
     f->ufac_entries = P.ufac_entries;
     f->acc_entries = P.acc_entries;
@@ -1553,6 +1669,9 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
                 const int32_t t = node(q);
                 if (S.child_ptr[(size_t)t] + r >= S.child_ptr[(size_t)t + 1]) continue;
                 const int32_t ch = S.child_idx[(size_t)S.child_ptr[(size_t)t] + r];
+                // (the update matrices of a distributed node's children travel through the staging buffer, below -- except a
+                //  replicated child's, which every rank holds whole)
+                if (S.kind[(size_t)t] == 4 && S.kind[(size_t)ch] != 2) continue;
                 const int32_t bc = S.f[(size_t)ch] - S.m[(size_t)ch];
                 for (int32_t i0 = 0; i0 < bc; i0 += 16) push(c.ext[(size_t)r], ch, i0);
             }
@@ -1567,7 +1686,9 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
                 const int32_t t = node(q);
                 const int32_t m = S.m[(size_t)t], b = S.f[(size_t)t] - m;
                 if (b == 0) continue;
-                const int32_t M = kind == 2 ? m : b, N = kind == 0 ? m : b;
+                // (a distributed node: this rank's boundary rows of L and of the update matrix, its own rows of U)
+                const int32_t M = kind == 2 ? S.orows[(size_t)t] : S.brow[(size_t)t], N = kind == 0 ? m : b;
+                if (M == 0) continue;
                 const int32_t TM = (M + kGT - 1) / kGT, TN = (N + kGT - 1) / kGT;
                 if ((int64_t)TM * TN < 512 || !xcd_order) {
                     for (int32_t tm = 0; tm < TM; ++tm)
@@ -1600,7 +1721,39 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         begin_list(c.save);
         for (int32_t q = 0; q < c.node_count; ++q) {
             const int32_t t = node(q);
-            for (int32_t r0 = 0; r0 < S.f[(size_t)t] - S.m[(size_t)t]; r0 += 16) push(c.save, t, r0);
+            for (int32_t r0 = 0; r0 < S.brow[(size_t)t]; r0 += 16) push(c.save, t, r0);
+        }
+        // the row chunks that reach this chunk's distributed nodes through the staging buffer: every rank works off its own
+        // queue (its slice of the rows of a distributed child, all rows of a subtree root it owns), one piece per step
+        {
+            std::vector<std::vector<NdChunk::XPiece>> queue((size_t)S.nranks);
+            for (int32_t q = 0; q < c.node_count; ++q) {
+                const int32_t t = node(q);
+                if (S.kind[(size_t)t] != 4) continue;
+                for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) {
+                    const int32_t ch = S.child_idx[(size_t)cp];
+                    if (S.kind[(size_t)ch] == 2) continue;
+                    const int32_t bc = S.f[(size_t)ch] - S.m[(size_t)ch];
+                    if (bc == 0) continue;
+                    const int32_t per = (int32_t)std::max<int64_t>(1, std::min<int64_t>(P.xstage_slot / bc, 1 << 30));
+                    for (int r = 0; r < S.nranks; ++r) {
+                        int32_t lo = 0, cnt = 0;
+                        if (S.kind[(size_t)ch] == 4) nd_slice(bc, S.nranks, r, &lo, &cnt);
+                        else if (S.owner[(size_t)ch] == r) cnt = bc;
+                        for (int32_t r0 = lo; r0 < lo + cnt; r0 += per) {
+                            NdChunk::XPiece pc;
+                            pc.child = ch, pc.row0 = r0, pc.nrows = std::min(per, lo + cnt - r0);
+                            queue[(size_t)r].push_back(pc);
+                        }
+                    }
+                }
+            }
+            size_t nsteps = 0;
+            for (const auto& qv : queue) nsteps = std::max(nsteps, qv.size());
+            c.xsteps.assign(nsteps, std::vector<NdChunk::XPiece>((size_t)S.nranks));
+            for (size_t st = 0; st < nsteps; ++st)
+                for (int r = 0; r < S.nranks; ++r)
+                    if (st < queue[(size_t)r].size()) c.xsteps[st][(size_t)r] = queue[(size_t)r][st];
         }
         if (c.max_m > 16384 && c.max_m < f->tp_min)  // (the tournament path has no such limit)
             return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a pivot block of %d rows exceeds the 16 384 the panel kernels hold in registers (LSA_ND_TP_MIN = %d)",
@@ -1618,7 +1771,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         int64_t tiles32 = 0;
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            tiles32 += (S.f[(size_t)t] + kRT - 1) / kRT;
+            tiles32 += (S.m[(size_t)t] + S.brow[(size_t)t] + kRT - 1) / kRT;
             L.max_m = std::max(L.max_m, S.m[(size_t)t]);
             L.max_f = std::max(L.max_f, S.f[(size_t)t]);
         }
@@ -1631,17 +1784,61 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f) {
         L.sweep_rows = tiles32 <= few ? 8 : (L.max_m <= thin && l > 0) ? 128 : kRT;
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            L.fwd_tiles = std::max(L.fwd_tiles, (S.f[(size_t)t] + L.sweep_rows - 1) / L.sweep_rows);
+            L.fwd_tiles = std::max(L.fwd_tiles, (S.m[(size_t)t] + S.brow[(size_t)t] + L.sweep_rows - 1) / L.sweep_rows);
             const int32_t bwd_rows = L.sweep_rows == 8 ? 8 : kRT;  // (the downward sweep of a thin level has few, long rows: 32-row tiles; 32 as well where the upward sweep takes 64)
-            if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.m[(size_t)t] + bwd_rows - 1) / bwd_rows);
+            if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.orows[(size_t)t] + bwd_rows - 1) / bwd_rows);
         }
         if (L.fwd_tiles > 65535) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu: a front of more than %d rows is not supported", 65535 * 8);
     }
     LSA_CHECK(upload(ctx, nodes, &f->d_nodes));
     {
-        std::vector<NdNodeDev> lnodes(S.lvl_nodes.size());
-        for (size_t q = 0; q < S.lvl_nodes.size(); ++q) lnodes[q] = nodes[(size_t)S.lvl_nodes[q]];
+        // the sweeps' records, in level order.  A distributed node differs from its factorisation record: upwards its update
+        // entries go to its rank's slot of the level's exchange region; downwards it appears as its slice of the own rows (the
+        // pushes to its children are nd_dist_unpack_kernel's, after the exchange)
+        std::vector<NdNodeDev> lnodes(S.lvl_nodes.size()), bnodes(S.lvl_nodes.size());
+        std::vector<int32_t> dist_nodes;
+        for (size_t q = 0; q < S.lvl_nodes.size(); ++q) {
+            const int32_t t = S.lvl_nodes[q];
+            lnodes[q] = bnodes[q] = nodes[(size_t)t];
+            if (S.kind[(size_t)t] != 4) continue;
+            lnodes[q].u_off = S.ux_base[(size_t)t] + (int64_t)S.rank * S.ux_stride[(size_t)t];
+            NdNodeDev& bn = bnodes[q];
+            const int32_t b = bn.f - bn.m;
+            bn.idx_off += bn.orow0;
+            bn.own0 += bn.orow0;
+            bn.m = bn.orows;
+            bn.f = bn.orows + b;
+            bn.nchild = 0;
+        }
+        for (int32_t l = 0; l < S.nlevels; ++l) {
+            NdLevel& L = f->levels[(size_t)l];
+            L.dist_begin = (int32_t)dist_nodes.size();
+            for (int32_t q = 0; q < L.node_count; ++q) {
+                const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+                if (S.kind[(size_t)t] != 4) continue;
+                if (L.dist_count == 0) {
+                    L.ux_base = S.ux_base[(size_t)t], L.ux_slot = S.ux_stride[(size_t)t];
+                    L.xg_base = S.xg_base[(size_t)t], L.xg_slot = S.xg_stride[(size_t)t];
+                }
+                L.ux_base = std::min(L.ux_base, S.ux_base[(size_t)t]);
+                L.xg_base = std::min(L.xg_base, S.xg_base[(size_t)t]);
+                ++L.dist_count;
+                dist_nodes.push_back(t);
+                L.dist_children = std::max(L.dist_children, S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t]);
+                L.dist_rows = std::max(L.dist_rows, S.m[(size_t)t]);
+                for (int32_t cp = S.child_ptr[(size_t)t]; cp < S.child_ptr[(size_t)t + 1]; ++cp) {
+                    const int32_t ch = S.child_idx[(size_t)cp];
+                    L.dist_rows = std::max(L.dist_rows, S.f[(size_t)ch] - S.m[(size_t)ch]);
+                }
+            }
+        }
         LSA_CHECK(upload(ctx, lnodes, &f->d_lnodes));
+        LSA_CHECK(upload(ctx, bnodes, &f->d_lnodes_bwd));
+        LSA_CHECK(upload(ctx, dist_nodes, &f->d_dist_nodes));
+        LSA_CHECK(upload(ctx, S.child_ptr, &f->d_child_ptr));
+        LSA_CHECK(upload(ctx, S.child_idx, &f->d_child_idx));
+        if (f->xstage_slot > 0) LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_xstage, (size_t)f->xstage_slot * (size_t)S.nranks * es));
+        if (S.xg_entries > 0) LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_xg, (size_t)S.xg_entries * 16));
     }
     LSA_CHECK(upload(ctx, S.gell, &f->d_gell));
     LSA_CHECK(upload(ctx, S.idx, &f->d_idx));
@@ -1863,6 +2060,27 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
         for (const TileList& e : L.ext)
             if (e.count > 0)
                 hipLaunchKernelGGL((nd_extend_add_kernel<T>), dim3(e.count), dim3(256), 0, st, tl + 2 * e.off, f->d_nodes, f->d_cmap, front, (const T*)upd);
+        // distributed top nodes: their children's update matrices, in row chunks.  Per step: every rank copies its piece (rows of
+        // a distributed child it holds, or of a subtree root it owns) into its slot of the staging buffer, one in-place
+        // all-gather, then every rank adds the rows it keeps -- the pivot block and F12 rows on every rank, boundary rows on
+        // their owner -- slot by slot (fixed order of the sums: the replicated pivot blocks stay bitwise alike).
+        for (const auto& step : L.xsteps) {
+            T* stage = (T*)f->d_xstage;
+            const NdChunk::XPiece& mine = step[(size_t)S.rank];
+            if (mine.nrows > 0) {
+                const int32_t bc = S.f[(size_t)mine.child] - S.m[(size_t)mine.child];
+                const int64_t src_off = f->chunk_node_upd_off(mine.child) + (int64_t)(mine.row0 - S.brow0[(size_t)mine.child]) * bc;
+                LSA_HIP_CHECK(ctx, hipMemcpyAsync(stage + (size_t)S.rank * (size_t)f->xstage_slot, upd + src_off, (size_t)mine.nrows * (size_t)bc * sizeof(T),
+                                                  hipMemcpyDeviceToDevice, st));
+            }
+            LSA_CHECK(k_allgather_inplace(ctx, stage, (size_t)f->xstage_slot * sizeof(T)));
+            for (int r = 0; r < S.nranks; ++r) {
+                const NdChunk::XPiece& pc = step[(size_t)r];
+                if (pc.nrows <= 0) continue;
+                hipLaunchKernelGGL((nd_extend_add_staged_kernel<T>), dim3((pc.nrows + 15) / 16), dim3(256), 0, st, f->d_nodes, f->d_cmap, front,
+                                   (const T*)(stage + (size_t)r * (size_t)f->xstage_slot), pc.child, pc.row0, pc.nrows);
+            }
+        }
         if (L.max_m >= f->tp_min) LSA_CHECK(launch_level_tp<T>(ctx, f, L, tiny2));
         for (int32_t kb = 0; kb < L.max_m && L.max_m < f->tp_min; kb += kNB) {
             if (L.max_m <= 64) launch_block<T, 64, 1, 8>(ctx, f, L, kb, tiny2);
@@ -1969,14 +2187,28 @@ int nd_apply_ordered(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
             else
                 hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 16, ORDERED>), grid, dim3(256), 0, st, ln, lfac, f->d_idx, f->d_gell, f->d_cmap, b, x, ubuf, acc, xb);
         }
+        // distributed top nodes of the level: every rank produced its slice of their update entries
+        if (L.dist_count > 0 && L.ux_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, ubuf + L.ux_base, (size_t)L.ux_slot * sizeof(VT)));
     }
     for (size_t l = f->levels.size(); l-- > 0;) {
         const NdLevel& L = f->levels[l];
         if (L.bwd_tiles > 0) {
             const dim3 grid(L.node_count, L.bwd_tiles);
-            const NdNodeDev* ln = f->d_lnodes + L.node_begin;
+            const NdNodeDev* ln = f->d_lnodes_bwd + L.node_begin;
             if (L.sweep_rows == 8) hipLaunchKernelGGL((nd_bwd_kernel<MT, VT, 64, ORDERED>), grid, dim3(256), 0, st, ln, ufac, f->d_idx, f->d_gell, x, xb);
             else hipLaunchKernelGGL((nd_bwd_kernel<MT, VT, 16, ORDERED>), grid, dim3(256), 0, st, ln, ufac, f->d_idx, f->d_gell, x, xb);
+        }
+        if (L.dist_count > 0) {
+            // ... their own rows: slices -> exchange buffer -> all ranks; then x and the children's boundary vectors
+            const int32_t* dn = f->d_dist_nodes + L.dist_begin;
+            VT* xg = (VT*)f->d_xg;
+            if (L.xg_slot > 0 && L.bwd_tiles > 0) {
+                hipLaunchKernelGGL((nd_dist_pack_kernel<VT, ORDERED>), dim3(L.dist_count, (L.dist_rows + 255) / 256), dim3(256), 0, st, dn, f->d_nodes, f->d_idx, S.rank,
+                                   (const VT*)x, xg);
+                LSA_CHECK(k_allgather_inplace(ctx, xg + L.xg_base, (size_t)L.xg_slot * sizeof(VT)));
+            }
+            hipLaunchKernelGGL((nd_dist_unpack_kernel<VT, ORDERED>), dim3(L.dist_count, 1 + L.dist_children, (L.dist_rows + 255) / 256), dim3(256), 0, st, dn, f->d_nodes,
+                               f->d_child_ptr, f->d_child_idx, f->d_cmap, f->d_idx, S.nranks, x, (const VT*)xg, xb);
         }
     }
     LSA_HIP_CHECK(ctx, hipGetLastError());
@@ -2019,6 +2251,9 @@ int nd_apply_T(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
 // x = C^-T b (conj == 0) or C^-H b (conj != 0) on the factors of C
 int ndlu_solve_adjoint_dev(lsa_ctx* ctx, lsa_ndlu* f, int conj, int vdtype, const void* b, void* x) {
     if (f->dtype == LSA_C128 && vdtype != LSA_C128) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve_adjoint: complex factors need complex vectors");
+    if (f->S.has_dist)
+        return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve_adjoint: the transposed sweeps are not available for a forest with distributed top nodes "
+                                               "(cut it with replicated top nodes: LSA_ND_DIST_MIN=0)");
     if (f->S.n == 0) return LSA_OK;
     if (b == x) {
         LSA_HIP_CHECK(ctx, hipMemcpyAsync(f->d_tmp, b, (size_t)f->S.n * esize(vdtype), hipMemcpyDeviceToDevice, ctx->stream));
@@ -2239,6 +2474,18 @@ int lsa_ndlu_create_tree(lsa_ctx* ctx, const lsa_mat* C, int32_t ntree, const in
     const double t0 = now_s();
     lsa_ndlu* f = nullptr;
     int setup_rc = LSA_OK;
+    // the free device memory the plan may count on, agreed over the ranks (collective: entered by every rank, first thing)
+    int64_t free_agreed = 0;
+    if (ctx->nranks > 1) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = (size_t)16 << 30;
+        if (ctx->nd_cache) {  // (what a parked factorisation holds comes back when it is dropped or reused)
+            const lsa_ndlu* c = ctx->nd_cache;
+            free_b += (size_t)(c->lfac_entries + c->ufac_entries + c->work_entries + c->upd_entries) * esize(c->dtype);
+        }
+        free_agreed = (int64_t)free_b;
+        LSA_CHECK(k_agree_min_i64(ctx, &free_agreed));
+    }
     // the parked factorisation, if it was made for this pattern, this tree and this rank
     if (ctx->nd_cache) {
         lsa_ndlu* c = ctx->nd_cache;
@@ -2276,7 +2523,7 @@ int lsa_ndlu_create_tree(lsa_ctx* ctx, const lsa_mat* C, int32_t ntree, const in
             rc = LSA_ERR_ARG;
             snprintf(buf, sizeof buf, "lsa_ndlu_create_tree: out of host memory in the analysis");
         }
-        if (rc == LSA_OK) rc = nd_setup(ctx, f);
+        if (rc == LSA_OK) rc = nd_setup(ctx, f, free_agreed);
         else lsa_set_error(ctx, rc, "%s", buf);
         setup_rc = rc;
         f->seconds_analyse = now_s() - t0;

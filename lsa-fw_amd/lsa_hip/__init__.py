@@ -142,6 +142,7 @@ SIGNATURES = {
     "lsa_nd_order": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _PP]),
     "lsa_nd_analyse_tree": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _PP]),
     "lsa_nd_sym_export_dist": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "lsa_nd_sym_export_top": (ctypes.c_int, [_P, _P, _P, _P, _P]),
     "lsa_nd_sym_error": (ctypes.c_char_p, [_P]),
     "lsa_nd_sym_destroy": (None, [_P]),
     "lsa_nd_sym_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64),
@@ -639,6 +640,13 @@ class NdAnalysis:
                                          _ptr(out["child_ptr"]), None, None)
         out["child_idx"] = np.empty(int(out["child_ptr"][-1]), np.int32)
         self._lib.lsa_nd_sym_export_dist(self.handle, None, None, None, None, None, _ptr(out["child_idx"]), None)
+        out["owner"] = np.zeros(self.ntree, np.int32)
+        rows, exch, totals = np.zeros(4 * self.ntree, np.int32), np.zeros(4 * self.ntree, np.int64), np.zeros(2, np.int64)
+        self._lib.lsa_nd_sym_export_top(self.handle, _ptr(out["owner"]), _ptr(rows), _ptr(exch), _ptr(totals))
+        rows, exch = rows.reshape(-1, 4), exch.reshape(-1, 4)
+        out.update({"brow0": rows[:, 0].copy(), "brow": rows[:, 1].copy(), "orow0": rows[:, 2].copy(), "orows": rows[:, 3].copy(),
+                    "ux_base": exch[:, 0].copy(), "ux_stride": exch[:, 1].copy(), "xg_base": exch[:, 2].copy(), "xg_stride": exch[:, 3].copy(),
+                    "u_entries": int(totals[0]), "xg_entries": int(totals[1])})
         out.update(ex)
         out.update({"front_slot": int(scal[0]), "u_slot": int(scal[1]), "phase_b_level": int(scal[2]), "nranks": int(scal[4]), "rank": int(scal[5])})
         return out

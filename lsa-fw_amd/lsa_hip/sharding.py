@@ -115,9 +115,24 @@ class ForestPartition:
     top_work: int  # factor scalars of the replicated top
 
 
+def dist_front_min() -> int:
+    """Front size from which a top node of the cut forest is DISTRIBUTED over the ranks instead of replicated
+    (``LSA_ND_DIST_MIN``; 0 = never).  Replicating the top is the cheaper form while its fronts are small (2D: a few thousand
+    rows, every exchange of the sweeps costs more than the redundant work); in 3D the top fronts ARE the factorisation (tens of
+    thousands of rows each) and replicating them is what kept a 5 M-unknown problem from fitting eight GPUs."""
+    import os
+
+    raw = os.environ.get("LSA_ND_DIST_MIN", "").strip()
+    return int(raw) if raw else 6144
+
+
 def partition_forest(perm: np.ndarray, node_start: np.ndarray, parent: np.ndarray, front_size: np.ndarray, nranks: int, align: int = 64,
-                     imbalance: float = 1.25) -> ForestPartition:
+                     imbalance: float = 1.25, dist_min: int | None = None) -> ForestPartition:
     """Cut the forest (arrays of ``NdAnalysis.export()``: nodes in post-order) over ``nranks`` ranks.
+
+    Top nodes whose front has at least ``dist_min`` rows (default: :func:`dist_front_min`), and every top node above one of
+    them, get owner -2: distributed over the ranks (rows of the boundary part of their fronts, see ``include/lsa_hip.h``);
+    the other top nodes owner -1: replicated.
 
     The frontier starts at the roots; its heaviest subtree is split (its root joins the replicated top, its children the
     frontier) until there are at least ``nranks`` subtrees and the heaviest one is within ``imbalance`` of the mean load,
@@ -158,6 +173,11 @@ def partition_forest(perm: np.ndarray, node_start: np.ndarray, parent: np.ndarra
     owner = np.full(nt, -1, dtype=np.int32)
     for t, r in rank_of_root.items():
         owner[t - nodes_in[t] + 1 : t + 1] = r  # a subtree is a contiguous run of post-order ids ending at its root
+    thr = dist_front_min() if dist_min is None else int(dist_min)
+    if thr > 0 and nranks > 1:
+        for t in range(nt):  # post-order: a node's children are decided before it
+            if owner[t] == -1 and (front_size[t] >= thr or any(owner[c] == -2 for c in children[t])):
+                owner[t] = -2
     # new node order: rank by rank, then the top
     new_nodes = np.concatenate([np.flatnonzero(owner == r) for r in range(nranks)] + [np.flatnonzero(owner < 0)])
     new_id = np.empty(nt, dtype=np.int64)

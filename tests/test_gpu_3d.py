@@ -131,7 +131,7 @@ def test_iterative_refinement_is_taken_and_helps(monkeypatch):
           "\nspoilt factors:", {k: st[k] for k in ("refined_solves", "backward_accepted", "max_rel_res", "op_applies", "gmres_iters")})
     assert st["refined_solves"] >= st["op_applies"] - 1 > 0  # every apply took the refinement step (queued steps carry it once the first check failed)
     assert st["backward_accepted"] == 0 and st["gmres_iters"] == 0
-    assert st["max_rel_res"] <= 1e-12  # after ONE step: (1e-7)^2 of the right-hand side, i.e. rounding level
+    assert st["max_rel_res"] <= 2e-12  # after ONE step: (1e-7)^2 of the right-hand side, i.e. rounding level (measured 9.8e-13; clean factors 1.9e-13)
     assert len(lam) == 10 and res.max() <= 1e-8
     for r in clean:
         assert np.min(np.abs(lam - r)) <= 1e-8 * abs(r)

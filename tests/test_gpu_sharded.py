@@ -57,13 +57,16 @@ def test_two_rank_shards_reproduce_global_spmv(hip_ctx):
     assert np.all(yp[part.pad_vector(np.ones(es.n)) == 0] == 0)  # padding untouched
 
 
-def _rank_main(rank: int, world: int, port: int, out_dir: str, case: str, pc: str) -> None:
+def _rank_main(rank: int, world: int, port: int, out_dir: str, case: str, pc: str, env: str = "") -> None:
     """One rank of a sharded solve; all ranks share GPU 0 and exchange through the host-staged transport (gloo)."""
     import os
     import sys
     from pathlib import Path
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for item in filter(None, env.split(",")):  # e.g. "LSA_ND_DIST_MIN=1,LSA_ND_XSTAGE_KB=64"
+        key, _, val = item.partition("=")
+        os.environ[key] = val
     if case.startswith("C"):
         os.environ["LSA_DIST_SPMV"] = "shard"  # the products on this rank's rows + exchange (the default of large 3D patterns)
     root = Path(__file__).resolve().parents[1]
@@ -162,6 +165,52 @@ def test_sharded_3d_case_with_four_ranks_matches_the_single_gpu_solve(tmp_path):
     assert helpers_match(out[0]["lam"], ref).max() <= 1e-8
     assert out[0]["res"].max() <= 1e-8 and int(out[0]["gmres"]) == 0 and int(out[0]["ranks"]) == 4
     assert shift_invert.compute_residuals(es.A, es.M, out[0]["lam"], out[0]["V"]).max() <= 1e-8
+
+
+@pytest.mark.parametrize("world,case,env", [(2, "S2k", "LSA_ND_DIST_MIN=1"), (4, "S2k", "LSA_ND_DIST_MIN=1,LSA_ND_XSTAGE_KB=8"),
+                                            (3, "C9k", "LSA_ND_DIST_MIN=1,LSA_ND_XSTAGE_KB=64"), (4, "C40k", "LSA_ND_DIST_MIN=1"),
+                                            (4, "C40k", "LSA_ND_DIST_MIN=2500,LSA_ND_WORK_MB=64")])
+def test_distributed_top_fronts_with_several_ranks_on_one_gpu(tmp_path, world, case, env):
+    """The top of the forest DISTRIBUTED over the ranks (what BASELINE config 4's 5 M unknowns on eight GPUs need: replicated, the
+    top fronts alone exceed a GPU): every rank keeps the whole pivot block of a top node and its slice of the boundary rows; the
+    children's update matrices travel in row chunks through the staging buffer (forced small here: many steps), the sweeps
+    exchange slices level by level.  Forced onto every top node (LSA_ND_DIST_MIN=1) or onto the large ones with replicated small
+    ones below (the mixed form), several chunks per level (LSA_ND_WORK_MB).  Same eigenvalues as the oracle / the single-GPU
+    solve, ranks bit-identical, no inner iteration."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from oracle import shift_invert
+    from synthetic import fem
+    from Solver.eigen import EigenSolver, EigensolverConfig
+    from Solver.utils import PreconditionerType, iSTType
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_main, args=(world, port, str(tmp_path), case, "lu", env), nprocs=world, join=True)
+    out = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    for o in out[1:]:
+        assert np.array_equal(o["lam"], out[0]["lam"]) and np.array_equal(o["V"], out[0]["V"])
+    cube = case.startswith("C")
+    es = fem.cube_case(case) if cube else fem.cylinder_case(case)
+    sigma = fem.SIGMA_CUBE if cube else fem.SIGMA_RE50
+    if es.n <= 12000:
+        ref, _, _ = shift_invert.solve(es.A, es.M, sigma, k=5, tol=1e-13)
+    else:
+        one = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=5, atol=1e-10, ncv=40), check_hermitian=False)
+        one.solver.set_st_type(iSTType.SINVERT)
+        one.solver.set_target(sigma)
+        one.solver.set_st_pc_type(PreconditionerType.LU)
+        ref = np.array([p[0] for p in one.solve()[:5]])
+        one.solver.release()
+    assert helpers_match(out[0]["lam"], ref).max() <= 1e-8
+    assert out[0]["res"].max() <= 1e-8 and int(out[0]["gmres"]) == 0 and int(out[0]["ranks"]) == world
+    assert shift_invert.compute_residuals(es.A, es.M, out[0]["lam"], out[0]["V"]).max() <= 1e-8
+    # more exchanges per apply than the replicated top's (two per distributed level on top of the 2 / 4 of the layout)
+    per_apply = 4 if cube else 2
+    assert int(out[0]["gathers"]) > (per_apply + 1) * int(out[0]["applies"])
 
 
 def helpers_match(found, ref):

@@ -201,3 +201,67 @@ def test_four_way_dissection_halves_the_levels_and_is_still_a_direct_solve(monke
         got[name] = (an.nlevels, an.ntree, an.factor_entries, int(np.diff(ex["node_start"]).max()))
     (l2, n2, e2, m2), (l4, n4, e4, m4) = got["binary"], got["four_way"]
     assert l4 < l2 and n4 < n2 and e2 < e4 <= 1.6 * e2 and m4 <= 512 + 0 * m2
+
+
+def _top_fronts(ex, nranks):
+    """Front sizes of the nodes partition_forest puts into the top for this rank count (the frontier split, replayed)."""
+    seen = []
+    for thr in sorted(set(int(v) for v in ex["front_size"]), reverse=True):
+        fp = sharding.partition_forest(ex["perm"], ex["node_start"], ex["parent"], ex["front_size"], nranks, dist_min=thr)
+        if np.any(fp.owner == -2):
+            seen.append(thr)
+            break
+    return np.array(seen)
+
+
+@pytest.mark.parametrize("case,nranks,dist_min", [("S5k", 2, 1), ("S5k", 4, 1), ("S5k", 8, "mixed"), ("C2k", 4, 1), ("C2k", 3, 1), ("C2k", 8, "mixed")])
+def test_distributed_top_nodes_are_still_a_direct_solve(case, nranks, dist_min):
+    """The forest cut over ranks with DISTRIBUTED top nodes (owner -2: every rank keeps the whole pivot block and its slice of
+    the boundary rows of those fronts), tables walked rank by rank with the data flow of the device path: row-wise travel of
+    the children's update matrices, slices of L, of the update matrix and of U, per-level exchanges of both sweeps."""
+    from nd_emulation import EmulatedDistributedTop
+
+    es = fem.cube_case(case) if case.startswith("C") else fem.cylinder_case(case)
+    C = _shifted(es, fem.SIGMA_CUBE if case.startswith("C") else fem.SIGMA_RE50)
+    flags = (C.diagonal() == 0) if case.startswith("C") else None
+    ex = lsa_hip.NdAnalysis(C, 64, constraint=flags).export()
+    if dist_min == "mixed":  # only the top node with the largest front (and what lies above it) is distributed
+        dist_min = int(_top_fronts(ex, nranks)[0])  # the largest front size that makes any top node distributed
+    fp = sharding.partition_forest(ex["perm"], ex["node_start"], ex["parent"], ex["front_size"], nranks, dist_min=dist_min)
+    top = fp.owner < 0
+    assert np.any(fp.owner == -2) and (dist_min > 1 or not np.any(fp.owner == -1))
+    par = fp.parent
+    assert all(fp.owner[par[t]] == -2 for t in np.flatnonzero(fp.owner == -2) if par[t] >= 0)  # closed upwards
+    if dist_min > 1:
+        assert np.any(fp.owner == -1)  # the mixed form: small top nodes stay replicated below distributed ones
+    Cp = C[fp.order][:, fp.order].tocsr()
+    Cp.sort_indices()
+    Cpad = sharding.pad_square(Cp, fp.rows)
+    tree = {"first": fp.first, "size": fp.size, "parent": fp.parent, "owner": fp.owner}
+    ans = [lsa_hip.NdAnalysis(Cpad, tree=tree, rank=r, nranks=nranks) for r in range(nranks)]
+    tabs = [a.export_tables() for a in ans]
+    for r, t in enumerate(tabs):
+        m = np.diff(t["node_start"]).astype(np.int64)
+        b = t["front_size"].astype(np.int64) - m
+        k4 = t["kind"] == 4
+        assert np.count_nonzero(k4) == np.count_nonzero(fp.owner == -2) and np.count_nonzero(t["kind"] == 2) == np.count_nonzero(fp.owner == -1)
+        w = -(-b // nranks)
+        assert np.array_equal(t["brow0"][k4], np.minimum(b[k4], r * w[k4])) and np.array_equal(t["brow"][k4], np.minimum(b[k4], (r + 1) * w[k4]) - t["brow0"][k4])
+        assert np.array_equal(t["brow"][~k4], b[~k4]) and np.array_equal(t["orows"][~k4], m[~k4])
+        # a rank's factor entries: whole inverse, its rows of L, its rows of U
+        here = t["kind"] != 3
+        want = int((m * m + t["brow"].astype(np.int64) * m + t["orows"].astype(np.int64) * b)[here].sum())
+        assert ans[r].factor_entries == want
+        mem = ans[r].memory(8, 0)
+        assert mem["factors"] == want * 8
+    # the slices of all ranks tile the boundaries, the exchange regions agree
+    # (a rank's buffers are its own -- the bases may differ -- but every rank must move the same count per exchange)
+    assert all(np.array_equal(t["ux_stride"][t["kind"] == 4], tabs[0]["ux_stride"][tabs[0]["kind"] == 4]) for t in tabs)
+    assert all(np.array_equal(t["xg_stride"][t["kind"] == 4], tabs[0]["xg_stride"][tabs[0]["kind"] == 4]) for t in tabs)
+    em = EmulatedDistributedTop(tabs, Cpad.data)
+    rng = np.random.default_rng(7)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    xp = em.solve(fp.rows.pad_vector(b))
+    x = fp.rows.unpad_vector(xp)
+    assert np.linalg.norm(Cp @ x - b) <= 1e-11 * np.linalg.norm(b)
+    assert top.sum() > 0

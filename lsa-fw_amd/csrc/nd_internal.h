@@ -37,11 +37,12 @@ struct NdSymbolic {
     int64_t xu_slot = 0;           // entries per rank in the exchange region at the start of the update-vector buffer
     std::vector<int32_t> kind;     // per kept node: 1 = factored here (own subtree), 2 = replicated top, 3 = another rank's subtree root,
                                    // 4 = DISTRIBUTED top node (below)
-    // Distributed top nodes (owner -2 in the caller's forest; closed upwards: the parent of one is one).  Every rank keeps the
-    // pivot block F11 whole (the Gauss-Jordan inversion runs redundantly, bitwise alike), F12 whole while the node is factored,
-    // and only its own slice of the boundary ROWS of F21 / F22: working front (m + brow) x f, packed L = [inv; -F21[rows] inv]
-    // ((m + brow) x m), update matrix rows brow x b.  U = inv F12 is stored by slices of the OWN rows (orows x b): a rank
-    // finishes its slice of x[own] in the downward sweep.  Slices are equal cuts: rank r owns [r s, min((r + 1) s, b)), s = ceil(b / P).
+    // Distributed top nodes (owner -2 in the caller's forest; closed upwards: the parent of one is one).  While such a node is
+    // factored every rank holds the pivot block F11 whole (the Gauss-Jordan inversion runs redundantly, bitwise alike) and F12
+    // whole, and only its own slice of the boundary ROWS of F21 / F22: working front (m + brow) x f (+ m^2 for the inverse).
+    // What stays: the rank's slice of the OWN rows of the inverse and of U = inv F12 (orows x m, orows x b: the rank produces
+    // and finishes that slice of x[own] in the sweeps), its boundary rows of L = -F21 inv (brow x m) and of the update matrix
+    // (brow x b).  Slices are equal cuts: rank r owns [r s, min((r + 1) s, count)), s = ceil(count / P).
     std::vector<int32_t> owner;           // per kept node: owning rank (kinds 1, 3), -1 (kind 2), -2 (kind 4)
     std::vector<int32_t> brow0, brow;     // per kept node: this rank's boundary rows [brow0, brow0 + brow)   (all of them unless kind 4)
     std::vector<int32_t> orow0, orows;    // per kept node: this rank's own rows of U                          (all of them unless kind 4)

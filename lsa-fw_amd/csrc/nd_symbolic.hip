@@ -530,9 +530,9 @@ int nd_finish(NdSymbolic& S, int32_t n, const int32_t* rp, const int32_t* ci, Gr
                 S.u_off[(size_t)q] = urun;
                 urun += b;
             }
-            if (S.kind[(size_t)q] == 4) {  // this rank's share: the replicated inverse, its boundary rows of L, its own rows of U
+            if (S.kind[(size_t)q] == 4) {  // this rank's share: its own rows of the inverse and of U, its boundary rows of L
                 const int64_t br = S.brow[(size_t)q], orr = S.orows[(size_t)q];
-                S.factor_entries += m * m + br * m + orr * b;
+                S.factor_entries += orr * m + br * m + orr * b;
                 S.flops += (double)m * m * m + (double)m * m * br + (double)m * m * orr * (b > 0) + (double)m * br * b;
             } else if (S.kind[(size_t)q] != 3) {
                 S.factor_entries += m * m + 2 * m * b;
@@ -940,8 +940,11 @@ void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P
     // (a distributed node: the widest slice of any rank, so that the chunks of the top levels -- their cuts decide where the
     //  collectives of the factorisation fall -- come out alike on every rank)
     auto work_size = [&](int32_t t) -> int64_t {
-        const int64_t rows = S.kind[(size_t)t] == 4 ? S.m[(size_t)t] + nd_slice_width(S.f[(size_t)t] - S.m[(size_t)t], S.nranks) : S.f[(size_t)t];
-        return rows * S.f[(size_t)t];
+        if (S.kind[(size_t)t] != 4) return (int64_t)S.f[(size_t)t] * S.f[(size_t)t];
+        // ... its slice of the front, and behind it the whole inverse of the pivot block while the node is factored (the packed
+        // factors keep only this rank's rows of it)
+        const int64_t rows = S.m[(size_t)t] + nd_slice_width(S.f[(size_t)t] - S.m[(size_t)t], S.nranks);
+        return rows * S.f[(size_t)t] + (int64_t)S.m[(size_t)t] * S.m[(size_t)t];
     };
     auto upd_size = [&](int32_t t) -> int64_t {
         if (S.kind[(size_t)t] == 3 && !is_xroot(t)) return 0;  // another rank's subtree root under a distributed parent: arrives in chunks
@@ -960,7 +963,7 @@ void nd_memory_plan(const NdSymbolic& S, int64_t budget_entries, NdMemoryPlan& P
         const int64_t m = S.m[(size_t)t], ff = S.f[(size_t)t];
         P.lfac_off[(size_t)t] = P.lfac_entries;
         P.ufac_off[(size_t)t] = P.ufac_entries;
-        P.lfac_entries += (m + S.brow[(size_t)t]) * m;
+        P.lfac_entries += ((int64_t)S.orows[(size_t)t] + S.brow[(size_t)t]) * m;  // rows of the inverse (all m unless distributed), then of -F21 inv
         P.ufac_entries += (int64_t)S.orows[(size_t)t] * (ff - m);
     }
     // ---- slot rows of the upward sweep: push form unless a child's update vector arrives by all-gather (then the node pulls) ----

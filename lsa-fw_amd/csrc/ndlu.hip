@@ -67,8 +67,10 @@ struct NdNodeDev {
     int32_t flags;      // bit 0: distributed node (its downward pushes are done by nd_dist_unpack_kernel, after the exchange of its own rows)
     int32_t pad0;
     int64_t xg_base, xg_stride;  // distributed node: own row j lies at xg_base + (j / s) * xg_stride + j % s of the own-row exchange buffer, s = ceil(m / ranks)
+    int64_t inv_off;    // distributed node: the whole inverse of its pivot block in the working arena while the node is factored (-1: the
+                        // first m rows of the packed L are the inverse)
 };
-static_assert(sizeof(NdNodeDev) == 136, "node record layout");
+static_assert(sizeof(NdNodeDev) == 144, "node record layout");
 
 struct TileList {
     int64_t off = 0;  // pairs of int32 into the tile buffer
@@ -734,7 +736,7 @@ __global__ __launch_bounds__(256) void nd_tp_colblock_kernel(const int32_t* __re
 // column a, q = its inverse)
 template <typename T>
 __global__ __launch_bounds__(256) void nd_unperm_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
-                                                        const T* __restrict__ front, const int32_t* __restrict__ ipiv,
+                                                        T* front, const int32_t* __restrict__ ipiv,
                                                         const int32_t* __restrict__ rowq, T* __restrict__ lfac) {
     const int32_t t = tiles[2 * blockIdx.x], r0 = tiles[2 * blockIdx.x + 1];
     const NdNodeDev nd = nodes[t];
@@ -742,9 +744,21 @@ __global__ __launch_bounds__(256) void nd_unperm_kernel(const int32_t* __restric
     const int32_t ra = r0 + (threadIdx.x >> 4);
     if (ra >= m) return;
     const T* src = front + nd.front_off + (size_t)ipiv[nd.piv_off + ra] * ld;
-    T* dst = lfac + nd.lfac_off + (size_t)ra * m;
     const int32_t* q = rowq + nd.piv_off;
-    for (int32_t cb = threadIdx.x & 15; cb < m; cb += 16) dst[cb] = src[q[cb]];
+    if (nd.inv_off < 0) {
+        T* dst = lfac + nd.lfac_off + (size_t)ra * m;
+        for (int32_t cb = threadIdx.x & 15; cb < m; cb += 16) dst[cb] = src[q[cb]];
+        return;
+    }
+    // a distributed node: the whole inverse into the working arena (operand of L = -F21 inv), this rank's rows also into the factors
+    T* dst = front + nd.inv_off + (size_t)ra * m;
+    const bool mine = ra >= nd.orow0 && ra < nd.orow0 + nd.orows;
+    T* keep = lfac + nd.lfac_off + (size_t)(mine ? ra - nd.orow0 : 0) * m;
+    for (int32_t cb = threadIdx.x & 15; cb < m; cb += 16) {
+        const T v = src[q[cb]];
+        dst[cb] = v;
+        if (mine) keep[cb] = v;
+    }
 }
 
 // batched dense products of a chunk (row-major, 64 x 64 tiles, 4 x 4 per thread); inv = the first m rows of the packed L:
@@ -760,8 +774,9 @@ __global__ __launch_bounds__(256) void nd_gemm_kernel(const int32_t* __restrict_
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, f = nd.f, b = f - m;
     T* F = front + nd.front_off;
-    T* inv = lfac + nd.lfac_off;
-    T* S1 = inv + (size_t)m * m;
+    T* inv = nd.inv_off < 0 ? lfac + nd.lfac_off : front + nd.inv_off;  // the whole inverse (a distributed node: in the working arena)
+    T* invrows = lfac + nd.lfac_off;                                    // this rank's own rows of it (all of them unless distributed)
+    T* S1 = invrows + (size_t)nd.orows * m;
     T* S2 = ufac + nd.ufac_off;
     const T *A, *B;
     T* C;
@@ -772,7 +787,7 @@ __global__ __launch_bounds__(256) void nd_gemm_kernel(const int32_t* __restrict_
     } else if (KIND == 1) {
         A = S1, lda = m, B = F + m, ldb = f, C = F + (size_t)m * f + m, ldc = f, M = nd.brow, N = b, K = m;
     } else {
-        A = inv + (size_t)nd.orow0 * m, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = nd.orows, N = b, K = m;
+        A = invrows, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = nd.orows, N = b, K = m;
     }
     const int32_t row0 = tm * kGT, col0 = tn * kGT;
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
@@ -918,8 +933,9 @@ __global__ __launch_bounds__(256) void nd_gemm_mfma_kernel(const int32_t* __rest
     const NdNodeDev nd = nodes[t];
     const int32_t m = nd.m, f = nd.f, b = f - m;
     T* F = front + nd.front_off;
-    T* inv = lfac + nd.lfac_off;
-    T* S1 = inv + (size_t)m * m;
+    T* inv = nd.inv_off < 0 ? lfac + nd.lfac_off : front + nd.inv_off;  // the whole inverse (a distributed node: in the working arena)
+    T* invrows = lfac + nd.lfac_off;                                    // this rank's own rows of it (all of them unless distributed)
+    T* S1 = invrows + (size_t)nd.orows * m;
     T* S2 = ufac + nd.ufac_off;
     const T *A, *B;
     T* C;
@@ -930,7 +946,7 @@ __global__ __launch_bounds__(256) void nd_gemm_mfma_kernel(const int32_t* __rest
     } else if (KIND == 1) {
         A = S1, lda = m, B = F + m, ldb = f, C = F + (size_t)m * f + m, ldc = f, M = nd.brow, N = b, K = m;
     } else {
-        A = inv + (size_t)nd.orow0 * m, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = nd.orows, N = b, K = m;
+        A = invrows, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = nd.orows, N = b, K = m;
     }
     const int32_t row0 = tm * kGT, col0 = tn * kGT;
     mfma_d4 acc[NPL][2][2];
@@ -1199,7 +1215,9 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict
     const NdNodeDev nd = lnodes[blockIdx.x];
     const int32_t r0 = (int32_t)blockIdx.y * ROWS;
     const int32_t m = nd.m, f = nd.f;
-    const int32_t floc = m + nd.brow;  // rows of the packed L on this rank (= f unless the node is distributed: then its slice of the boundary rows)
+    // rows of the packed L on this rank: its own rows of the inverse, then its boundary rows (m and f - m of them unless the node
+    // is distributed: then orows rows from orow0 and brow rows from brow0)
+    const int32_t mr = nd.orows, floc = mr + nd.brow;
     if (r0 >= floc) return;
     const int32_t* ix = idx + nd.idx_off;
     const int32_t* ge = gell + nd.ge_off;
@@ -1231,14 +1249,16 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict
         ub[p] = scalar_traits<VT>::zero();
         ca[p] = cb[p] = 0;
         if (sl == 0) {
-            // (front position of local row r >= m: r + brow0)
-            if (ra[p] >= m && ra[p] < floc) {
-                ua[p] = push ? slot_sum(slots, nd.nchild, f, ra[p] + nd.brow0, ua[p]) : gather_updates(ge, nd.nchild, f, ra[p] + nd.brow0, ubuf, ua[p]);
-                if (nd.pacc_off >= 0) ca[p] = cmap[nd.cmap_off + ra[p] - m];
+            // (front position of local row r >= mr: m + brow0 + r - mr)
+            if (ra[p] >= mr && ra[p] < floc) {
+                const int32_t jg = m + nd.brow0 + ra[p] - mr;
+                ua[p] = push ? slot_sum(slots, nd.nchild, f, jg, ua[p]) : gather_updates(ge, nd.nchild, f, jg, ubuf, ua[p]);
+                if (nd.pacc_off >= 0) ca[p] = cmap[nd.cmap_off + ra[p] - mr];
             }
-            if (rb[p] >= m && rb[p] < floc) {
-                ub[p] = push ? slot_sum(slots, nd.nchild, f, rb[p] + nd.brow0, ub[p]) : gather_updates(ge, nd.nchild, f, rb[p] + nd.brow0, ubuf, ub[p]);
-                if (nd.pacc_off >= 0) cb[p] = cmap[nd.cmap_off + rb[p] - m];
+            if (rb[p] >= mr && rb[p] < floc) {
+                const int32_t jg = m + nd.brow0 + rb[p] - mr;
+                ub[p] = push ? slot_sum(slots, nd.nchild, f, jg, ub[p]) : gather_updates(ge, nd.nchild, f, jg, ubuf, ub[p]);
+                if (nd.pacc_off >= 0) cb[p] = cmap[nd.cmap_off + rb[p] - mr];
             }
         }
     }
@@ -1261,21 +1281,21 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict
         const VT s0 = lanes_sum<LPR>(acc0[p]), s1 = lanes_sum<LPR>(acc1[p]);
         if (sl == 0) {
             const bool root_push = f == m && !(nd.flags & 1);
-            if (ra[p] < m) {
-                x[ORDERED ? nd.own0 + ra[p] : ix[ra[p]]] = s0;
+            if (ra[p] < mr) {
+                x[ORDERED ? nd.own0 + nd.orow0 + ra[p] : ix[nd.orow0 + ra[p]]] = s0;
                 if (root_push) push_down(ge, nd.nchild, f, ra[p], xb, s0);
             } else if (ra[p] < floc) {
                 const VT u = s_add(ua[p], s0);
                 if (nd.pacc_off >= 0) acc[nd.pacc_off + ca[p]] = u;
-                else ubuf[nd.u_off + (ra[p] - m)] = u;
+                else ubuf[nd.u_off + (ra[p] - mr)] = u;
             }
-            if (rb[p] < m) {
-                x[ORDERED ? nd.own0 + rb[p] : ix[rb[p]]] = s1;
+            if (rb[p] < mr) {
+                x[ORDERED ? nd.own0 + nd.orow0 + rb[p] : ix[nd.orow0 + rb[p]]] = s1;
                 if (root_push) push_down(ge, nd.nchild, f, rb[p], xb, s1);
             } else if (rb[p] < floc) {
                 const VT u = s_add(ub[p], s1);
                 if (nd.pacc_off >= 0) acc[nd.pacc_off + cb[p]] = u;
-                else ubuf[nd.u_off + (rb[p] - m)] = u;
+                else ubuf[nd.u_off + (rb[p] - mr)] = u;
             }
         }
     }
@@ -1350,7 +1370,7 @@ __global__ __launch_bounds__(256) void nd_dist_pack_kernel(const int32_t* __rest
                                                            const int32_t* __restrict__ idx, int32_t rank, const VT* __restrict__ x, VT* __restrict__ xg) {
     const NdNodeDev nd = nodes[dnodes[blockIdx.x]];
     const int32_t r = (int32_t)blockIdx.y * 256 + threadIdx.x;
-    if (r >= nd.orows || nd.f == nd.m) return;
+    if (r >= nd.orows) return;
     const int32_t j = nd.orow0 + r;
     xg[nd.xg_base + (int64_t)rank * nd.xg_stride + r] = x[ORDERED ? nd.own0 + j : idx[nd.idx_off + j]];
 }
@@ -1365,13 +1385,10 @@ __global__ __launch_bounds__(256) void nd_dist_unpack_kernel(const int32_t* __re
     const int32_t m = nd.m, b = nd.f - m;
     const int32_t ms = (m + nranks - 1) / nranks;
     const int32_t i = (int32_t)blockIdx.z * 256 + threadIdx.x;
-    // own row j of the node: a root's rows are complete on every rank already (the replicated inverse of the upward sweep)
-    auto own_val = [&](int32_t j) -> VT {
-        if (b == 0) return x[ORDERED ? nd.own0 + j : idx[nd.idx_off + j]];
-        return xg[nd.xg_base + (int64_t)(j / ms) * nd.xg_stride + j % ms];
-    };
+    (void)b;
+    auto own_val = [&](int32_t j) -> VT { return xg[nd.xg_base + (int64_t)(j / ms) * nd.xg_stride + j % ms]; };
     if (blockIdx.y == 0) {
-        if (b == 0 || i >= m) return;
+        if (i >= m) return;
         x[ORDERED ? nd.own0 + i : idx[nd.idx_off + i]] = own_val(i);
         return;
     }
@@ -1592,6 +1609,10 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         nd.pad0 = 0;
         nd.xg_base = S.xg_base[(size_t)t];
         nd.xg_stride = S.xg_stride[(size_t)t];
+        // (the plan's working block of a distributed node: its slice of the front at the widest slice of any rank, then the inverse)
+        nd.inv_off = S.kind[(size_t)t] == 4
+                         ? nd.front_off + (int64_t)(S.m[(size_t)t] + nd_slice_width(S.f[(size_t)t] - S.m[(size_t)t], S.nranks)) * S.f[(size_t)t]
+                         : -1;
     }
     f->xstage_slot = P.xstage_slot;
     f->h_upd_off = P.upd_off;
@@ -1771,7 +1792,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         int64_t tiles32 = 0;
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            tiles32 += (S.m[(size_t)t] + S.brow[(size_t)t] + kRT - 1) / kRT;
+            tiles32 += (S.orows[(size_t)t] + S.brow[(size_t)t] + kRT - 1) / kRT;
             L.max_m = std::max(L.max_m, S.m[(size_t)t]);
             L.max_f = std::max(L.max_f, S.f[(size_t)t]);
         }
@@ -1784,7 +1805,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         L.sweep_rows = tiles32 <= few ? 8 : (L.max_m <= thin && l > 0) ? 128 : kRT;
         for (int32_t q = 0; q < L.node_count; ++q) {
             const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-            L.fwd_tiles = std::max(L.fwd_tiles, (S.m[(size_t)t] + S.brow[(size_t)t] + L.sweep_rows - 1) / L.sweep_rows);
+            L.fwd_tiles = std::max(L.fwd_tiles, (S.orows[(size_t)t] + S.brow[(size_t)t] + L.sweep_rows - 1) / L.sweep_rows);
             const int32_t bwd_rows = L.sweep_rows == 8 ? 8 : kRT;  // (the downward sweep of a thin level has few, long rows: 32-row tiles; 32 as well where the upward sweep takes 64)
             if (S.f[(size_t)t] > S.m[(size_t)t]) L.bwd_tiles = std::max(L.bwd_tiles, (S.orows[(size_t)t] + bwd_rows - 1) / bwd_rows);
         }
@@ -2094,7 +2115,7 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
             else launch_block<T, 1024, 16, 1>(ctx, f, L, kb, tiny2);
         }
         if (L.unperm.count > 0)
-            hipLaunchKernelGGL((nd_unperm_kernel<T>), dim3(L.unperm.count), dim3(256), 0, st, tl + 2 * L.unperm.off, f->d_nodes, (const T*)front, f->d_ipiv,
+            hipLaunchKernelGGL((nd_unperm_kernel<T>), dim3(L.unperm.count), dim3(256), 0, st, tl + 2 * L.unperm.off, f->d_nodes, front, f->d_ipiv,
                                f->d_rowq, lfac);
         static const bool vector_gemm = getenv("LSA_ND_GEMM") && !strcmp(getenv("LSA_ND_GEMM"), "vector");  // (A/B measurement aid)
         auto product = [&](auto kind) {
@@ -2202,7 +2223,7 @@ int nd_apply_ordered(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
             // ... their own rows: slices -> exchange buffer -> all ranks; then x and the children's boundary vectors
             const int32_t* dn = f->d_dist_nodes + L.dist_begin;
             VT* xg = (VT*)f->d_xg;
-            if (L.xg_slot > 0 && L.bwd_tiles > 0) {
+            if (L.xg_slot > 0) {
                 hipLaunchKernelGGL((nd_dist_pack_kernel<VT, ORDERED>), dim3(L.dist_count, (L.dist_rows + 255) / 256), dim3(256), 0, st, dn, f->d_nodes, f->d_idx, S.rank,
                                    (const VT*)x, xg);
                 LSA_CHECK(k_allgather_inplace(ctx, xg + L.xg_base, (size_t)L.xg_slot * sizeof(VT)));

@@ -126,6 +126,15 @@ def dist_front_min() -> int:
     return int(raw) if raw else 6144
 
 
+def dist_split_min() -> int:
+    """Front size from which a subtree root is moved into the distributed top whatever the load balance says
+    (``LSA_ND_DIST_SPLIT``; 0 = never): keeps the largest front and update matrix a single rank must hold below ~ 2 x 2.6 GB."""
+    import os
+
+    raw = os.environ.get("LSA_ND_DIST_SPLIT", "").strip()
+    return int(raw) if raw else 18000
+
+
 def partition_forest(perm: np.ndarray, node_start: np.ndarray, parent: np.ndarray, front_size: np.ndarray, nranks: int, align: int = 64,
                      imbalance: float = 1.25, dist_min: int | None = None) -> ForestPartition:
     """Cut the forest (arrays of ``NdAnalysis.export()``: nodes in post-order) over ``nranks`` ranks.
@@ -164,6 +173,19 @@ def partition_forest(perm: np.ndarray, node_start: np.ndarray, parent: np.ndarra
         frontier.remove(t)
         top.append(t)
         frontier.extend(children[t])
+    # A subtree root with a very large front does not belong to ONE rank whatever the balance says: its working front and the
+    # update matrix it hands up (b^2 scalars, alive until its parent is factored) would sit on that rank alone -- at 5 M
+    # unknowns in 3D a 66 k-row root front is 35 GB plus a 51 GB update matrix.  Such roots join the (distributed) top.
+    thr = dist_front_min() if dist_min is None else int(dist_min)
+    big = dist_split_min() if thr > 0 else 0
+    while big > 0 and nranks > 1:
+        huge = [t for t in frontier if children[t] and front_size[t] >= big]
+        if not huge:
+            break
+        for t in huge:
+            frontier.remove(t)
+            top.append(t)
+            frontier.extend(children[t])
     load = np.zeros(nranks, dtype=np.int64)
     rank_of_root = {}
     for t in sorted(frontier, key=lambda t: (-sub[t], t)):
@@ -173,7 +195,6 @@ def partition_forest(perm: np.ndarray, node_start: np.ndarray, parent: np.ndarra
     owner = np.full(nt, -1, dtype=np.int32)
     for t, r in rank_of_root.items():
         owner[t - nodes_in[t] + 1 : t + 1] = r  # a subtree is a contiguous run of post-order ids ending at its root
-    thr = dist_front_min() if dist_min is None else int(dist_min)
     if thr > 0 and nranks > 1:
         for t in range(nt):  # post-order: a node's children are decided before it
             if owner[t] == -1 and (front_size[t] >= thr or any(owner[c] == -2 for c in children[t])):

@@ -381,7 +381,8 @@ class EmulatedDistributedTop:
                     inv, Lr, _ = d["fac"][q]
                     gath = gather(d, us[r], q)
                     v = rhs[ix[:m]] + gath[:m]
-                    xs[r][ix[:m]] = inv @ v
+                    o0, on = int(d["orow0"][q]), int(d["orows"][q])
+                    xs[r][ix[o0:o0 + on]] = inv[o0:o0 + on] @ v  # (a rank keeps and applies only its own rows of the inverse)
                     lo, cnt = int(d["brow0"][q]), int(d["brow"][q])
                     at = int(d["ux_base"][q]) + r * int(d["ux_stride"][q])
                     us[r][at:at + cnt] = gath[m + lo:m + lo + cnt] + Lr @ v
@@ -409,9 +410,8 @@ class EmulatedDistributedTop:
                     m = int(d["m"][q])
                     ix = d["idx"][d["idx_off"][q]:d["idx_off"][q + 1]]
                     o0, on = int(d["orow0"][q]), int(d["orows"][q])
-                    if d["b"][q] > 0:
-                        piece = xs[r][ix[o0:o0 + on]] - d["fac"][q][2] @ xs[r][ix[m:]]
-                        pieces.append((ix[o0:o0 + on], piece))
+                    piece = xs[r][ix[o0:o0 + on]] - (d["fac"][q][2] @ xs[r][ix[m:]] if d["b"][q] > 0 else 0.0)
+                    pieces.append((ix[o0:o0 + on], piece))
                 for own, piece in pieces:  # exchange of the own-row slices
                     for r in range(P):
                         xs[r][own] = piece

@@ -248,9 +248,9 @@ def test_distributed_top_nodes_are_still_a_direct_solve(case, nranks, dist_min):
         w = -(-b // nranks)
         assert np.array_equal(t["brow0"][k4], np.minimum(b[k4], r * w[k4])) and np.array_equal(t["brow"][k4], np.minimum(b[k4], (r + 1) * w[k4]) - t["brow0"][k4])
         assert np.array_equal(t["brow"][~k4], b[~k4]) and np.array_equal(t["orows"][~k4], m[~k4])
-        # a rank's factor entries: whole inverse, its rows of L, its rows of U
+        # a rank's factor entries: its own rows of the inverse and of U, its boundary rows of L
         here = t["kind"] != 3
-        want = int((m * m + t["brow"].astype(np.int64) * m + t["orows"].astype(np.int64) * b)[here].sum())
+        want = int((t["orows"].astype(np.int64) * m + t["brow"].astype(np.int64) * m + t["orows"].astype(np.int64) * b)[here].sum())
         assert ans[r].factor_entries == want
         mem = ans[r].memory(8, 0)
         assert mem["factors"] == want * 8

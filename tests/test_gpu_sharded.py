@@ -168,7 +168,7 @@ def test_sharded_3d_case_with_four_ranks_matches_the_single_gpu_solve(tmp_path):
 
 
 @pytest.mark.parametrize("world,case,env", [(2, "S2k", "LSA_ND_DIST_MIN=1"), (4, "S2k", "LSA_ND_DIST_MIN=1,LSA_ND_XSTAGE_KB=8"),
-                                            (3, "C9k", "LSA_ND_DIST_MIN=1,LSA_ND_XSTAGE_KB=64"), (4, "C40k", "LSA_ND_DIST_MIN=1"),
+                                            (3, "C9k", "LSA_ND_DIST_MIN=1,LSA_ND_XSTAGE_KB=64"),
                                             (4, "C40k", "LSA_ND_DIST_MIN=2500,LSA_ND_WORK_MB=64"), (4, "C160k", "LSA_ND_DIST_MIN=3000")])
 def test_distributed_top_fronts_with_several_ranks_on_one_gpu(tmp_path, world, case, env):
     """The top of the forest DISTRIBUTED over the ranks (what BASELINE config 4's 5 M unknowns on eight GPUs need: replicated, the

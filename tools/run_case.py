@@ -20,6 +20,17 @@ ap.add_argument("--atol", type=float, default=1e-10)
 ap.add_argument("--levels", type=int, default=2)
 ap.add_argument("--ncv", type=int, default=80)
 args = ap.parse_args()
+import threading  # noqa: E402
+
+
+def _heartbeat():  # (a 2 M-unknown 3D assembly is minutes of silent numpy: the GPU box ends commands that say nothing for 7 minutes)
+    while True:
+        time.sleep(60)
+        print(f"... {time.time() - T_START:.0f}s", flush=True)
+
+
+T_START = time.time()
+threading.Thread(target=_heartbeat, daemon=True).start()
 t0 = time.time()
 es = fem.cube_case(args.case) if args.case.startswith("C") else fem.cylinder_case(args.case)
 sigma = fem.SIGMA_CUBE if args.case.startswith("C") else fem.SIGMA_RE50

@@ -125,26 +125,6 @@ int lsa_ilu_info(const lsa_ilu *pc, int64_t *nnz, int32_t *levels_lower, int32_t
 /* copy the factor out (CSR, L strictly below the diagonal with unit diagonal implied, U on and above) */
 int lsa_ilu_download(lsa_ctx *ctx, const lsa_ilu *pc, int32_t *rowptr, int32_t *col, void *val);
 
-/* ---- exact block-tridiagonal LU: PC LU of the ST's KSP (the reference's cylinder setting, -------------------------
- * .examples/eigenvalues.py:100; Sensitivity/__init__.py:182,260) ---------------------------------------------------- */
-typedef struct lsa_blu lsa_blu;
-/* C must be in a banded (RCM) order.  block_size <= 0 picks max(1024, bandwidth + 1) rounded up to 256.  The Schur
- * blocks are inverted on the device (Gauss-Jordan, partial pivoting) into n * block_size resident scalars; fails with
- * LSA_ERR_HIP when they do not fit (3D meshes: use lsa_ilu_create) and with LSA_ERR_ZERO_PIVOT on a singular block.
- * C is borrowed: its sparse off-diagonal blocks are read at every solve, so it must outlive the factorisation. */
-int lsa_blu_create(lsa_ctx *ctx, const lsa_mat *C, int32_t block_size, lsa_blu **out);
-void lsa_blu_destroy(lsa_blu *f);
-/* x = C^-1 b (direct solve: forward + backward block sweeps replayed from a hipGraph) */
-int lsa_blu_solve(lsa_ctx *ctx, lsa_blu *f, const lsa_vec *b, lsa_vec *x);
-int lsa_blu_solve_time(lsa_ctx *ctx, lsa_blu *f, const lsa_vec *b, lsa_vec *x, int iters, double *avg_ms);
-int lsa_blu_info(const lsa_blu *f, int32_t *block_size, int32_t *nblocks, int32_t *bandwidth, double *seconds);
-/* algorithmic bytes of one lsa_blu_solve: the Schur inverses (elimination sweep: whole blocks; substitution sweep: the
- * columns that meet a non-zero), the off-block entries of C twice, the vectors -- the numerator of an achieved GB/s */
-int lsa_blu_apply_bytes(const lsa_blu *f, int64_t *bytes);
-/* dependent kernel launches of one lsa_blu_solve: one per pair of blocks and sweep when the couplings to the neighbouring
- * blocks are absorbed into dense operators (blocks of <= 1024 rows), two otherwise (sparse update + dense mat-vec) */
-int lsa_blu_apply_launches(const lsa_blu *f, int32_t *launches);
-
 /* ---- nested-dissection multifrontal LU: PC LU of the ST's KSP (.examples/eigenvalues.py:100;
  * Sensitivity/__init__.py:182,260) ---------------------------------------------------------------------------------------
  * The sparse direct solver PETSc's PC LU stands for, rebuilt for the device: elimination forest of dense fronts from a
@@ -258,8 +238,8 @@ typedef struct {
     double ksp_rtol;      /* inner GMRES relative tolerance                                  */
     int32_t ksp_restart;  /* GMRES restart length                                            */
     int32_t ksp_maxit;    /* GMRES iteration cap                                             */
-    int32_t pc_type;      /* 0 = none, 1 = ILU(k), 2 = exact LU (nested-dissection multifrontal), 3 = exact block-tridiagonal LU
-                             of a banded order; 2 and 3 fall back to ILU(k) + GMRES only when they run out of device memory */
+    int32_t pc_type;      /* 0 = none, 1 = ILU(k), 2 = exact LU (nested-dissection multifrontal; falls back to ILU(k) + GMRES only
+                             when it runs out of device memory).  (3, round 1's banded block LU, is a cross-check library now.) */
     double antishift[2];  /* mode 2 only: nu of the Cayley transform (re, im); SLEPc's default is nu = sigma */
 } lsa_op_options;
 

@@ -318,8 +318,8 @@ class iEpsSolver:
         self._ksp_rtol, self._restart_len, self._ksp_max_it = ksp_rtol, restart, ksp_max_it
         self._ilu_levels, self._ilu_shift = ilu_levels, ilu_shift
         self._ordering = ordering
-        if lu not in ("nd", "band"):
-            raise ValueError("lu must be 'nd' (nested-dissection multifrontal LU) or 'band' (block-tridiagonal LU of the RCM order)")
+        if lu != "nd":  # ('band', round 1's block-tridiagonal LU of the RCM order, is a cross-check library of the tests now)
+            raise ValueError("lu must be 'nd' (nested-dissection multifrontal LU)")
         self._lu = lu
         # adjoint=True: eigenpairs of (A^H, M^H) -- left eigenvectors of (A, M) -- through the operator
         # (A - conj(target) M)^-H M^H applied on the factors of A - conj(target) M: no transposed matrix is formed
@@ -394,9 +394,9 @@ class iEpsSolver:
         if self._pc_type in (PreconditionerType.ILU, PreconditionerType.ICC):
             return 1, 0  # PETSc's PCILU default: zero fill
         if self._pc_type in (PreconditionerType.LU, PreconditionerType.CHOLESKY):
-            # exact solves in the reference: nested-dissection multifrontal LU on the device (``lu="band"``: the
-            # block-tridiagonal LU of the RCM order); ILU(2) + GMRES only if the factors do not fit the device memory
-            return (2 if self._lu == "nd" else 3), 2
+            # exact solves in the reference: nested-dissection multifrontal LU on the device; ILU(2) + GMRES only if the
+            # factors do not fit the device memory
+            return 2, 2
         return 1, 2  # every other PETSc name: ILU(2) + GMRES
 
     def _signature(self):

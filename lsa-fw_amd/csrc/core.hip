@@ -85,7 +85,6 @@ void lsa_ctx_destroy(lsa_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    lsa_blu_drop_cache(ctx);
     lsa_ndlu_drop_cache(ctx);
     lsa_krylov_drop_cache(ctx);
     comm_release(ctx);  // before the stream the communicator is bound to goes away

@@ -103,13 +103,11 @@ struct lsa_ctx {
     void* comm_stage = nullptr;
     size_t comm_stage_bytes = 0;
     int64_t comm_calls = 0, comm_bytes = 0;  // all-gathers issued, bytes received by this rank
-    // the last destroyed block LU (symbolic data + buffers), reused when the next one has the same pattern and shape:
-    // a shift sweep refactorises the same pattern once per sigma (.examples/eigenvalues.py:97-108)
-    struct lsa_blu* blu_cache = nullptr;
-    struct lsa_ndlu* nd_cache = nullptr;  // the same for the nested-dissection LU (analysis + tables + buffers)
+    // the last destroyed nested-dissection LU (analysis + tables + buffers), reused when the next one has the same pattern and
+    // shape: a shift sweep refactorises the same pattern once per sigma (.examples/eigenvalues.py:97-108)
+    struct lsa_ndlu* nd_cache = nullptr;
     struct lsa_krylov* krylov_cache = nullptr;  // the last destroyed Krylov workspace (two bases, work vectors), reused by the next of the same shape
 };
-extern "C" void lsa_blu_drop_cache(lsa_ctx* ctx);   // blocklu.hip (internal; not part of include/lsa_hip.h)
 extern "C" void lsa_ndlu_drop_cache(lsa_ctx* ctx);  // ndlu.hip
 extern "C" void lsa_krylov_drop_cache(lsa_ctx* ctx);  // solver.hip
 

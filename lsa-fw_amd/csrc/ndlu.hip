@@ -1581,6 +1581,8 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         if (S.has_dist) budget = std::max<int64_t>((free_agreed > 0 ? free_agreed : (int64_t)free_b) / 6, (int64_t)256 << 20) / (int64_t)es;
         if (const char* e = getenv("LSA_ND_WORK_MB")) budget = std::max<int64_t>(atoll(e), 1) * (1 << 20) / (int64_t)es;
     }
+    if (getenv("LSA_ND_TEST_OOM"))  // test aid: rehearses the one failure the operator layer answers by a leaner method
+        return lsa_set_error(ctx, LSA_ERR_OOM, "lsa_ndlu: out of device memory (forced by LSA_ND_TEST_OOM)");
     NdMemoryPlan P;
     nd_memory_plan(S, budget, P);
     for (int32_t t = 0; t < nt; ++t) {  // every kept node, the other ranks' subtree roots included (they are children here)

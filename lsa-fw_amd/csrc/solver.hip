@@ -10,8 +10,6 @@
 
 int ilu_check_abort(lsa_ctx* ctx, lsa_ilu* pc);
 int k_allgather_inplace(lsa_ctx* ctx, void* vec, size_t bytes_per_rank);  // comm.hip
-struct lsa_blu;
-int blu_solve_dev(lsa_ctx* ctx, lsa_blu* f, int vdtype, const void* b, void* x);  // blocklu.hip
 
 namespace {
 
@@ -131,13 +129,12 @@ int spmv_global(lsa_ctx* ctx, const lsa_mat* A, int dtype, const void* x, void* 
 // x = P^-1 b: block-Jacobi over ranks (each rank holds the ILU(k) of its diagonal block), then all-gather
 struct PcRef {
     lsa_ilu* ilu = nullptr;  // ILU(k) + triangular solves
-    lsa_blu* blu = nullptr;  // exact block-tridiagonal LU (banded order)
     lsa_ndlu* nd = nullptr;  // exact nested-dissection multifrontal LU
     bool nd_dist = false;    // the subtree-parallel form: reads and writes whole replicated vectors
     bool adjoint = false;    // solve with C^H on the same factors (nd only)
     double normF = 0.0;      // ||C||_F when known: lets a direct solve be judged by its backward error
-    explicit operator bool() const { return ilu || blu || nd; }
-    bool exact() const { return blu || nd; }
+    explicit operator bool() const { return ilu || nd; }
+    bool exact() const { return nd != nullptr; }
 };
 
 int pc_global(lsa_ctx* ctx, PcRef pc, int32_t row0, int64_t nglobal, int dtype, const void* b, void* x) {
@@ -147,7 +144,6 @@ int pc_global(lsa_ctx* ctx, PcRef pc, int32_t row0, int64_t nglobal, int dtype, 
     if (pc.nd && pc.adjoint) LSA_CHECK(ndlu_solve_adjoint_dev(ctx, pc.nd, 1, dtype, pc.nd_dist ? b : bl, pc.nd_dist ? x : xl));
     else if (pc.nd && pc.nd_dist) LSA_CHECK(ndlu_solve_dev(ctx, pc.nd, dtype, b, x));  // own subtrees + replicated top; x completed below
     else if (pc.nd) LSA_CHECK(ndlu_solve_dev(ctx, pc.nd, dtype, bl, xl));
-    else if (pc.blu) LSA_CHECK(blu_solve_dev(ctx, pc.blu, dtype, bl, xl));
     else LSA_CHECK(ilu_solve_dev(ctx, pc.ilu, 2, dtype, bl, xl));
     if (ctx->nranks > 1) LSA_CHECK(k_allgather_inplace(ctx, x, (size_t)(nglobal / ctx->nranks) * es));
     return LSA_OK;
@@ -445,7 +441,6 @@ struct lsa_op {
     lsa_mat* owned_mul = nullptr;  // Cayley: A + nu M
     lsa_mat* owned_diag;  // sharded layout: this rank's diagonal block of C (input of the block-Jacobi ILU)
     lsa_ilu* pc;
-    lsa_blu* blu;         // exact block-tridiagonal LU (opts.pc_type == 3)
     lsa_ndlu* nd = nullptr;  // exact nested-dissection LU (opts.pc_type == 2)
     bool nd_dist = false;    // ... subtree-parallel over the ranks: works on whole replicated vectors
     bool adjoint = false;    // y = Kfac^-H Kmul^H x on the same factors (lsa_op_set_adjoint)
@@ -566,7 +561,6 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
     op->Kmul = op->Kfac = nullptr;
     op->owned = op->owned_diag = nullptr;
     op->pc = nullptr;
-    op->blu = nullptr;
     op->opts = *opts;
     op->gw_ready = false;
     op->t = nullptr;
@@ -633,7 +627,12 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
         fac_src = sharded ? Md : M;
     }
     bool lu_fell_back = false;
-    if (op->Kfac && fac_src && (opts->pc_type == 2 || opts->pc_type == 3)) {
+    if (opts->pc_type == 3) {
+        lsa_op_destroy(op);
+        return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_op_create: pc_type 3 (the banded block LU of round 1) left the product library; it lives on as a "
+                                               "cross-check library for the tests (tests/xcheck).  Use pc_type 2, the nested-dissection LU");
+    }
+    if (op->Kfac && fac_src && opts->pc_type == 2) {
         // exact LU.  Only running out of device memory is answered by the leaner ILU(k) + GMRES (and said so on stderr
         // and in the statistics); a singular pivot block or any other failure is an error, as with PETSc's PC LU.
         if (tree) {
@@ -644,7 +643,7 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
                 return rc;
             }
         } else
-            rc = opts->pc_type == 2 ? lsa_ndlu_create(ctx, fac_src, 0, &op->nd) : lsa_blu_create(ctx, fac_src, 0, &op->blu);
+            rc = lsa_ndlu_create(ctx, fac_src, 0, &op->nd);
         if (rc == LSA_OK && op->nd) {
             double sa = 1.0;
             (void)lsa_ndlu_info(op->nd, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, &sa, nullptr);
@@ -672,7 +671,7 @@ static int op_build(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* M, const lsa_
         lsa_op_destroy(op);
         return lsa_set_error(ctx, LSA_ERR_HIP, "lsa_op_create: out of device memory");
     }
-    if (op->Kfac && (op->nd || op->blu) && fac_src && fac_src->nnz > 0) {
+    if (op->Kfac && op->nd && fac_src && fac_src->nnz > 0) {
         // ||C||_F (one reduction over the values): the scale of the backward-error test of the direct solves
         // (the result goes to the head of the operator's own temp vector, not to the context's scratch: k_nrm2 keeps its partial
         //  sums there and may reallocate it; the head is zeroed again afterwards -- padding rows must read zero)
@@ -712,7 +711,6 @@ void lsa_op_destroy(lsa_op* op) {
     if (!op) return;
     if (op->ctx && op->ctx->stream) (void)hipStreamSynchronize(op->ctx->stream);
     if (op->pc) lsa_ilu_destroy(op->pc);
-    if (op->blu) lsa_blu_destroy(op->blu);
     if (op->nd) lsa_ndlu_destroy(op->nd);
     if (op->view_fac) lsa_mat_destroy(op->view_fac);
     if (op->view_mul) lsa_mat_destroy(op->view_mul);
@@ -744,13 +742,12 @@ static int op_apply_dev(lsa_ctx* ctx, lsa_op* op, const void* x, void* y) {
     if (!op->gw_ready) {
         int restart = std::max(1, std::min(op->opts.ksp_restart, op->opts.ksp_maxit));
         // with an exact factorisation on one GPU GMRES only polishes (0-2 iterations): keep its basis small
-        if ((op->blu || op->nd) && (ctx->nranks == 1 || op->nd_dist)) restart = std::min(restart, 40);
+        if (op->nd && (ctx->nranks == 1 || op->nd_dist)) restart = std::min(restart, 40);
         LSA_CHECK(op->gw.alloc(ctx, op->n, restart, dtype));
         op->gw_ready = true;
     }
     PcRef pcr;
     pcr.ilu = op->pc;
-    pcr.blu = op->blu;
     pcr.nd = op->nd;
     pcr.nd_dist = op->nd_dist;
     pcr.adjoint = op->adjoint;
@@ -943,7 +940,6 @@ static int krylov_enqueue_step(lsa_ctx* ctx, lsa_krylov* k, int32_t j, int32_t s
         rhs = op->t;
     }
     PcRef pcr;
-    pcr.blu = op->blu;
     pcr.nd = op->nd;
     pcr.nd_dist = op->nd_dist;
     pcr.adjoint = op->adjoint;
@@ -977,7 +973,7 @@ static int krylov_enqueue_step(lsa_ctx* ctx, lsa_krylov* k, int32_t j, int32_t s
 // synchronises with the host by itself (the host-staged exchange does)
 static bool krylov_can_pipeline(const lsa_ctx* ctx, const lsa_krylov* k) {
     const lsa_op* op = k->op;
-    if (!k->pipeline || !op->Kfac || !(op->nd || op->blu) || op->pc) return false;
+    if (!k->pipeline || !op->Kfac || !op->nd || op->pc) return false;
     if (ctx->nranks > 1 && (!op->nd_dist || ctx->host_gather)) return false;
     return true;
 }

@@ -131,13 +131,6 @@ SIGNATURES = {
     "lsa_ilu_solve_time": (ctypes.c_int, [_P, _P, ctypes.c_int, _P, _P, ctypes.c_int, ctypes.POINTER(_DBL)]),
     "lsa_ilu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I64), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)]),
     "lsa_ilu_download": (ctypes.c_int, [_P, _P, _P, _P, _P]),
-    "lsa_blu_create": (ctypes.c_int, [_P, _P, _I32, _PP]),
-    "lsa_blu_destroy": (None, [_P]),
-    "lsa_blu_solve": (ctypes.c_int, [_P, _P, _P, _P]),
-    "lsa_blu_solve_time": (ctypes.c_int, [_P, _P, _P, _P, ctypes.c_int, ctypes.POINTER(_DBL)]),
-    "lsa_blu_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_DBL)]),
-    "lsa_blu_apply_bytes": (ctypes.c_int, [_P, ctypes.POINTER(_I64)]),
-    "lsa_blu_apply_launches": (ctypes.c_int, [_P, ctypes.POINTER(_I32)]),
     "lsa_nd_analyse": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _PP]),
     "lsa_nd_order": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _PP]),
     "lsa_nd_analyse_tree": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _PP]),
@@ -518,40 +511,6 @@ class Ilu:
     def __del__(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
             self.ctx._lib.lsa_ilu_destroy(self.handle)
-            self.handle = None
-
-
-class BlockLu:
-    """Exact block-tridiagonal LU of a banded CSR matrix, resident on the device (``lsa_blu_*``)."""
-
-    def __init__(self, ctx: Context, C: CsrMatrix, block_size: int = 0):
-        self.ctx, self._C = ctx, C  # C is borrowed by the factorisation: keep it alive
-        h = ctypes.c_void_p()
-        ctx.check(ctx._lib.lsa_blu_create(ctx.handle, C.handle, int(block_size), ctypes.byref(h)))
-        self.handle = h
-        self.n = C.shape[0]
-
-    def info(self) -> dict:
-        B, nb, bw, sec = _I32(0), _I32(0), _I32(0), _DBL(0.0)
-        self.ctx._lib.lsa_blu_info(self.handle, ctypes.byref(B), ctypes.byref(nb), ctypes.byref(bw), ctypes.byref(sec))
-        nbytes = _I64(0)
-        self.ctx._lib.lsa_blu_apply_bytes(self.handle, ctypes.byref(nbytes))
-        nl = _I32(0)
-        self.ctx._lib.lsa_blu_apply_launches(self.handle, ctypes.byref(nl))
-        return {"block_size": B.value, "nblocks": nb.value, "bandwidth": bw.value, "seconds": sec.value, "apply_bytes": nbytes.value,
-                "apply_launches": nl.value}
-
-    def solve(self, b: DeviceVector, x: DeviceVector) -> None:
-        self.ctx.check(self.ctx._lib.lsa_blu_solve(self.ctx.handle, self.handle, b.handle, x.handle))
-
-    def time_solve(self, b: DeviceVector, x: DeviceVector, iters: int) -> float:
-        ms = _DBL(0.0)
-        self.ctx.check(self.ctx._lib.lsa_blu_solve_time(self.ctx.handle, self.handle, b.handle, x.handle, int(iters), ctypes.byref(ms)))
-        return ms.value
-
-    def __del__(self):
-        if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):
-            self.ctx._lib.lsa_blu_destroy(self.handle)
             self.handle = None
 
 

@@ -57,3 +57,18 @@ def test_no_gpu_means_loud_failure_not_fallback():
     es = EigenSolver(np.diag([1.0, 2.0, 3.0]), None, EigensolverConfig(num_eig=1))
     with pytest.raises(RuntimeError):
         es.solve()
+
+
+def test_cross_check_library_exports_its_header():
+    """tests/xcheck/liblsa_xcheck.so (test-only: round 1's banded block LU) loads beside the product library and exports what its
+    own header declares; none of it is part of include/lsa_hip.h any more."""
+    import helpers  # noqa: F401
+    import xcheck
+
+    lib = xcheck.load_library()
+    text = re.sub(r"/\*.*?\*/", "", (Path(__file__).resolve().parent / "xcheck" / "lsa_xcheck.h").read_text(), flags=re.S)
+    declared = set(re.findall(r"\b(lsa_blu_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(xcheck.SIGNATURES) and len(declared) == 7
+    for name in declared:
+        assert hasattr(lib, name)
+    assert not any(name.startswith("lsa_blu") for name in declared_functions())

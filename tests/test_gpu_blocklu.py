@@ -1,5 +1,6 @@
-"""GPU parity tests of the exact block-tridiagonal LU (PreconditionerType.LU on the device) against SuperLU and the
-eigen oracle."""
+"""GPU tests of the CROSS-CHECK library (tests/xcheck: round 1's exact block-tridiagonal LU, an independent direct solver on the
+device) against SuperLU, of the product's exact LU against it, and of PreconditionerType.LU through the drop-in surface against
+the eigen oracle."""
 
 import numpy as np
 import pytest
@@ -7,6 +8,9 @@ import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
 pytestmark = pytest.mark.gpu
+
+import helpers  # noqa: E402,F401  (sys.path)
+import xcheck  # noqa: E402  (tests/xcheck: liblsa_xcheck.so)
 
 
 def _ordered(case, sigma):
@@ -31,7 +35,7 @@ def test_block_lu_is_a_direct_solver(hip_ctx, case, sigma, block):
 
     es, Cp = _ordered(case, sigma)
     dC = lsa_hip.CsrMatrix.from_scipy(hip_ctx, Cp)
-    f = lsa_hip.BlockLu(hip_ctx, dC, block)
+    f = xcheck.BlockLu(hip_ctx, dC, block)
     info = f.info()
     assert info["block_size"] > info["bandwidth"] and info["block_size"] % 256 == 0
     assert info["nblocks"] == -(-es.n // info["block_size"])
@@ -59,7 +63,7 @@ def test_block_lu_real_matrix(hip_ctx, block):
     A = A + sp.diags(0.05 * np.ones(n), 0)
     A = sp.csr_matrix(A)
     A.sort_indices()
-    f = lsa_hip.BlockLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), block)
+    f = xcheck.BlockLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), block)
     b = rng.standard_normal(n)
     dx = lsa_hip.DeviceVector(hip_ctx, n, np.float64)
     f.solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
@@ -76,7 +80,7 @@ def test_block_lu_ragged_sizes(hip_ctx, n):
     offs = [o for o in (-3, -1, 0, 1, 2) if abs(o) < n]
     A = sp.csr_matrix(sp.diags([rng.standard_normal(n - abs(o)) + 1j * rng.standard_normal(n - abs(o)) for o in offs], offs, format="csr"))
     A.sort_indices()
-    f = lsa_hip.BlockLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), 256)
+    f = xcheck.BlockLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), 256)
     b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
     dx = lsa_hip.DeviceVector(hip_ctx, n, np.complex128)
     f.solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
@@ -97,7 +101,7 @@ def test_block_lu_absorbed_and_sparse_sweeps_agree(hip_ctx, monkeypatch, block):
     xs, launches = [], []
     for absorb in ("1", "0"):
         monkeypatch.setenv("LSA_BLU_ABSORB", absorb)
-        f = lsa_hip.BlockLu(hip_ctx, dC, block)
+        f = xcheck.BlockLu(hip_ctx, dC, block)
         dx = lsa_hip.DeviceVector(hip_ctx, es.n, np.complex128)
         f.solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
         xs.append(dx.numpy())
@@ -119,7 +123,7 @@ def test_block_lu_unblocked_elimination_agrees(hip_ctx, monkeypatch):
     for panel in ("8", "1"):
         monkeypatch.setenv("LSA_GJ_PANEL", panel)
         dx = lsa_hip.DeviceVector(hip_ctx, es.n, np.complex128)
-        lsa_hip.BlockLu(hip_ctx, dC, 512).solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
+        xcheck.BlockLu(hip_ctx, dC, 512).solve(lsa_hip.DeviceVector.from_numpy(hip_ctx, b), dx)
         xs.append(dx.numpy())
     assert np.linalg.norm(xs[0] - xs[1]) <= 1e-11 * np.linalg.norm(xs[1])
 
@@ -132,7 +136,7 @@ def test_block_lu_reports_singular_block(hip_ctx):
     rows = np.repeat(np.arange(n), np.diff(A.indptr))
     A.data[(rows == 10) | (A.indices == 10)] = 0.0  # row and column 10 vanish; the entries stay in the pattern
     with pytest.raises(lsa_hip.LsaError) as ei:
-        lsa_hip.BlockLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), 256)
+        xcheck.BlockLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, A), 256)
     assert ei.value.status == -3
 
 
@@ -162,12 +166,10 @@ def test_eigensolver_with_lu_preconditioner_matches_oracle():
     assert solver.solver.residuals().max() <= 1e-8
 
 
-def test_lu_request_falls_back_to_ilu_when_the_band_does_not_fit():
-    """PreconditionerType.LU with the block-tridiagonal LU (``lu="band"``) on a matrix whose band cannot be inverted in HBM
-    (a periodic chain in natural order: bandwidth n - 1): ``lsa_blu_create`` reports LSA_ERR_OOM -- the only failure that
-    is answered by a leaner method --, the operator is built on ILU(2) + GMRES instead, says so (``stats["pc_fallback"]``,
-    a warning) and the eigenvalues still match the oracle.  The nested-dissection LU (the default) has no band to fit:
-    it solves the same problem directly."""
+def test_lu_request_falls_back_to_ilu_when_the_factors_do_not_fit(monkeypatch):
+    """PreconditionerType.LU when the exact factors do not fit the device memory (forced here: LSA_ND_TEST_OOM makes the set-up of the
+    nested-dissection LU report LSA_ERR_OOM -- the only failure that is answered by a leaner method): the operator is built on
+    ILU(2) + GMRES instead, says so (``stats["pc_fallback"]``, a warning) and the eigenvalues still match the oracle."""
     from oracle import shift_invert
     from Solver.eigen import EigenSolver, EigensolverConfig
     from Solver.utils import PreconditionerType, iSTType
@@ -179,8 +181,12 @@ def test_lu_request_falls_back_to_ilu_when_the_band_does_not_fit():
     A = sp.csr_matrix(A)
     sigma = 1.7
     ref, _, _ = shift_invert.solve(A, None, sigma, k=3, tol=1e-12, ncv=30)
-    for kind in ("band", "nd"):
-        solver = EigenSolver(A, None, EigensolverConfig(num_eig=3, atol=1e-10, ncv=30), check_hermitian=False, ordering="natural", lu=kind)
+    for forced in (True, False):
+        if forced:
+            monkeypatch.setenv("LSA_ND_TEST_OOM", "1")
+        else:
+            monkeypatch.delenv("LSA_ND_TEST_OOM")
+        solver = EigenSolver(A, None, EigensolverConfig(num_eig=3, atol=1e-10, ncv=30), check_hermitian=False, ordering="natural")
         solver.solver.set_st_type(iSTType.SINVERT)
         solver.solver.set_target(sigma)
         solver.solver.set_st_pc_type(PreconditionerType.LU)
@@ -188,7 +194,7 @@ def test_lu_request_falls_back_to_ilu_when_the_band_does_not_fit():
         for r in ref:
             assert np.min(np.abs(lam - r)) <= 1e-8 * abs(r)
         st = solver.solver.stats
-        if kind == "band":  # inner solves were iterative: the block LU was not available
+        if forced:  # inner solves were iterative: the exact LU was not available
             assert st["pc_fallback"] == 1 and st["gmres_iters"] > 0
         else:
             assert st["pc_fallback"] == 0 and st["gmres_iters"] == 0

@@ -68,18 +68,14 @@ def test_s30k_cayley_agrees_with_shift_invert(s30k):
         assert np.min(np.abs(lam_cy - r)) <= 1e-8 * abs(r)
 
 
-def test_s30k_block_lu_round_trip(hip_ctx, s30k):
-    """x -> C x (SpMV) -> C^-1 (block LU sweeps) returns x: the two hot kernels against each other at full size."""
+def test_s30k_lu_round_trip(hip_ctx, s30k):
+    """x -> C x (SpMV) -> C^-1 (sweeps of the exact LU) returns x: the two hot kernels against each other at full size."""
     import lsa_hip
     from synthetic import fem
-    from Solver.utils import pivot_safe_rcm
 
     C = sp.csr_matrix((s30k.A.data - fem.SIGMA_RE50 * s30k.M.data, s30k.A.indices, s30k.A.indptr), shape=s30k.A.shape)
-    perm = pivot_safe_rcm(C)
-    C = C[perm][:, perm].tocsr()
-    C.sort_indices()
     dC = lsa_hip.CsrMatrix.from_scipy(hip_ctx, C)
-    f = lsa_hip.BlockLu(hip_ctx, dC)
+    f = lsa_hip.NdLu(hip_ctx, dC, 0)
     rng = np.random.default_rng(5)
     x = rng.standard_normal(s30k.n) + 1j * rng.standard_normal(s30k.n)
     dx = lsa_hip.DeviceVector.from_numpy(hip_ctx, x)
@@ -90,5 +86,4 @@ def test_s30k_block_lu_round_trip(hip_ctx, s30k):
     f.solve(db, dy)
     assert np.linalg.norm(dy.numpy() - x) <= 1e-9 * np.linalg.norm(x)  # cond(C) ~ 1e5 at this shift
     info = f.info()
-    assert info["block_size"] == 1024 and info["nblocks"] == 31 and info["apply_bytes"] > 5e8
-    assert info["apply_launches"] == 31  # absorbed couplings: one launch per pair of blocks and sweep, plus the middle block
+    assert info["apply_bytes"] > 1e8 and info["apply_launches"] <= 2 * info["levels"]

@@ -175,24 +175,32 @@ def test_ndlu_refactor_and_cached_analysis(hip_ctx):
     assert np.array_equal(_solve(hip_ctx, g, b), x0)
 
 
-def test_eigensolver_lu_variants_agree(hip_ctx):
-    """The drop-in surface with both exact factorisations (lu='nd' default, lu='band'): same eigenvalues to 1e-10."""
+def test_product_lu_against_the_cross_check_library(hip_ctx):
+    """The product's direct solver (nested-dissection multifrontal LU) against an independent one on the same device (round 1's
+    block-tridiagonal LU of the RCM order, tests/xcheck): the same solution to 1e-10."""
+    import helpers  # noqa: F401
+    import lsa_hip
+    import xcheck
     from synthetic import fem
-    from Solver.eigen import EigenSolver, EigensolverConfig
-    from Solver.utils import PreconditionerType, iSTType
+    from Solver.utils import pivot_safe_rcm
 
     es = fem.cylinder_case("S5k")
-    lam = {}
-    for kind in ("nd", "band"):
-        s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=6, atol=1e-11, ncv=40), check_hermitian=False, lu=kind)
-        s.solver.set_st_type(iSTType.SINVERT)
-        s.solver.set_target(SIGMA)
-        s.solver.set_st_pc_type(PreconditionerType.LU)
-        pairs = s.solve()
-        lam[kind] = np.array([p[0] for p in pairs[:6]])
-        assert s.solver.stats["gmres_iters"] <= 2 * s.solver.stats["op_applies"]  # direct solves, at most polished
-        s.solver.release()
-    assert np.max(np.abs(lam["nd"] - lam["band"]) / np.abs(lam["band"])) < 1e-10
+    C = sp.csr_matrix((es.A.data - SIGMA * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
+    perm = pivot_safe_rcm(C)
+    C = C[perm][:, perm].tocsr()
+    C.sort_indices()
+    dC = lsa_hip.CsrMatrix.from_scipy(hip_ctx, C)
+    rng = np.random.default_rng(11)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    db = lsa_hip.DeviceVector.from_numpy(hip_ctx, b)
+    xs = []
+    for f in (lsa_hip.NdLu(hip_ctx, dC, 0), xcheck.BlockLu(hip_ctx, dC)):
+        dx = lsa_hip.DeviceVector(hip_ctx, es.n, np.complex128)
+        f.solve(db, dx)
+        xs.append(dx.numpy())
+        del f
+    assert np.linalg.norm(xs[0] - xs[1]) <= 1e-10 * np.linalg.norm(xs[1])
+    assert np.linalg.norm(C @ xs[0] - b) <= 1e-12 * np.linalg.norm(b)
 
 
 @pytest.mark.parametrize("case,sigma,leaf,tp_min", [("S5k", SIGMA, 0, 32), ("S5k", 0.05, 200, 32), ("S30k", SIGMA, 0, 64), ("S30k", SIGMA, 600, 100),

@@ -1,3 +1,7 @@
+// CROSS-CHECK LIBRARY (liblsa_xcheck.so, tests only -- not part of liblsa_hip.so): round 1's exact solver, superseded in the
+// product by the nested-dissection multifrontal LU (lsa-fw_amd/csrc/ndlu.hip) and kept as an independent direct solver the
+// tests compare it with.
+//
 // Exact block-tridiagonal LU of the shifted operator: the device counterpart of PreconditionerType.LU, which is what
 // the reference's cylinder runs use for the ST's inner solve (.examples/eigenvalues.py:100, Sensitivity/__init__.py:182).
 //
@@ -19,12 +23,12 @@
 // substitution sweep reads only the columns of the Schur inverses that meet a non-zero.  It is a *direct* solve
 // (residual ~1e-14): the GMRES around it checks b - C x and only iterates if that check fails.
 // Not usable when the band does not fit (3D meshes) or a Schur block is singular (no pivoting across blocks):
-// lsa_blu_create then fails and the ILU(k) path is used.  A destroyed factorisation parks its buffers and symbolic
-// data in the context for the next shift of the same pattern.
+// lsa_blu_create then fails.
 #include <algorithm>
 #include <chrono>
 
 #include "lsa_internal.h"
+#include "lsa_xcheck.h"
 
 struct lsa_blu {
     lsa_ctx* ctx;
@@ -1116,29 +1120,10 @@ static void blu_free(lsa_blu* f) {
     delete f;
 }
 
-void lsa_blu_drop_cache(lsa_ctx* ctx) {
-    if (!ctx || !ctx->blu_cache) return;
-    blu_free(ctx->blu_cache);
-    ctx->blu_cache = nullptr;
-}
-
-// A destroyed factorisation parks its symbolic data and buffers in the context (one slot): allocating, clearing and
-// freeing n x B scalars and rebuilding the CSC view cost ~15 ms per shift at S30k, a fifth of the numeric work.
 void lsa_blu_destroy(lsa_blu* f) {
     if (!f) return;
-    lsa_ctx* ctx = f->ctx;
-    if (!ctx || !f->sinv || !f->cptr || f->pattern_hash == 0 || getenv("LSA_BLU_NO_CACHE")) {
-        blu_free(f);
-        return;
-    }
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (int vd = 0; vd < 2; ++vd) {  // the captured sweeps point into the values of a matrix that is going away
-        if (f->graph[vd]) (void)hipGraphExecDestroy((hipGraphExec_t)f->graph[vd]);
-        f->graph[vd] = nullptr;
-    }
-    f->C = nullptr;
-    lsa_blu_drop_cache(ctx);
-    ctx->blu_cache = f;
+    if (f->ctx && f->ctx->stream) (void)hipStreamSynchronize(f->ctx->stream);
+    blu_free(f);
 }
 
 // symbolic part of a factorisation: splits on C's pattern, a CSC view (positions into C's value array) for the corner
@@ -1273,16 +1258,6 @@ int lsa_blu_create(lsa_ctx* ctx, const lsa_mat* C, int32_t block_size, lsa_blu**
     const char* absorb_env = getenv("LSA_BLU_ABSORB");
     const bool absorb = absorb_env ? atoi(absorb_env) != 0 : B <= 1024;
     lsa_blu* f = nullptr;
-    if (lsa_blu* c = ctx->blu_cache) {
-        if (c->pattern_hash == hash && c->n == n && c->nnz == C->nnz && c->B == B && c->dtype == C->dtype && c->mid == mid && c->want_absorb == absorb &&
-            !getenv("LSA_BLU_NO_CACHE")) {
-            f = c;
-            ctx->blu_cache = nullptr;
-            f->C = C;
-        } else {
-            lsa_blu_drop_cache(ctx);  // do not hold n x B scalars for a pattern that is gone
-        }
-    }
     const bool reused = f != nullptr;
     if (!reused) {
         f = new lsa_blu();

@@ -22,7 +22,7 @@ dC = lsa_hip.CsrMatrix.from_scipy(ctx, Cp)
 for gap_ms in (0, 0, 1, 5, 10, 20, 50, 200, 0, 0):
     time.sleep(gap_ms * 1e-3)
     t0 = time.perf_counter()
-    f = lsa_hip.BlockLu(ctx, dC, 0)
+    f = lsa_hip.NdLu(ctx, dC, 0)
     dt = time.perf_counter() - t0
     del f
     print(f"idle {gap_ms:4d} ms before -> factorisation {dt * 1e3:.1f} ms", flush=True)

@@ -522,14 +522,22 @@ class iEpsSolver:
             # operators (K above is complex whenever the target was stored as a Python complex)
             cplx_factors = A.dtype.kind == "c" or (M is not None and M.dtype.kind == "c") or (sinvert and complex(sigma).imag != 0.0)
             fac = dAd if dAd is not None else dA
-            if nd_tree is not None and dAd is None:
-                fac.prepare_lu_tree(cplx_factors, nd_tree["first"], nd_tree["size"], nd_tree["parent"])
-            else:  # a rank's diagonal block (block-Jacobi layout), or no ordering asked for: the library dissects by itself
-                zero_diag = None
-                if part is None and fac.nnz > 60 * fac.shape[0]:
-                    zd = sp.csr_matrix(K).diagonal()[perm] == 0
-                    zero_diag = zd if zd.any() else None
-                fac.prepare_lu(cplx_factors, constraint=zero_diag)
+            try:
+                if nd_tree is not None and dAd is None:
+                    fac.prepare_lu_tree(cplx_factors, nd_tree["first"], nd_tree["size"], nd_tree["parent"])
+                else:  # a rank's diagonal block (block-Jacobi layout), or no ordering asked for: the library dissects by itself
+                    zero_diag = None
+                    if part is None and fac.nnz > 60 * fac.shape[0]:
+                        zd = sp.csr_matrix(K).diagonal()[perm] == 0
+                        zero_diag = zd if zd.any() else None
+                    fac.prepare_lu(cplx_factors, constraint=zero_diag)
+            except lsa_hip.LsaError as exc:
+                # The buffers of the exact LU do not fit the device: not an error of this phase.  The operator build meets the
+                # same condition and answers it as PETSc's users would have to by hand: ILU(k) + GMRES, said in the statistics
+                # (stats["pc_fallback"]) and on stderr.  Anything else is an error here as there.
+                if exc.status != lsa_hip.LSA_ERR_OOM:
+                    raise
+                logger.warning("The exact LU does not fit the device memory (%s); the solve will fall back to ILU(k) + GMRES.", exc)
         self._prepared = {"sig": self._signature(), "ctx": ctx, "dA": dA, "dM": dM, "dAd": dAd, "dMd": dMd, "part": part, "perm": perm,
                           "forest": forest,
                           "n": n, "sinvert": sinvert, "cayley": self._st_type is iSTType.CAYLEY, "sigma": sigma, "pc_code": pc_code,

@@ -108,8 +108,8 @@ def test_spmv_on_the_3d_pattern(hip_ctx):
     assert np.linalg.norm(dy.numpy() - ref) <= 1e-13 * np.linalg.norm(ref)
 
 
-def test_iterative_refinement_is_taken_and_helps(monkeypatch):
-    """One step x += C^-1 (b - C x) before any looser acceptance (csrc/solver.hip, the check of Solver/eigen2.py:178-189).  The
+def test_cube_c80k_golden_fixture_and_iterative_refinement(monkeypatch):
+    """BASELINE config 4's discretisation at 76.5 k unknowns against the oracle's golden fixture, then one step x += C^-1 (b - C x) before any looser acceptance (csrc/solver.hip, the check of Solver/eigen2.py:178-189).  The
     factors are spoilt on purpose (every U scalar times 1 + 1e-7, LSA_ND_TEST_PERTURB): a bare solve is then wrong by ~1e-7, far
     above ksp_rtol; with refinement every inner solve reaches rounding level again, nothing is accepted on its backward error
     and the eigenvalues are those of the clean factorisation."""
@@ -121,6 +121,11 @@ def test_iterative_refinement_is_taken_and_helps(monkeypatch):
     st0 = dict(s.solver.stats)
     s.solver.release()
     assert len(clean) == 10 and st0["gmres_iters"] == 0
+    # the clean solve against the oracle's fixture at this size (tests/golden/make_golden_c80k.py: SuperLU + ARPACK, 6 minutes on the CPU)
+    gold = json.loads((GOLDEN / "cube_c80k.json").read_text())
+    assert es.n == gold["n"] and es.A.nnz == gold["nnz"]
+    for r in (complex(a, b) for a, b in gold["eigenvalues"]):
+        assert np.min(np.abs(clean - r)) <= 1e-8 * abs(r)
     monkeypatch.setenv("LSA_ND_TEST_PERTURB", "1e-7")
     s = _solver(es, fem.SIGMA_CUBE, 10)
     lam = np.array([p[0] for p in s.solve()])

@@ -72,6 +72,19 @@ struct NdNodeDev {
 };
 static_assert(sizeof(NdNodeDev) == 144, "node record layout");
 
+// what the sweeps read of a node (in level order: one record per workgroup and launch, loaded first thing -- kept at 96 bytes)
+struct NdSweepNode {
+    int64_t lfac_off, ufac_off, u_off, ge_off, acc_off, pacc_off;
+    int32_t idx_off, cmap_off, own0, m, f, nchild;
+    int32_t brow0, brow, orow0, orows, flags, pad0;
+    NdSweepNode() = default;
+    explicit NdSweepNode(const NdNodeDev& n)
+        : lfac_off(n.lfac_off), ufac_off(n.ufac_off), u_off(n.u_off), ge_off(n.ge_off), acc_off(n.acc_off), pacc_off(n.pacc_off), idx_off(n.idx_off),
+          cmap_off(n.cmap_off), own0(n.own0), m(n.m), f(n.f), nchild(n.nchild), brow0(n.brow0), brow(n.brow), orow0(n.orow0), orows(n.orows),
+          flags(n.flags), pad0(0) {}
+};
+static_assert(sizeof(NdSweepNode) == 96, "sweep record layout");
+
 struct TileList {
     int64_t off = 0;  // pairs of int32 into the tile buffer
     int32_t count = 0;
@@ -1150,6 +1163,33 @@ __device__ __forceinline__ void two_row_dot_prefetched(const MT* __restrict__ Fa
     if (cn > 4 * LPR) two_row_dot<LPR>(Fa + 4 * LPR, Fb + 4 * LPR, vs + 4 * LPR, cn - 4 * LPR, sl, acc0, acc1);
 }
 
+// Loads and stores of data that ANOTHER WORKGROUP OF THE SAME LAUNCH produces or consumes (the chained sweeps below): 8-byte
+// agent-scope relaxed atomics, i.e. `sc1` accesses that go past the CU's L1 and the XCD's L2 (per-XCD L2s are not coherent with
+// each other: MI355X_MICROARCH.md, inter-workgroup visibility).  H = false: plain accesses (one launch per level: the kernel
+// boundary publishes everything).
+template <bool H>
+__device__ __forceinline__ double ld_h(const double* p) {
+    if constexpr (H) return __longlong_as_double(__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    else return *p;
+}
+template <bool H>
+__device__ __forceinline__ cplx ld_h(const cplx* p) {
+    if constexpr (H) return cplx{ld_h<true>(&p->re), ld_h<true>(&p->im)};
+    else return *p;
+}
+template <bool H>
+__device__ __forceinline__ void st_h(double* p, double v) {
+    if constexpr (H) __hip_atomic_store((long long*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <bool H>
+__device__ __forceinline__ void st_h(cplx* p, cplx v) {
+    if constexpr (H) {
+        st_h<true>(&p->re, v.re);
+        st_h<true>(&p->im, v.im);
+    } else *p = v;
+}
+
 // PULL form: sum of the children's update-vector entries that land on front position j, through the per-child gather rows
 // (fixed order: child rank).  Used where a child's vector arrives by all-gather (the replicated top of a forest cut over ranks)
 // and by the transposed sweeps.
@@ -1175,144 +1215,132 @@ __device__ __forceinline__ VT gather_updates(const int32_t* __restrict__ ge, int
 
 // PUSH form: the same sum from the node's slot rows (row c = what child c added to every front position; slots no child maps
 // to were zeroed once and are never written): contiguous loads, no index in between.  Same order of additions as the pull form.
-template <typename VT>
-__device__ __forceinline__ VT slot_sum(const VT* __restrict__ slots, int32_t nchild, int32_t f, int32_t j, VT v) {
+template <bool H = false, typename VT>
+__device__ __forceinline__ VT slot_sum(const VT* slots, int32_t nchild, int32_t f, int32_t j, VT v) {
     int32_t c = 0;
     for (; c + 3 < nchild; c += 4) {
-        const VT u0 = slots[(size_t)c * f + j], u1 = slots[(size_t)(c + 1) * f + j], u2 = slots[(size_t)(c + 2) * f + j], u3 = slots[(size_t)(c + 3) * f + j];
+        const VT u0 = ld_h<H>(slots + (size_t)c * f + j), u1 = ld_h<H>(slots + (size_t)(c + 1) * f + j), u2 = ld_h<H>(slots + (size_t)(c + 2) * f + j),
+                 u3 = ld_h<H>(slots + (size_t)(c + 3) * f + j);
         v = s_add(s_add(s_add(s_add(v, u0), u1), u2), u3);
     }
     VT u[3];
-    for (int q = 0; q < 3; ++q) u[q] = c + q < nchild ? slots[(size_t)(c + q) * f + j] : scalar_traits<VT>::zero();
+    for (int q = 0; q < 3; ++q) u[q] = c + q < nchild ? ld_h<H>(slots + (size_t)(c + q) * f + j) : scalar_traits<VT>::zero();
     for (int q = 0; q < 3; ++q)
         if (c + q < nchild) v = s_add(v, u[q]);
     return v;
 }
 
 // downward sweep: the value of front position j goes into the boundary vector of every child that has j in its boundary
-template <typename VT>
-__device__ __forceinline__ void push_down(const int32_t* __restrict__ ge, int32_t nchild, int32_t f, int32_t j, VT* __restrict__ xb, VT val) {
+template <bool H = false, typename VT>
+__device__ __forceinline__ void push_down(const int32_t* __restrict__ ge, int32_t nchild, int32_t f, int32_t j, VT* xb, VT val) {
     for (int32_t c = 0; c < nchild; ++c) {
         const int32_t g = ge[(size_t)c * f + j];
-        if (g >= 0) xb[g] = val;
+        if (g >= 0) st_h<H>(xb + g, val);
     }
 }
 
-// upward sweep, one tree level: workgroup (x = node of the level, y = tile of 512 / LPR rows of its packed L block);
-// LPR lanes run along a pair of rows: 16 (32 rows per workgroup) where the level has many tiles, 64 (8 rows) near the top
-// of the tree, where a few tall fronts must still be spread over the whole chip, 4 (128 rows) on levels of thin separators.
+// One tile of the upward sweep: 512 / LPR rows from r0 of node nd's packed L block.  LPR lanes run along a pair of rows: 16 (32
+// rows per workgroup) where the level has many tiles, 64 (8 rows) near the top of the tree, where a few tall fronts must still be
+// spread over the whole chip, 4 (128 rows) on levels of thin separators.
 // ORDERED: the vectors are in elimination order (own unknown r of the node = own0 + r), else through idx.
 // A root (no boundary) also starts the downward sweep: its rows are final, they go to its children's boundary vectors.
-template <typename MT, typename VT, int LPR, bool ORDERED, int NP = 1>
-__global__ __launch_bounds__(256) void nd_fwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ lfac,
-                                                     const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
-                                                     const int32_t* __restrict__ cmap, const VT* __restrict__ rhs, VT* __restrict__ x,
-                                                     VT* __restrict__ ubuf, VT* __restrict__ acc, VT* __restrict__ xb) {
-    // NP row pairs per sub-wave: NP * 512 / LPR rows per workgroup share one gather of the node's vector (NP = 1 everywhere:
-    // NP = 2 was measured on the widest level and does not pay)
-    __shared__ VT vs[kCH];
-    constexpr int ROWS = NP * 512 / LPR;
-    const NdNodeDev nd = lnodes[blockIdx.x];
-    const int32_t r0 = (int32_t)blockIdx.y * ROWS;
+// H: the children's contributions were written, and this tile's are read, by other workgroups of the SAME launch (chained
+// sweeps): `ready()` is called once everything that depends on the node record alone has been requested -- it returns when the
+// children are done (false: give up) -- and the hand-over data goes through ld_h / st_h.
+template <typename MT, typename VT, int LPR, bool ORDERED, bool H, typename Ready>
+__device__ __forceinline__ bool nd_fwd_tile(const NdSweepNode& nd, int32_t r0, VT* vs, const MT* __restrict__ lfac, const int32_t* __restrict__ idx,
+                                            const int32_t* __restrict__ gell, const int32_t* __restrict__ cmap, const VT* __restrict__ rhs, VT* x,
+                                            VT* ubuf, VT* acc, VT* xb, Ready ready) {
     const int32_t m = nd.m, f = nd.f;
     // rows of the packed L on this rank: its own rows of the inverse, then its boundary rows (m and f - m of them unless the node
     // is distributed: then orows rows from orow0 and brow rows from brow0)
     const int32_t mr = nd.orows, floc = mr + nd.brow;
-    if (r0 >= floc) return;
     const int32_t* ix = idx + nd.idx_off;
     const int32_t* ge = gell + nd.ge_off;
     const MT* L = lfac + nd.lfac_off;
     const int tid = threadIdx.x, sw = tid / LPR, sl = tid % LPR;
-    int32_t ra[NP], rb[NP];
-    const MT *La[NP], *Lb[NP];
-    VT acc0[NP], acc1[NP];
-    // everything that depends only on the node record is requested first: the head of the rows, what the children added to
-    // the update entries these rows produce, where those entries go
-    MT pa[NP][4], pb[NP][4];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        ra[p] = r0 + sw + p * (512 / LPR);
-        rb[p] = ra[p] + 256 / LPR;
-        La[p] = L + (size_t)min(ra[p], floc - 1) * m;
-        Lb[p] = L + (size_t)min(rb[p], floc - 1) * m;
-        acc0[p] = scalar_traits<VT>::zero();
-        acc1[p] = scalar_traits<VT>::zero();
-        row_pair_prefetch<LPR>(La[p], Lb[p], min(kCH, m), sl, pa[p], pb[p]);
-    }
+    const int32_t ra = r0 + sw, rb = ra + 256 / LPR;
+    const MT* La = L + (size_t)min(ra, floc - 1) * m;
+    const MT* Lb = L + (size_t)min(rb, floc - 1) * m;
+    VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
+    // everything that depends only on the node record is requested first: the head of the rows, where the update entries go
+    MT pa[4], pb[4];
+    row_pair_prefetch<LPR>(La, Lb, min(kCH, m), sl, pa, pb);
     const bool push = nd.acc_off >= 0;
     const VT* slots = acc + (push ? nd.acc_off : 0);
-    VT ua[NP], ub[NP];
-    int32_t ca[NP], cb[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        ua[p] = scalar_traits<VT>::zero();
-        ub[p] = scalar_traits<VT>::zero();
-        ca[p] = cb[p] = 0;
-        if (sl == 0) {
-            // (front position of local row r >= mr: m + brow0 + r - mr)
-            if (ra[p] >= mr && ra[p] < floc) {
-                const int32_t jg = m + nd.brow0 + ra[p] - mr;
-                ua[p] = push ? slot_sum(slots, nd.nchild, f, jg, ua[p]) : gather_updates(ge, nd.nchild, f, jg, ubuf, ua[p]);
-                if (nd.pacc_off >= 0) ca[p] = cmap[nd.cmap_off + ra[p] - mr];
-            }
-            if (rb[p] >= mr && rb[p] < floc) {
-                const int32_t jg = m + nd.brow0 + rb[p] - mr;
-                ub[p] = push ? slot_sum(slots, nd.nchild, f, jg, ub[p]) : gather_updates(ge, nd.nchild, f, jg, ubuf, ub[p]);
-                if (nd.pacc_off >= 0) cb[p] = cmap[nd.cmap_off + rb[p] - mr];
-            }
+    int32_t ca = 0, cb = 0;
+    if (sl == 0 && nd.pacc_off >= 0) {
+        if (ra >= mr && ra < floc) ca = cmap[nd.cmap_off + ra - mr];
+        if (rb >= mr && rb < floc) cb = cmap[nd.cmap_off + rb - mr];
+    }
+    if (!ready()) return false;
+    // ... then what the children added to the update entries these rows produce (front position of local row r >= mr: m + brow0 + r - mr)
+    VT ua = scalar_traits<VT>::zero(), ub = scalar_traits<VT>::zero();
+    if (sl == 0) {
+        if (ra >= mr && ra < floc) {
+            const int32_t jg = m + nd.brow0 + ra - mr;
+            ua = push ? slot_sum<H>(slots, nd.nchild, f, jg, ua) : gather_updates(ge, nd.nchild, f, jg, (const VT*)ubuf, ua);
+        }
+        if (rb >= mr && rb < floc) {
+            const int32_t jg = m + nd.brow0 + rb - mr;
+            ub = push ? slot_sum<H>(slots, nd.nchild, f, jg, ub) : gather_updates(ge, nd.nchild, f, jg, (const VT*)ubuf, ub);
         }
     }
     for (int32_t c0 = 0; c0 < m; c0 += kCH) {
         const int32_t cn = min(kCH, m - c0);
         for (int32_t j = tid; j < cn; j += 256) {
             const VT v = rhs[ORDERED ? nd.own0 + c0 + j : ix[c0 + j]];
-            vs[j] = push ? slot_sum(slots, nd.nchild, f, c0 + j, v) : gather_updates(ge, nd.nchild, f, c0 + j, ubuf, v);
+            vs[j] = push ? slot_sum<H>(slots, nd.nchild, f, c0 + j, v) : gather_updates(ge, nd.nchild, f, c0 + j, (const VT*)ubuf, v);
         }
         __syncthreads();
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            if (c0 == 0) two_row_dot_prefetched<LPR>(La[p], Lb[p], vs, cn, sl, acc0[p], acc1[p], pa[p], pb[p]);
-            else two_row_dot<LPR>(La[p] + c0, Lb[p] + c0, vs, cn, sl, acc0[p], acc1[p]);
-        }
+        if (c0 == 0) two_row_dot_prefetched<LPR>(La, Lb, vs, cn, sl, acc0, acc1, pa, pb);
+        else two_row_dot<LPR>(La + c0, Lb + c0, vs, cn, sl, acc0, acc1);
         __syncthreads();
     }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const VT s0 = lanes_sum<LPR>(acc0[p]), s1 = lanes_sum<LPR>(acc1[p]);
-        if (sl == 0) {
-            const bool root_push = f == m && !(nd.flags & 1);
-            if (ra[p] < mr) {
-                x[ORDERED ? nd.own0 + nd.orow0 + ra[p] : ix[nd.orow0 + ra[p]]] = s0;
-                if (root_push) push_down(ge, nd.nchild, f, ra[p], xb, s0);
-            } else if (ra[p] < floc) {
-                const VT u = s_add(ua[p], s0);
-                if (nd.pacc_off >= 0) acc[nd.pacc_off + ca[p]] = u;
-                else ubuf[nd.u_off + (ra[p] - mr)] = u;
-            }
-            if (rb[p] < mr) {
-                x[ORDERED ? nd.own0 + nd.orow0 + rb[p] : ix[nd.orow0 + rb[p]]] = s1;
-                if (root_push) push_down(ge, nd.nchild, f, rb[p], xb, s1);
-            } else if (rb[p] < floc) {
-                const VT u = s_add(ub[p], s1);
-                if (nd.pacc_off >= 0) acc[nd.pacc_off + cb[p]] = u;
-                else ubuf[nd.u_off + (rb[p] - mr)] = u;
-            }
+    const VT s0 = lanes_sum<LPR>(acc0), s1 = lanes_sum<LPR>(acc1);
+    if (sl == 0) {
+        const bool root_push = f == m && !(nd.flags & 1);
+        if (ra < mr) {
+            st_h<H>(x + (ORDERED ? nd.own0 + nd.orow0 + ra : ix[nd.orow0 + ra]), s0);
+            if (root_push) push_down<H>(ge, nd.nchild, f, ra, xb, s0);
+        } else if (ra < floc) {
+            const VT u = s_add(ua, s0);
+            if (nd.pacc_off >= 0) st_h<H>(acc + nd.pacc_off + ca, u);
+            else ubuf[nd.u_off + (ra - mr)] = u;
+        }
+        if (rb < mr) {
+            st_h<H>(x + (ORDERED ? nd.own0 + nd.orow0 + rb : ix[nd.orow0 + rb]), s1);
+            if (root_push) push_down<H>(ge, nd.nchild, f, rb, xb, s1);
+        } else if (rb < floc) {
+            const VT u = s_add(ub, s1);
+            if (nd.pacc_off >= 0) st_h<H>(acc + nd.pacc_off + cb, u);
+            else ubuf[nd.u_off + (rb - mr)] = u;
         }
     }
+    return true;
 }
 
-// downward sweep, one tree level: x[own] -= U x[boundary]; the boundary vector was filled by the ancestors' launches, and this
-// launch fills the children's: the rows it finishes, and (split over the node's tiles) the boundary entries it received
+// upward sweep, one tree level: workgroup (x = node of the level, y = tile of 512 / LPR rows of its packed L block)
 template <typename MT, typename VT, int LPR, bool ORDERED>
-__global__ __launch_bounds__(256) void nd_bwd_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ ufac,
-                                                     const int32_t* __restrict__ idx, const int32_t* __restrict__ gell, VT* __restrict__ x,
-                                                     VT* __restrict__ xb) {
+__global__ __launch_bounds__(256) void nd_fwd_kernel(const NdSweepNode* __restrict__ lnodes, const MT* __restrict__ lfac,
+                                                     const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
+                                                     const int32_t* __restrict__ cmap, const VT* __restrict__ rhs, VT* __restrict__ x,
+                                                     VT* __restrict__ ubuf, VT* __restrict__ acc, VT* __restrict__ xb) {
     __shared__ VT vs[kCH];
+    const NdSweepNode nd = lnodes[blockIdx.x];
+    const int32_t r0 = (int32_t)blockIdx.y * (512 / LPR);
+    if (r0 >= nd.orows + nd.brow) return;
+    (void)nd_fwd_tile<MT, VT, LPR, ORDERED, false>(nd, r0, vs, lfac, idx, gell, cmap, rhs, x, ubuf, acc, xb, [] { return true; });
+}
+
+// One tile of the downward sweep: x[own] -= U x[boundary] for 512 / LPR own rows from r0; the boundary vector was filled by the
+// ancestors, and this tile fills the children's: the rows it finishes, and (tile `ty` of the node's `ntile`) its share of the
+// boundary entries the node received.  H / ready: as in nd_fwd_tile (the producers are the parent's tiles).
+template <typename MT, typename VT, int LPR, bool ORDERED, bool H, typename Ready>
+__device__ __forceinline__ bool nd_bwd_tile(const NdSweepNode& nd, int32_t r0, int32_t ty, VT* vs, const MT* __restrict__ ufac,
+                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ gell, VT* x, VT* xb, Ready ready) {
     constexpr int ROWS = 512 / LPR;
-    const NdNodeDev nd = lnodes[blockIdx.x];
-    const int32_t r0 = (int32_t)blockIdx.y * ROWS;
     const int32_t m = nd.m, f = nd.f, b = f - m;
-    if (r0 >= m || b == 0) return;
     const int32_t* ix = idx + nd.idx_off;
     const int32_t* ge = gell + nd.ge_off;
     const MT* U = ufac + nd.ufac_off;
@@ -1321,15 +1349,16 @@ __global__ __launch_bounds__(256) void nd_bwd_kernel(const NdNodeDev* __restrict
     const int32_t ra = r0 + sw, rb = r0 + sw + 256 / LPR;
     const MT* Ua = U + (size_t)min(ra, m - 1) * b;
     const MT* Ub = U + (size_t)min(rb, m - 1) * b;
-    // the rows' own entries are needed only at the end: issue their loads before the sweep over the boundary
     const int32_t ia = ORDERED ? nd.own0 + min(ra, m - 1) : ix[min(ra, m - 1)], ib = ORDERED ? nd.own0 + min(rb, m - 1) : ix[min(rb, m - 1)];
-    const VT xa = x[ia], xc = x[ib];
-    VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
     MT pa[4], pb[4];
     row_pair_prefetch<LPR>(Ua, Ub, min(kCH, b), sl, pa, pb);
+    if (!ready()) return false;
+    // the rows' own entries are needed only at the end: issue their loads before the sweep over the boundary
+    const VT xa = ld_h<H>(x + ia), xc = ld_h<H>(x + ib);
+    VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
     for (int32_t c0 = 0; c0 < b; c0 += kCH) {
         const int32_t cn = min(kCH, b - c0);
-        for (int32_t j = tid; j < cn; j += 256) vs[j] = bv[c0 + j];
+        for (int32_t j = tid; j < cn; j += 256) vs[j] = ld_h<H>(bv + c0 + j);
         __syncthreads();
         if (c0 == 0) two_row_dot_prefetched<LPR>(Ua, Ub, vs, cn, sl, acc0, acc1, pa, pb);
         else two_row_dot<LPR>(Ua + c0, Ub + c0, vs, cn, sl, acc0, acc1);
@@ -1341,22 +1370,115 @@ __global__ __launch_bounds__(256) void nd_bwd_kernel(const NdNodeDev* __restrict
         if (ra < m) {
             const VT v = s_sub(xa, acc0);
             x[ia] = v;
-            push_down(ge, nd.nchild, f, ra, xb, v);
+            push_down<H>(ge, nd.nchild, f, ra, xb, v);
         }
         if (rb < m) {
             const VT v = s_sub(xc, acc1);
             x[ib] = v;
-            push_down(ge, nd.nchild, f, rb, xb, v);
+            push_down<H>(ge, nd.nchild, f, rb, xb, v);
         }
     }
     if (nd.nchild > 0) {  // the boundary entries this node received, handed on to the children whose boundaries hold them
         const int32_t ntile = (m + ROWS - 1) / ROWS;
         const int64_t total = (int64_t)nd.nchild * b;
-        for (int64_t e = (int64_t)blockIdx.y * 256 + tid; e < total; e += (int64_t)ntile * 256) {
+        for (int64_t e = (int64_t)ty * 256 + tid; e < total; e += (int64_t)ntile * 256) {
             const int32_t c = (int32_t)(e / b), j = (int32_t)(e - (int64_t)c * b);
             const int32_t g = ge[(size_t)c * f + m + j];
-            if (g >= 0) xb[g] = bv[j];
+            if (g >= 0) st_h<H>(xb + g, ld_h<H>(bv + j));
         }
+    }
+    return true;
+}
+
+// downward sweep, one tree level
+template <typename MT, typename VT, int LPR, bool ORDERED>
+__global__ __launch_bounds__(256) void nd_bwd_kernel(const NdSweepNode* __restrict__ lnodes, const MT* __restrict__ ufac,
+                                                     const int32_t* __restrict__ idx, const int32_t* __restrict__ gell, VT* __restrict__ x,
+                                                     VT* __restrict__ xb) {
+    __shared__ VT vs[kCH];
+    const NdSweepNode nd = lnodes[blockIdx.x];
+    const int32_t r0 = (int32_t)blockIdx.y * (512 / LPR);
+    if (r0 >= nd.m || nd.f == nd.m) return;
+    (void)nd_bwd_tile<MT, VT, LPR, ORDERED, false>(nd, r0, (int32_t)blockIdx.y, vs, ufac, idx, gell, x, xb, [] { return true; });
+}
+
+// ---- chained sweeps: the top levels of the forest in ONE launch per direction ------------------------------------------------
+// Near the top of the tree a level is a handful of small tiles; as a launch of its own it costs ~7 us whatever it computes (its
+// chain of dependent loads plus the dispatch of a dependent kernel), and a 30 k-unknown solve is 184 applies x 11 such levels.
+// Here the tiles of all those levels form ONE persistent launch: at most one workgroup per CU (all resident at once), tile i is
+// worked by workgroup i mod G, tiles are listed level by level -- so a tile only ever waits for tiles listed before it, which
+// are done or in the hands of a running workgroup.  A node's tiles add 1 to the node's counter when their stores have drained;
+// a consumer polls the counters of the nodes it depends on (its children going up, its parent going down) against epoch x tiles
+// (the counters are never reset: the epoch counts the applies).  Hand-over data (slot rows, boundary vectors, the chain's own x
+// entries) is stored and loaded with agent-scope relaxed atomics = `sc1` accesses, the form of MI355X_MICROARCH.md's table of
+// valid hand-offs: every storing wave waits for its stores, the workgroup meets at a barrier, ONE lane signals with an
+// agent-scope atomic add; ONE wave polls, the others load behind a barrier.  Waits are bounded: a wait that expires sets the
+// abort word, every tile still to come sees it and returns, and the host reports LSA_ERR_TIMEOUT instead of hanging.
+// Same arithmetic in the same order as the one-launch-per-level sweeps: bitwise the same x (tests/test_gpu_ndlu.py).
+struct NdChainTile {
+    int32_t q;       // position of the node's record in the level-ordered sweep records
+    int32_t ty;      // tile of the node
+    int32_t node;    // node id (counter, children)
+    int32_t parent;  // parent's node id, or -1
+};
+constexpr uint32_t kChainMaxSpins = 1u << 24;  // ~ 10 s of polling
+
+__device__ __forceinline__ bool chain_wait(const uint32_t* cnt, uint32_t target, int32_t* abort_word) {
+    for (uint32_t spins = 0;; ++spins) {
+        const uint32_t have = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int32_t)(have - target) >= 0) return true;
+        if ((spins & 255u) == 255u) {
+            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+            if (spins > kChainMaxSpins) {
+                __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+template <typename MT, typename VT, bool ORDERED, bool DOWN>
+__global__ __launch_bounds__(256) void nd_chain_kernel(const NdChainTile* __restrict__ tiles, int32_t ntiles, const NdSweepNode* __restrict__ lnodes,
+                                                       const int32_t* __restrict__ child_ptr, const int32_t* __restrict__ child_idx,
+                                                       const uint32_t* __restrict__ tiles_up, const uint32_t* __restrict__ tiles_dn, uint32_t* cnt_up,
+                                                       uint32_t* cnt_dn, uint32_t epoch, int32_t* abort_word, const MT* __restrict__ fac,
+                                                       const int32_t* __restrict__ idx, const int32_t* __restrict__ gell, const int32_t* __restrict__ cmap,
+                                                       const VT* __restrict__ rhs, VT* x, VT* ubuf, VT* acc, VT* xb) {
+    __shared__ VT vs[kCH];
+    __shared__ int ok_s;
+    for (int32_t ti = (int32_t)blockIdx.x; ti < ntiles; ti += (int32_t)gridDim.x) {
+        const NdChainTile te = tiles[ti];
+        const NdSweepNode nd = lnodes[te.q];
+        auto ready = [&]() -> bool {
+            if (threadIdx.x < 64) {  // ONE wave polls
+                bool ok = true;
+                if constexpr (!DOWN) {
+                    // children worked by this launch (the others were finished by earlier launches: tiles_up == 0)
+                    for (int32_t cp = child_ptr[te.node] + (int32_t)threadIdx.x; cp < child_ptr[te.node + 1]; cp += 64) {
+                        const int32_t c = child_idx[cp];
+                        const uint32_t nt = tiles_up[c];
+                        if (nt != 0) ok = chain_wait(cnt_up + c, epoch * nt, abort_word) && ok;
+                    }
+                } else if (threadIdx.x == 0 && te.parent >= 0) {
+                    // the parent's downward tiles; a root has none: its upward tiles (an earlier launch) fed this node
+                    const uint32_t nt = tiles_dn[te.parent];
+                    if (nt != 0) ok = chain_wait(cnt_dn + te.parent, epoch * nt, abort_word);
+                }
+                ok = __all(ok) != 0;
+                if (threadIdx.x == 0) ok_s = ok ? 1 : 0;
+            }
+            __syncthreads();
+            return ok_s != 0;
+        };
+        bool fine;
+        if constexpr (!DOWN) fine = nd_fwd_tile<MT, VT, 64, ORDERED, true>(nd, te.ty * 8, vs, fac, idx, gell, cmap, rhs, x, ubuf, acc, xb, ready);
+        else fine = nd_bwd_tile<MT, VT, 64, ORDERED, true>(nd, te.ty * 8, te.ty, vs, fac, idx, gell, x, xb, ready);
+        if (!fine) return;  // (uniform: ok_s is read by every thread behind the barrier)
+        // publish: every storing wave waits for its stores, all meet, one lane signals
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add((DOWN ? cnt_dn : cnt_up) + te.node, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1414,12 +1536,12 @@ __device__ __forceinline__ MT maybe_conj(MT a) {
 }
 
 template <typename MT, typename VT, bool CONJ, bool DOWN>
-__global__ __launch_bounds__(256) void nd_sweepT_kernel(const NdNodeDev* __restrict__ lnodes, const MT* __restrict__ lfac, const MT* __restrict__ ufac,
+__global__ __launch_bounds__(256) void nd_sweepT_kernel(const NdSweepNode* __restrict__ lnodes, const MT* __restrict__ lfac, const MT* __restrict__ ufac,
                                                         const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
                                                         const VT* __restrict__ rhs, VT* __restrict__ x, VT* __restrict__ ubuf) {
     __shared__ VT vs[kCH];
     __shared__ VT part[4][64];
-    const NdNodeDev nd = lnodes[blockIdx.x];
+    const NdSweepNode nd = lnodes[blockIdx.x];
     const int32_t m = nd.m, f = nd.f, b = f - m;
     const int32_t ncols = DOWN ? m : f;       // outputs of this sweep
     const int32_t K = DOWN ? b : m;           // rows summed over
@@ -1475,11 +1597,19 @@ struct lsa_ndlu {
     bool ordered = false;           // the matrix came in elimination order: own unknown r of a node is own0 + r
     std::vector<NdChunk> chunks;    // factorisation order
     std::vector<NdLevel> levels;    // sweep order
-    NdNodeDev *d_nodes = nullptr, *d_lnodes = nullptr;  // by node id / in lvl_nodes order
-    NdNodeDev* d_lnodes_bwd = nullptr;                  // in lvl_nodes order, for the downward sweep: a distributed node appears as its slice of own rows
+    NdNodeDev* d_nodes = nullptr;                        // by node id (factorisation, exchange kernels of the sweeps)
+    NdSweepNode *d_lnodes = nullptr, *d_lnodes_bwd = nullptr;  // in lvl_nodes order: the sweeps' records (downwards a distributed node appears as its slice of own rows)
     int32_t *d_dist_nodes = nullptr, *d_child_ptr = nullptr, *d_child_idx = nullptr;  // distributed nodes by level; children of every node
     void *d_xstage = nullptr, *d_xg = nullptr;          // staging of update rows on their way to distributed parents; own-row exchange buffer of the sweeps
     int64_t xstage_slot = 0;                            // scalars per rank of d_xstage
+    // chained sweeps (nd_chain_kernel): the levels [chain_first, nlevels) in one launch per direction
+    int32_t chain_first = -1;                           // -1: every level is a launch of its own
+    int32_t chain_up_tiles = 0, chain_dn_tiles = 0;
+    NdChainTile *d_chain_up = nullptr, *d_chain_dn = nullptr;
+    uint32_t *d_chain_tiles_up = nullptr, *d_chain_tiles_dn = nullptr, *d_chain_cnt = nullptr;  // per node: tiles per direction; counters (up, then down)
+    int32_t* d_chain_abort = nullptr;
+    uint32_t chain_epoch = 0;
+    bool chain_dirty = false;                           // an apply was queued since the abort word was last read
     std::vector<int64_t> h_upd_off;                     // per node: its update matrix in the update arena (host copy of the plan)
     int64_t chunk_node_upd_off(int32_t t) const { return h_upd_off[(size_t)t]; }
     int32_t* d_gell = nullptr;
@@ -1512,6 +1642,8 @@ namespace {
 
 void nd_free(lsa_ndlu* f) {
     if (!f) return;
+    for (void* p : {(void*)f->d_chain_up, (void*)f->d_chain_dn, (void*)f->d_chain_tiles_up, (void*)f->d_chain_tiles_dn, (void*)f->d_chain_cnt, (void*)f->d_chain_abort})
+        if (p) (void)hipFree(p);
     for (void* p : {(void*)f->d_lnodes_bwd, (void*)f->d_dist_nodes, (void*)f->d_child_ptr, (void*)f->d_child_idx, f->d_xstage, f->d_xg})
         if (p) (void)hipFree(p);
     for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
@@ -1818,14 +1950,14 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         // the sweeps' records, in level order.  A distributed node differs from its factorisation record: upwards its update
         // entries go to its rank's slot of the level's exchange region; downwards it appears as its slice of the own rows (the
         // pushes to its children are nd_dist_unpack_kernel's, after the exchange)
-        std::vector<NdNodeDev> lnodes(S.lvl_nodes.size()), bnodes(S.lvl_nodes.size());
+        std::vector<NdSweepNode> lnodes(S.lvl_nodes.size()), bnodes(S.lvl_nodes.size());
         std::vector<int32_t> dist_nodes;
         for (size_t q = 0; q < S.lvl_nodes.size(); ++q) {
             const int32_t t = S.lvl_nodes[q];
-            lnodes[q] = bnodes[q] = nodes[(size_t)t];
+            lnodes[q] = bnodes[q] = NdSweepNode(nodes[(size_t)t]);
             if (S.kind[(size_t)t] != 4) continue;
             lnodes[q].u_off = S.ux_base[(size_t)t] + (int64_t)S.rank * S.ux_stride[(size_t)t];
-            NdNodeDev& bn = bnodes[q];
+            NdSweepNode& bn = bnodes[q];
             const int32_t b = bn.f - bn.m;
             bn.idx_off += bn.orow0;
             bn.own0 += bn.orow0;
@@ -1862,6 +1994,55 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         LSA_CHECK(upload(ctx, S.child_idx, &f->d_child_idx));
         if (f->xstage_slot > 0) LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_xstage, (size_t)f->xstage_slot * (size_t)S.nranks * es));
         if (S.xg_entries > 0) LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_xg, (size_t)S.xg_entries * 16));
+    }
+    // ---- chained sweeps: the run of 8-row-tile levels at the top of the tree, one launch per direction (one rank only: the
+    // levels of a forest cut over ranks are separated by exchanges) ----
+    {
+        f->chain_first = -1;
+        const char* ce = getenv("LSA_ND_CHAIN");
+        const bool want = !(ce && *ce && atoi(ce) == 0);
+        int32_t first = S.nlevels;
+        while (first > 1 && f->levels[(size_t)first - 1].sweep_rows == 8) --first;
+        if (want && S.nranks == 1 && S.nlevels - first >= 2) {
+            std::vector<NdChainTile> up, dn;
+            std::vector<uint32_t> tiles_up((size_t)nt, 0), tiles_dn((size_t)nt, 0);
+            bool all_push = true;
+            for (int32_t l = first; l < S.nlevels; ++l) {
+                const NdLevel& L = f->levels[(size_t)l];
+                for (int32_t q = 0; q < L.node_count; ++q) {
+                    const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+                    const int32_t nchild = S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t];
+                    all_push = all_push && (nchild == 0 || nodes[(size_t)t].acc_off >= 0) && (S.parent[(size_t)t] < 0 || nodes[(size_t)t].pacc_off >= 0);
+                    const int32_t nup = (S.f[(size_t)t] + 7) / 8;
+                    tiles_up[(size_t)t] = (uint32_t)nup;
+                    for (int32_t ty = 0; ty < nup; ++ty) up.push_back(NdChainTile{L.node_begin + q, ty, t, S.parent[(size_t)t]});
+                }
+            }
+            for (int32_t l = S.nlevels - 1; l >= first; --l) {
+                const NdLevel& L = f->levels[(size_t)l];
+                for (int32_t q = 0; q < L.node_count; ++q) {
+                    const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+                    if (S.f[(size_t)t] == S.m[(size_t)t]) continue;  // a root: nothing to do on the way down
+                    const int32_t ndn = (S.m[(size_t)t] + 7) / 8;
+                    tiles_dn[(size_t)t] = (uint32_t)ndn;
+                    for (int32_t ty = 0; ty < ndn; ++ty) dn.push_back(NdChainTile{L.node_begin + q, ty, t, S.parent[(size_t)t]});
+                }
+            }
+            if (all_push && !up.empty()) {
+                f->chain_first = first;
+                f->chain_up_tiles = (int32_t)up.size();
+                f->chain_dn_tiles = (int32_t)dn.size();
+                LSA_CHECK(upload(ctx, up, &f->d_chain_up));
+                LSA_CHECK(upload(ctx, dn, &f->d_chain_dn));
+                LSA_CHECK(upload(ctx, tiles_up, &f->d_chain_tiles_up));
+                LSA_CHECK(upload(ctx, tiles_dn, &f->d_chain_tiles_dn));
+                LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_chain_cnt, 2 * (size_t)std::max(nt, 1) * sizeof(uint32_t)));
+                LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_chain_abort, 4 * sizeof(int32_t)));
+                LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_chain_cnt, 0, 2 * (size_t)std::max(nt, 1) * sizeof(uint32_t), ctx->stream));
+                LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_chain_abort, 0, 4 * sizeof(int32_t), ctx->stream));
+                f->chain_epoch = 0;
+            }
+        }
     }
     LSA_CHECK(upload(ctx, S.gell, &f->d_gell));
     LSA_CHECK(upload(ctx, S.idx, &f->d_idx));
@@ -1904,7 +2085,12 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         }
     }
     f->solve_launches = 0;
-    for (const NdLevel& L : f->levels) f->solve_launches += (L.fwd_tiles > 0) + (L.bwd_tiles > 0);
+    for (int32_t l = 0; l < S.nlevels; ++l) {
+        const NdLevel& L = f->levels[(size_t)l];
+        if (f->chain_first >= 0 && l >= f->chain_first) continue;
+        f->solve_launches += (L.fwd_tiles > 0) + (L.bwd_tiles > 0);
+    }
+    if (f->chain_first >= 0) f->solve_launches += (f->chain_up_tiles > 0) + (f->chain_dn_tiles > 0);
     return LSA_OK;
 }
 
@@ -2199,10 +2385,24 @@ int nd_apply_ordered(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
         // subtree-parallel: the update vectors of all ranks' subtree roots, before the replicated top of the tree
         if ((int32_t)li == S.phase_b_level && S.nranks > 1 && S.xu_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, f->d_ubuf, (size_t)S.xu_slot * sizeof(VT)));
         if (li == f->levels.size()) break;
+        if (f->chain_first >= 0 && (int32_t)li >= f->chain_first) {
+            // the top levels in one launch (nd_chain_kernel): at most one workgroup per CU, all resident
+            if ((int32_t)li == f->chain_first && f->chain_up_tiles > 0) {
+                ++f->chain_epoch;
+                f->chain_dirty = true;
+                uint32_t* cnt = f->d_chain_cnt;
+                hipLaunchKernelGGL((nd_chain_kernel<MT, VT, ORDERED, false>), dim3(std::min(f->chain_up_tiles, ctx->num_cu)), dim3(256), 0, st,
+                                   (const NdChainTile*)f->d_chain_up, f->chain_up_tiles, (const NdSweepNode*)f->d_lnodes, (const int32_t*)f->d_child_ptr,
+                                   (const int32_t*)f->d_child_idx, (const uint32_t*)f->d_chain_tiles_up, (const uint32_t*)f->d_chain_tiles_dn, cnt,
+                                   cnt + S.nt, f->chain_epoch, f->d_chain_abort, lfac, (const int32_t*)f->d_idx, (const int32_t*)f->d_gell,
+                                   (const int32_t*)f->d_cmap, b, x, ubuf, acc, xb);
+            }
+            continue;
+        }
         const NdLevel& L = f->levels[li];
         if (L.fwd_tiles > 0) {
             const dim3 grid(L.node_count, L.fwd_tiles);
-            const NdNodeDev* ln = f->d_lnodes + L.node_begin;
+            const NdSweepNode* ln = f->d_lnodes + L.node_begin;
             if (L.sweep_rows == 8)
                 hipLaunchKernelGGL((nd_fwd_kernel<MT, VT, 64, ORDERED>), grid, dim3(256), 0, st, ln, lfac, f->d_idx, f->d_gell, f->d_cmap, b, x, ubuf, acc, xb);
             else if (L.sweep_rows == 128)
@@ -2213,11 +2413,20 @@ int nd_apply_ordered(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
         // distributed top nodes of the level: every rank produced its slice of their update entries
         if (L.dist_count > 0 && L.ux_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, ubuf + L.ux_base, (size_t)L.ux_slot * sizeof(VT)));
     }
+    if (f->chain_first >= 0 && f->chain_dn_tiles > 0) {
+        uint32_t* cnt = f->d_chain_cnt;
+        hipLaunchKernelGGL((nd_chain_kernel<MT, VT, ORDERED, true>), dim3(std::min(f->chain_dn_tiles, ctx->num_cu)), dim3(256), 0, st,
+                           (const NdChainTile*)f->d_chain_dn, f->chain_dn_tiles, (const NdSweepNode*)f->d_lnodes_bwd, (const int32_t*)f->d_child_ptr,
+                           (const int32_t*)f->d_child_idx, (const uint32_t*)f->d_chain_tiles_up, (const uint32_t*)f->d_chain_tiles_dn, cnt, cnt + S.nt,
+                           f->chain_epoch, f->d_chain_abort, ufac, (const int32_t*)f->d_idx, (const int32_t*)f->d_gell, (const int32_t*)f->d_cmap, b, x,
+                           ubuf, acc, xb);
+    }
     for (size_t l = f->levels.size(); l-- > 0;) {
+        if (f->chain_first >= 0 && (int32_t)l >= f->chain_first) continue;
         const NdLevel& L = f->levels[l];
         if (L.bwd_tiles > 0) {
             const dim3 grid(L.node_count, L.bwd_tiles);
-            const NdNodeDev* ln = f->d_lnodes_bwd + L.node_begin;
+            const NdSweepNode* ln = f->d_lnodes_bwd + L.node_begin;
             if (L.sweep_rows == 8) hipLaunchKernelGGL((nd_bwd_kernel<MT, VT, 64, ORDERED>), grid, dim3(256), 0, st, ln, ufac, f->d_idx, f->d_gell, x, xb);
             else hipLaunchKernelGGL((nd_bwd_kernel<MT, VT, 16, ORDERED>), grid, dim3(256), 0, st, ln, ufac, f->d_idx, f->d_gell, x, xb);
         }
@@ -2285,6 +2494,22 @@ int ndlu_solve_adjoint_dev(lsa_ctx* ctx, lsa_ndlu* f, int conj, int vdtype, cons
     if (f->dtype == LSA_C128) return conj ? nd_apply_T<cplx, cplx, true>(ctx, f, (const cplx*)b, (cplx*)x) : nd_apply_T<cplx, cplx, false>(ctx, f, (const cplx*)b, (cplx*)x);
     if (vdtype == LSA_C128) return nd_apply_T<double, cplx, false>(ctx, f, (const cplx*)b, (cplx*)x);  // real factors: C^H = C^T
     return nd_apply_T<double, double, false>(ctx, f, (const double*)b, (double*)x);
+}
+
+// The chained sweeps bound their waits; a wait that expired left the abort word set and x unfinished.  Called by whoever has
+// just synchronised with the stream: returns LSA_ERR_TIMEOUT once and puts the chain's state back in order.
+int ndlu_check_abort(lsa_ctx* ctx, lsa_ndlu* f) {
+    if (!f || f->chain_first < 0 || !f->chain_dirty) return LSA_OK;
+    f->chain_dirty = false;
+    int32_t h = 0;
+    LSA_HIP_CHECK(ctx, hipMemcpyAsync(&h, f->d_chain_abort, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (h == 0) return LSA_OK;
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_chain_cnt, 0, 2 * (size_t)std::max(f->S.nt, 1) * sizeof(uint32_t), ctx->stream));
+    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_chain_abort, 0, 4 * sizeof(int32_t), ctx->stream));
+    f->chain_epoch = 0;
+    return lsa_set_error(ctx, LSA_ERR_TIMEOUT, "lsa_ndlu: a dependency wait of the chained sweeps expired (the device was held by other work for seconds, "
+                                               "or a workgroup never became resident); LSA_ND_CHAIN=0 runs one launch per level");
 }
 
 // x = C^-1 b on device pointers (b and x distinct or identical: an aliased right-hand side is copied first)
@@ -2585,7 +2810,7 @@ int lsa_ndlu_solve(lsa_ctx* ctx, lsa_ndlu* f, const lsa_vec* b, lsa_vec* x) {
     if (b->n != f->S.n || x->n != f->S.n || b->dtype != x->dtype) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve: shape/dtype mismatch");
     LSA_CHECK(ndlu_solve_dev(ctx, f, b->dtype, b->d, x->d));
     LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return LSA_OK;
+    return ndlu_check_abort(ctx, f);
 }
 
 int lsa_ndlu_solve_adjoint(lsa_ctx* ctx, lsa_ndlu* f, int conj, const lsa_vec* b, lsa_vec* x) {
@@ -2606,7 +2831,7 @@ int lsa_ndlu_solve_time(lsa_ctx* ctx, lsa_ndlu* f, const lsa_vec* b, lsa_vec* x,
     float ms = 0.f;
     LSA_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_ms = (double)ms / iters;
-    return LSA_OK;
+    return ndlu_check_abort(ctx, f);
 }
 
 int lsa_ndlu_info(const lsa_ndlu* f, int32_t* ntree, int32_t* nlevels, int32_t* max_front, int64_t* factor_entries, int64_t* front_entries,

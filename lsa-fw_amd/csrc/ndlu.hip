@@ -1167,14 +1167,17 @@ __device__ __forceinline__ void two_row_dot_prefetched(const MT* __restrict__ Fa
 // agent-scope relaxed atomics, i.e. `sc1` accesses that go past the CU's L1 and the XCD's L2 (per-XCD L2s are not coherent with
 // each other: MI355X_MICROARCH.md, inter-workgroup visibility).  H = false: plain accesses (one launch per level: the kernel
 // boundary publishes everything).
+#ifndef LSA_CHAIN_SC1_LOADS
+#define LSA_CHAIN_SC1_LOADS 0  // 1: hand-over loads as agent-scope atomics instead of ONE acquire fence per tile + plain loads
+#endif
 template <bool H>
 __device__ __forceinline__ double ld_h(const double* p) {
-    if constexpr (H) return __longlong_as_double(__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if constexpr (H && LSA_CHAIN_SC1_LOADS) return __longlong_as_double(__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     else return *p;
 }
 template <bool H>
 __device__ __forceinline__ cplx ld_h(const cplx* p) {
-    if constexpr (H) return cplx{ld_h<true>(&p->re), ld_h<true>(&p->im)};
+    if constexpr (H && LSA_CHAIN_SC1_LOADS) return cplx{ld_h<true>(&p->re), ld_h<true>(&p->im)};
     else return *p;
 }
 template <bool H>
@@ -1434,7 +1437,6 @@ __device__ __forceinline__ bool chain_wait(const uint32_t* cnt, uint32_t target,
                 return false;
             }
         }
-        __builtin_amdgcn_s_sleep(1);
     }
 }
 
@@ -1467,6 +1469,12 @@ __global__ __launch_bounds__(256) void nd_chain_kernel(const NdChainTile* __rest
                 }
                 ok = __all(ok) != 0;
                 if (threadIdx.x == 0) ok_s = ok ? 1 : 0;
+#if !LSA_CHAIN_SC1_LOADS
+                // ONE agent-scope acquire after the polls (drops this CU's stale lines), its wait, then the barrier: every wave's
+                // plain loads of the hand-over data come behind it
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             }
             __syncthreads();
             return ok_s != 0;
@@ -2001,8 +2009,24 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         f->chain_first = -1;
         const char* ce = getenv("LSA_ND_CHAIN");
         const bool want = !(ce && *ce && atoi(ce) == 0);
+        // ... as far down as all its tiles fit the chip at once (LSA_ND_CHAIN_TILES per direction, default 4 workgroups per CU):
+        // a chain worked off by fewer workgroups than it has tiles serialises what a launch per level runs side by side
+        static const int64_t tile_budget = getenv("LSA_ND_CHAIN_TILES") ? atoll(getenv("LSA_ND_CHAIN_TILES")) : 4 * (int64_t)ctx->num_cu;
         int32_t first = S.nlevels;
-        while (first > 1 && f->levels[(size_t)first - 1].sweep_rows == 8) --first;
+        int64_t up_tiles = 0, dn_tiles = 0;
+        while (first > 1 && f->levels[(size_t)first - 1].sweep_rows == 8) {
+            const NdLevel& L = f->levels[(size_t)first - 1];
+            int64_t lu = 0, ld = 0;
+            for (int32_t q = 0; q < L.node_count; ++q) {
+                const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+                lu += (S.f[(size_t)t] + 7) / 8;
+                if (S.f[(size_t)t] > S.m[(size_t)t]) ld += (S.m[(size_t)t] + 7) / 8;
+            }
+            if (up_tiles + lu > tile_budget || dn_tiles + ld > tile_budget) break;
+            up_tiles += lu;
+            dn_tiles += ld;
+            --first;
+        }
         if (want && S.nranks == 1 && S.nlevels - first >= 2) {
             std::vector<NdChainTile> up, dn;
             std::vector<uint32_t> tiles_up((size_t)nt, 0), tiles_dn((size_t)nt, 0);
@@ -2391,7 +2415,7 @@ int nd_apply_ordered(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
                 ++f->chain_epoch;
                 f->chain_dirty = true;
                 uint32_t* cnt = f->d_chain_cnt;
-                hipLaunchKernelGGL((nd_chain_kernel<MT, VT, ORDERED, false>), dim3(std::min(f->chain_up_tiles, ctx->num_cu)), dim3(256), 0, st,
+                hipLaunchKernelGGL((nd_chain_kernel<MT, VT, ORDERED, false>), dim3(f->chain_up_tiles), dim3(256), 0, st,
                                    (const NdChainTile*)f->d_chain_up, f->chain_up_tiles, (const NdSweepNode*)f->d_lnodes, (const int32_t*)f->d_child_ptr,
                                    (const int32_t*)f->d_child_idx, (const uint32_t*)f->d_chain_tiles_up, (const uint32_t*)f->d_chain_tiles_dn, cnt,
                                    cnt + S.nt, f->chain_epoch, f->d_chain_abort, lfac, (const int32_t*)f->d_idx, (const int32_t*)f->d_gell,
@@ -2415,7 +2439,7 @@ int nd_apply_ordered(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
     }
     if (f->chain_first >= 0 && f->chain_dn_tiles > 0) {
         uint32_t* cnt = f->d_chain_cnt;
-        hipLaunchKernelGGL((nd_chain_kernel<MT, VT, ORDERED, true>), dim3(std::min(f->chain_dn_tiles, ctx->num_cu)), dim3(256), 0, st,
+        hipLaunchKernelGGL((nd_chain_kernel<MT, VT, ORDERED, true>), dim3(f->chain_dn_tiles), dim3(256), 0, st,
                            (const NdChainTile*)f->d_chain_dn, f->chain_dn_tiles, (const NdSweepNode*)f->d_lnodes_bwd, (const int32_t*)f->d_child_ptr,
                            (const int32_t*)f->d_child_idx, (const uint32_t*)f->d_chain_tiles_up, (const uint32_t*)f->d_chain_tiles_dn, cnt, cnt + S.nt,
                            f->chain_epoch, f->d_chain_abort, ufac, (const int32_t*)f->d_idx, (const int32_t*)f->d_gell, (const int32_t*)f->d_cmap, b, x,

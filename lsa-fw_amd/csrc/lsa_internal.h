@@ -271,4 +271,3 @@ void blk_release(lsa_ilu* pc);
 struct lsa_ndlu;
 int ndlu_solve_dev(lsa_ctx* ctx, lsa_ndlu* f, int vdtype, const void* b, void* x);
 int ndlu_solve_adjoint_dev(lsa_ctx* ctx, lsa_ndlu* f, int conj, int vdtype, const void* b, void* x);
-int ndlu_check_abort(lsa_ctx* ctx, lsa_ndlu* f);  // after a synchronisation: LSA_ERR_TIMEOUT if a bounded wait of the chained sweeps expired

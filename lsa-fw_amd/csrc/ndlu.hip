@@ -1163,36 +1163,6 @@ __device__ __forceinline__ void two_row_dot_prefetched(const MT* __restrict__ Fa
     if (cn > 4 * LPR) two_row_dot<LPR>(Fa + 4 * LPR, Fb + 4 * LPR, vs + 4 * LPR, cn - 4 * LPR, sl, acc0, acc1);
 }
 
-// Loads and stores of data that ANOTHER WORKGROUP OF THE SAME LAUNCH produces or consumes (the chained sweeps below): 8-byte
-// agent-scope relaxed atomics, i.e. `sc1` accesses that go past the CU's L1 and the XCD's L2 (per-XCD L2s are not coherent with
-// each other: MI355X_MICROARCH.md, inter-workgroup visibility).  H = false: plain accesses (one launch per level: the kernel
-// boundary publishes everything).
-#ifndef LSA_CHAIN_SC1_LOADS
-#define LSA_CHAIN_SC1_LOADS 0  // 1: hand-over loads as agent-scope atomics instead of ONE acquire fence per tile + plain loads
-#endif
-template <bool H>
-__device__ __forceinline__ double ld_h(const double* p) {
-    if constexpr (H && LSA_CHAIN_SC1_LOADS) return __longlong_as_double(__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    else return *p;
-}
-template <bool H>
-__device__ __forceinline__ cplx ld_h(const cplx* p) {
-    if constexpr (H && LSA_CHAIN_SC1_LOADS) return cplx{ld_h<true>(&p->re), ld_h<true>(&p->im)};
-    else return *p;
-}
-template <bool H>
-__device__ __forceinline__ void st_h(double* p, double v) {
-    if constexpr (H) __hip_atomic_store((long long*)p, __double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
-template <bool H>
-__device__ __forceinline__ void st_h(cplx* p, cplx v) {
-    if constexpr (H) {
-        st_h<true>(&p->re, v.re);
-        st_h<true>(&p->im, v.im);
-    } else *p = v;
-}
-
 // PULL form: sum of the children's update-vector entries that land on front position j, through the per-child gather rows
 // (fixed order: child rank).  Used where a child's vector arrives by all-gather (the replicated top of a forest cut over ranks)
 // and by the transposed sweeps.
@@ -1218,27 +1188,27 @@ __device__ __forceinline__ VT gather_updates(const int32_t* __restrict__ ge, int
 
 // PUSH form: the same sum from the node's slot rows (row c = what child c added to every front position; slots no child maps
 // to were zeroed once and are never written): contiguous loads, no index in between.  Same order of additions as the pull form.
-template <bool H = false, typename VT>
+template <typename VT>
 __device__ __forceinline__ VT slot_sum(const VT* slots, int32_t nchild, int32_t f, int32_t j, VT v) {
     int32_t c = 0;
     for (; c + 3 < nchild; c += 4) {
-        const VT u0 = ld_h<H>(slots + (size_t)c * f + j), u1 = ld_h<H>(slots + (size_t)(c + 1) * f + j), u2 = ld_h<H>(slots + (size_t)(c + 2) * f + j),
-                 u3 = ld_h<H>(slots + (size_t)(c + 3) * f + j);
+        const VT u0 = slots[(size_t)c * f + j], u1 = slots[(size_t)(c + 1) * f + j], u2 = slots[(size_t)(c + 2) * f + j],
+                 u3 = slots[(size_t)(c + 3) * f + j];
         v = s_add(s_add(s_add(s_add(v, u0), u1), u2), u3);
     }
     VT u[3];
-    for (int q = 0; q < 3; ++q) u[q] = c + q < nchild ? ld_h<H>(slots + (size_t)(c + q) * f + j) : scalar_traits<VT>::zero();
+    for (int q = 0; q < 3; ++q) u[q] = c + q < nchild ? slots[(size_t)(c + q) * f + j] : scalar_traits<VT>::zero();
     for (int q = 0; q < 3; ++q)
         if (c + q < nchild) v = s_add(v, u[q]);
     return v;
 }
 
 // downward sweep: the value of front position j goes into the boundary vector of every child that has j in its boundary
-template <bool H = false, typename VT>
+template <typename VT>
 __device__ __forceinline__ void push_down(const int32_t* __restrict__ ge, int32_t nchild, int32_t f, int32_t j, VT* xb, VT val) {
     for (int32_t c = 0; c < nchild; ++c) {
         const int32_t g = ge[(size_t)c * f + j];
-        if (g >= 0) st_h<H>(xb + g, val);
+        if (g >= 0) xb[g] = val;
     }
 }
 
@@ -1247,13 +1217,10 @@ __device__ __forceinline__ void push_down(const int32_t* __restrict__ ge, int32_
 // spread over the whole chip, 4 (128 rows) on levels of thin separators.
 // ORDERED: the vectors are in elimination order (own unknown r of the node = own0 + r), else through idx.
 // A root (no boundary) also starts the downward sweep: its rows are final, they go to its children's boundary vectors.
-// H: the children's contributions were written, and this tile's are read, by other workgroups of the SAME launch (chained
-// sweeps): `ready()` is called once everything that depends on the node record alone has been requested -- it returns when the
-// children are done (false: give up) -- and the hand-over data goes through ld_h / st_h.
-template <typename MT, typename VT, int LPR, bool ORDERED, bool H, typename Ready>
-__device__ __forceinline__ bool nd_fwd_tile(const NdSweepNode& nd, int32_t r0, VT* vs, const MT* __restrict__ lfac, const int32_t* __restrict__ idx,
+template <typename MT, typename VT, int LPR, bool ORDERED>
+__device__ __forceinline__ void nd_fwd_tile(const NdSweepNode& nd, int32_t r0, VT* vs, const MT* __restrict__ lfac, const int32_t* __restrict__ idx,
                                             const int32_t* __restrict__ gell, const int32_t* __restrict__ cmap, const VT* __restrict__ rhs, VT* x,
-                                            VT* ubuf, VT* acc, VT* xb, Ready ready) {
+                                            VT* ubuf, VT* acc, VT* xb) {
     const int32_t m = nd.m, f = nd.f;
     // rows of the packed L on this rank: its own rows of the inverse, then its boundary rows (m and f - m of them unless the node
     // is distributed: then orows rows from orow0 and brow rows from brow0)
@@ -1276,24 +1243,23 @@ __device__ __forceinline__ bool nd_fwd_tile(const NdSweepNode& nd, int32_t r0, V
         if (ra >= mr && ra < floc) ca = cmap[nd.cmap_off + ra - mr];
         if (rb >= mr && rb < floc) cb = cmap[nd.cmap_off + rb - mr];
     }
-    if (!ready()) return false;
     // ... then what the children added to the update entries these rows produce (front position of local row r >= mr: m + brow0 + r - mr)
     VT ua = scalar_traits<VT>::zero(), ub = scalar_traits<VT>::zero();
     if (sl == 0) {
         if (ra >= mr && ra < floc) {
             const int32_t jg = m + nd.brow0 + ra - mr;
-            ua = push ? slot_sum<H>(slots, nd.nchild, f, jg, ua) : gather_updates(ge, nd.nchild, f, jg, (const VT*)ubuf, ua);
+            ua = push ? slot_sum(slots, nd.nchild, f, jg, ua) : gather_updates(ge, nd.nchild, f, jg, (const VT*)ubuf, ua);
         }
         if (rb >= mr && rb < floc) {
             const int32_t jg = m + nd.brow0 + rb - mr;
-            ub = push ? slot_sum<H>(slots, nd.nchild, f, jg, ub) : gather_updates(ge, nd.nchild, f, jg, (const VT*)ubuf, ub);
+            ub = push ? slot_sum(slots, nd.nchild, f, jg, ub) : gather_updates(ge, nd.nchild, f, jg, (const VT*)ubuf, ub);
         }
     }
     for (int32_t c0 = 0; c0 < m; c0 += kCH) {
         const int32_t cn = min(kCH, m - c0);
         for (int32_t j = tid; j < cn; j += 256) {
             const VT v = rhs[ORDERED ? nd.own0 + c0 + j : ix[c0 + j]];
-            vs[j] = push ? slot_sum<H>(slots, nd.nchild, f, c0 + j, v) : gather_updates(ge, nd.nchild, f, c0 + j, (const VT*)ubuf, v);
+            vs[j] = push ? slot_sum(slots, nd.nchild, f, c0 + j, v) : gather_updates(ge, nd.nchild, f, c0 + j, (const VT*)ubuf, v);
         }
         __syncthreads();
         if (c0 == 0) two_row_dot_prefetched<LPR>(La, Lb, vs, cn, sl, acc0, acc1, pa, pb);
@@ -1304,23 +1270,22 @@ __device__ __forceinline__ bool nd_fwd_tile(const NdSweepNode& nd, int32_t r0, V
     if (sl == 0) {
         const bool root_push = f == m && !(nd.flags & 1);
         if (ra < mr) {
-            st_h<H>(x + (ORDERED ? nd.own0 + nd.orow0 + ra : ix[nd.orow0 + ra]), s0);
-            if (root_push) push_down<H>(ge, nd.nchild, f, ra, xb, s0);
+            x[ORDERED ? nd.own0 + nd.orow0 + ra : ix[nd.orow0 + ra]] = s0;
+            if (root_push) push_down(ge, nd.nchild, f, ra, xb, s0);
         } else if (ra < floc) {
             const VT u = s_add(ua, s0);
-            if (nd.pacc_off >= 0) st_h<H>(acc + nd.pacc_off + ca, u);
+            if (nd.pacc_off >= 0) acc[nd.pacc_off + ca] = u;
             else ubuf[nd.u_off + (ra - mr)] = u;
         }
         if (rb < mr) {
-            st_h<H>(x + (ORDERED ? nd.own0 + nd.orow0 + rb : ix[nd.orow0 + rb]), s1);
-            if (root_push) push_down<H>(ge, nd.nchild, f, rb, xb, s1);
+            x[ORDERED ? nd.own0 + nd.orow0 + rb : ix[nd.orow0 + rb]] = s1;
+            if (root_push) push_down(ge, nd.nchild, f, rb, xb, s1);
         } else if (rb < floc) {
             const VT u = s_add(ub, s1);
-            if (nd.pacc_off >= 0) st_h<H>(acc + nd.pacc_off + cb, u);
+            if (nd.pacc_off >= 0) acc[nd.pacc_off + cb] = u;
             else ubuf[nd.u_off + (rb - mr)] = u;
         }
     }
-    return true;
 }
 
 // upward sweep, one tree level: workgroup (x = node of the level, y = tile of 512 / LPR rows of its packed L block)
@@ -1333,15 +1298,15 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdSweepNode* __restri
     const NdSweepNode nd = lnodes[blockIdx.x];
     const int32_t r0 = (int32_t)blockIdx.y * (512 / LPR);
     if (r0 >= nd.orows + nd.brow) return;
-    (void)nd_fwd_tile<MT, VT, LPR, ORDERED, false>(nd, r0, vs, lfac, idx, gell, cmap, rhs, x, ubuf, acc, xb, [] { return true; });
+    nd_fwd_tile<MT, VT, LPR, ORDERED>(nd, r0, vs, lfac, idx, gell, cmap, rhs, x, ubuf, acc, xb);
 }
 
 // One tile of the downward sweep: x[own] -= U x[boundary] for 512 / LPR own rows from r0; the boundary vector was filled by the
 // ancestors, and this tile fills the children's: the rows it finishes, and (tile `ty` of the node's `ntile`) its share of the
-// boundary entries the node received.  H / ready: as in nd_fwd_tile (the producers are the parent's tiles).
-template <typename MT, typename VT, int LPR, bool ORDERED, bool H, typename Ready>
-__device__ __forceinline__ bool nd_bwd_tile(const NdSweepNode& nd, int32_t r0, int32_t ty, VT* vs, const MT* __restrict__ ufac,
-                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ gell, VT* x, VT* xb, Ready ready) {
+// boundary entries the node received.
+template <typename MT, typename VT, int LPR, bool ORDERED>
+__device__ __forceinline__ void nd_bwd_tile(const NdSweepNode& nd, int32_t r0, int32_t ty, VT* vs, const MT* __restrict__ ufac,
+                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ gell, VT* x, VT* xb) {
     constexpr int ROWS = 512 / LPR;
     const int32_t m = nd.m, f = nd.f, b = f - m;
     const int32_t* ix = idx + nd.idx_off;
@@ -1355,13 +1320,12 @@ __device__ __forceinline__ bool nd_bwd_tile(const NdSweepNode& nd, int32_t r0, i
     const int32_t ia = ORDERED ? nd.own0 + min(ra, m - 1) : ix[min(ra, m - 1)], ib = ORDERED ? nd.own0 + min(rb, m - 1) : ix[min(rb, m - 1)];
     MT pa[4], pb[4];
     row_pair_prefetch<LPR>(Ua, Ub, min(kCH, b), sl, pa, pb);
-    if (!ready()) return false;
     // the rows' own entries are needed only at the end: issue their loads before the sweep over the boundary
-    const VT xa = ld_h<H>(x + ia), xc = ld_h<H>(x + ib);
+    const VT xa = x[ia], xc = x[ib];
     VT acc0 = scalar_traits<VT>::zero(), acc1 = scalar_traits<VT>::zero();
     for (int32_t c0 = 0; c0 < b; c0 += kCH) {
         const int32_t cn = min(kCH, b - c0);
-        for (int32_t j = tid; j < cn; j += 256) vs[j] = ld_h<H>(bv + c0 + j);
+        for (int32_t j = tid; j < cn; j += 256) vs[j] = bv[c0 + j];
         __syncthreads();
         if (c0 == 0) two_row_dot_prefetched<LPR>(Ua, Ub, vs, cn, sl, acc0, acc1, pa, pb);
         else two_row_dot<LPR>(Ua + c0, Ub + c0, vs, cn, sl, acc0, acc1);
@@ -1373,12 +1337,12 @@ __device__ __forceinline__ bool nd_bwd_tile(const NdSweepNode& nd, int32_t r0, i
         if (ra < m) {
             const VT v = s_sub(xa, acc0);
             x[ia] = v;
-            push_down<H>(ge, nd.nchild, f, ra, xb, v);
+            push_down(ge, nd.nchild, f, ra, xb, v);
         }
         if (rb < m) {
             const VT v = s_sub(xc, acc1);
             x[ib] = v;
-            push_down<H>(ge, nd.nchild, f, rb, xb, v);
+            push_down(ge, nd.nchild, f, rb, xb, v);
         }
     }
     if (nd.nchild > 0) {  // the boundary entries this node received, handed on to the children whose boundaries hold them
@@ -1387,10 +1351,9 @@ __device__ __forceinline__ bool nd_bwd_tile(const NdSweepNode& nd, int32_t r0, i
         for (int64_t e = (int64_t)ty * 256 + tid; e < total; e += (int64_t)ntile * 256) {
             const int32_t c = (int32_t)(e / b), j = (int32_t)(e - (int64_t)c * b);
             const int32_t g = ge[(size_t)c * f + m + j];
-            if (g >= 0) st_h<H>(xb + g, ld_h<H>(bv + j));
+            if (g >= 0) xb[g] = bv[j];
         }
     }
-    return true;
 }
 
 // downward sweep, one tree level
@@ -1402,92 +1365,7 @@ __global__ __launch_bounds__(256) void nd_bwd_kernel(const NdSweepNode* __restri
     const NdSweepNode nd = lnodes[blockIdx.x];
     const int32_t r0 = (int32_t)blockIdx.y * (512 / LPR);
     if (r0 >= nd.m || nd.f == nd.m) return;
-    (void)nd_bwd_tile<MT, VT, LPR, ORDERED, false>(nd, r0, (int32_t)blockIdx.y, vs, ufac, idx, gell, x, xb, [] { return true; });
-}
-
-// ---- chained sweeps: the top levels of the forest in ONE launch per direction ------------------------------------------------
-// Near the top of the tree a level is a handful of small tiles; as a launch of its own it costs ~7 us whatever it computes (its
-// chain of dependent loads plus the dispatch of a dependent kernel), and a 30 k-unknown solve is 184 applies x 11 such levels.
-// Here the tiles of all those levels form ONE persistent launch: at most one workgroup per CU (all resident at once), tile i is
-// worked by workgroup i mod G, tiles are listed level by level -- so a tile only ever waits for tiles listed before it, which
-// are done or in the hands of a running workgroup.  A node's tiles add 1 to the node's counter when their stores have drained;
-// a consumer polls the counters of the nodes it depends on (its children going up, its parent going down) against epoch x tiles
-// (the counters are never reset: the epoch counts the applies).  Hand-over data (slot rows, boundary vectors, the chain's own x
-// entries) is stored and loaded with agent-scope relaxed atomics = `sc1` accesses, the form of MI355X_MICROARCH.md's table of
-// valid hand-offs: every storing wave waits for its stores, the workgroup meets at a barrier, ONE lane signals with an
-// agent-scope atomic add; ONE wave polls, the others load behind a barrier.  Waits are bounded: a wait that expires sets the
-// abort word, every tile still to come sees it and returns, and the host reports LSA_ERR_TIMEOUT instead of hanging.
-// Same arithmetic in the same order as the one-launch-per-level sweeps: bitwise the same x (tests/test_gpu_ndlu.py).
-struct NdChainTile {
-    int32_t q;       // position of the node's record in the level-ordered sweep records
-    int32_t ty;      // tile of the node
-    int32_t node;    // node id (counter, children)
-    int32_t parent;  // parent's node id, or -1
-};
-constexpr uint32_t kChainMaxSpins = 1u << 24;  // ~ 10 s of polling
-
-__device__ __forceinline__ bool chain_wait(const uint32_t* cnt, uint32_t target, int32_t* abort_word) {
-    for (uint32_t spins = 0;; ++spins) {
-        const uint32_t have = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((int32_t)(have - target) >= 0) return true;
-        if ((spins & 255u) == 255u) {
-            if (__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-            if (spins > kChainMaxSpins) {
-                __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return false;
-            }
-        }
-    }
-}
-
-template <typename MT, typename VT, bool ORDERED, bool DOWN>
-__global__ __launch_bounds__(256) void nd_chain_kernel(const NdChainTile* __restrict__ tiles, int32_t ntiles, const NdSweepNode* __restrict__ lnodes,
-                                                       const int32_t* __restrict__ child_ptr, const int32_t* __restrict__ child_idx,
-                                                       const uint32_t* __restrict__ tiles_up, const uint32_t* __restrict__ tiles_dn, uint32_t* cnt_up,
-                                                       uint32_t* cnt_dn, uint32_t epoch, int32_t* abort_word, const MT* __restrict__ fac,
-                                                       const int32_t* __restrict__ idx, const int32_t* __restrict__ gell, const int32_t* __restrict__ cmap,
-                                                       const VT* __restrict__ rhs, VT* x, VT* ubuf, VT* acc, VT* xb) {
-    __shared__ VT vs[kCH];
-    __shared__ int ok_s;
-    for (int32_t ti = (int32_t)blockIdx.x; ti < ntiles; ti += (int32_t)gridDim.x) {
-        const NdChainTile te = tiles[ti];
-        const NdSweepNode nd = lnodes[te.q];
-        auto ready = [&]() -> bool {
-            if (threadIdx.x < 64) {  // ONE wave polls
-                bool ok = true;
-                if constexpr (!DOWN) {
-                    // children worked by this launch (the others were finished by earlier launches: tiles_up == 0)
-                    for (int32_t cp = child_ptr[te.node] + (int32_t)threadIdx.x; cp < child_ptr[te.node + 1]; cp += 64) {
-                        const int32_t c = child_idx[cp];
-                        const uint32_t nt = tiles_up[c];
-                        if (nt != 0) ok = chain_wait(cnt_up + c, epoch * nt, abort_word) && ok;
-                    }
-                } else if (threadIdx.x == 0 && te.parent >= 0) {
-                    // the parent's downward tiles; a root has none: its upward tiles (an earlier launch) fed this node
-                    const uint32_t nt = tiles_dn[te.parent];
-                    if (nt != 0) ok = chain_wait(cnt_dn + te.parent, epoch * nt, abort_word);
-                }
-                ok = __all(ok) != 0;
-                if (threadIdx.x == 0) ok_s = ok ? 1 : 0;
-#if !LSA_CHAIN_SC1_LOADS
-                // ONE agent-scope acquire after the polls (drops this CU's stale lines), its wait, then the barrier: every wave's
-                // plain loads of the hand-over data come behind it
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            }
-            __syncthreads();
-            return ok_s != 0;
-        };
-        bool fine;
-        if constexpr (!DOWN) fine = nd_fwd_tile<MT, VT, 64, ORDERED, true>(nd, te.ty * 8, vs, fac, idx, gell, cmap, rhs, x, ubuf, acc, xb, ready);
-        else fine = nd_bwd_tile<MT, VT, 64, ORDERED, true>(nd, te.ty * 8, te.ty, vs, fac, idx, gell, x, xb, ready);
-        if (!fine) return;  // (uniform: ok_s is read by every thread behind the barrier)
-        // publish: every storing wave waits for its stores, all meet, one lane signals
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add((DOWN ? cnt_dn : cnt_up) + te.node, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    nd_bwd_tile<MT, VT, LPR, ORDERED>(nd, r0, (int32_t)blockIdx.y, vs, ufac, idx, gell, x, xb);
 }
 
 // ---- downward sweep of DISTRIBUTED top nodes: a rank finishes its slice of the node's own rows (nd_bwd_kernel on a record
@@ -1610,14 +1488,6 @@ struct lsa_ndlu {
     int32_t *d_dist_nodes = nullptr, *d_child_ptr = nullptr, *d_child_idx = nullptr;  // distributed nodes by level; children of every node
     void *d_xstage = nullptr, *d_xg = nullptr;          // staging of update rows on their way to distributed parents; own-row exchange buffer of the sweeps
     int64_t xstage_slot = 0;                            // scalars per rank of d_xstage
-    // chained sweeps (nd_chain_kernel): the levels [chain_first, nlevels) in one launch per direction
-    int32_t chain_first = -1;                           // -1: every level is a launch of its own
-    int32_t chain_up_tiles = 0, chain_dn_tiles = 0;
-    NdChainTile *d_chain_up = nullptr, *d_chain_dn = nullptr;
-    uint32_t *d_chain_tiles_up = nullptr, *d_chain_tiles_dn = nullptr, *d_chain_cnt = nullptr;  // per node: tiles per direction; counters (up, then down)
-    int32_t* d_chain_abort = nullptr;
-    uint32_t chain_epoch = 0;
-    bool chain_dirty = false;                           // an apply was queued since the abort word was last read
     std::vector<int64_t> h_upd_off;                     // per node: its update matrix in the update arena (host copy of the plan)
     int64_t chunk_node_upd_off(int32_t t) const { return h_upd_off[(size_t)t]; }
     int32_t* d_gell = nullptr;
@@ -1650,8 +1520,6 @@ namespace {
 
 void nd_free(lsa_ndlu* f) {
     if (!f) return;
-    for (void* p : {(void*)f->d_chain_up, (void*)f->d_chain_dn, (void*)f->d_chain_tiles_up, (void*)f->d_chain_tiles_dn, (void*)f->d_chain_cnt, (void*)f->d_chain_abort})
-        if (p) (void)hipFree(p);
     for (void* p : {(void*)f->d_lnodes_bwd, (void*)f->d_dist_nodes, (void*)f->d_child_ptr, (void*)f->d_child_idx, f->d_xstage, f->d_xg})
         if (p) (void)hipFree(p);
     for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
@@ -2003,76 +1871,6 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         if (f->xstage_slot > 0) LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_xstage, (size_t)f->xstage_slot * (size_t)S.nranks * es));
         if (S.xg_entries > 0) LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_xg, (size_t)S.xg_entries * 16));
     }
-    // ---- chained sweeps: the run of 8-row-tile levels at the top of the tree, one launch per direction (one rank only: the
-    // levels of a forest cut over ranks are separated by exchanges) ----
-    {
-        f->chain_first = -1;
-        const char* ce = getenv("LSA_ND_CHAIN");
-        const bool want = !(ce && *ce && atoi(ce) == 0);
-        // ... as far down as all its tiles fit the chip at once (LSA_ND_CHAIN_TILES per direction, default 4 workgroups per CU):
-        // a chain worked off by fewer workgroups than it has tiles serialises what a launch per level runs side by side
-        static const int64_t tile_budget = getenv("LSA_ND_CHAIN_TILES") ? atoll(getenv("LSA_ND_CHAIN_TILES")) : 4 * (int64_t)ctx->num_cu;
-        int32_t first = S.nlevels;
-        int64_t up_tiles = 0, dn_tiles = 0;
-        while (first > 1 && f->levels[(size_t)first - 1].sweep_rows == 8) {
-            const NdLevel& L = f->levels[(size_t)first - 1];
-            int64_t lu = 0, ld = 0;
-            for (int32_t q = 0; q < L.node_count; ++q) {
-                const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-                lu += (S.f[(size_t)t] + 7) / 8;
-                if (S.f[(size_t)t] > S.m[(size_t)t]) ld += (S.m[(size_t)t] + 7) / 8;
-            }
-            if (up_tiles + lu > tile_budget || dn_tiles + ld > tile_budget) break;
-            up_tiles += lu;
-            dn_tiles += ld;
-            --first;
-        }
-        if (want && S.nranks == 1 && S.nlevels - first >= 2) {
-            std::vector<NdChainTile> up, dn;
-            std::vector<uint32_t> tiles_up((size_t)nt, 0), tiles_dn((size_t)nt, 0);
-            bool all_push = true;
-            for (int32_t l = first; l < S.nlevels; ++l) {
-                const NdLevel& L = f->levels[(size_t)l];
-                for (int32_t q = 0; q < L.node_count; ++q) {
-                    const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-                    const int32_t nchild = S.child_ptr[(size_t)t + 1] - S.child_ptr[(size_t)t];
-                    all_push = all_push && (nchild == 0 || nodes[(size_t)t].acc_off >= 0) && (S.parent[(size_t)t] < 0 || nodes[(size_t)t].pacc_off >= 0);
-                    const int32_t nup = (S.f[(size_t)t] + 7) / 8;
-                    tiles_up[(size_t)t] = (uint32_t)nup;
-                    for (int32_t ty = 0; ty < nup; ++ty) up.push_back(NdChainTile{L.node_begin + q, ty, t, S.parent[(size_t)t]});
-                }
-            }
-            for (int32_t l = S.nlevels - 1; l >= first; --l) {
-                const NdLevel& L = f->levels[(size_t)l];
-                for (int32_t q = 0; q < L.node_count; ++q) {
-                    const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
-                    if (S.f[(size_t)t] == S.m[(size_t)t]) continue;  // a root: nothing to do on the way down
-                    const int32_t ndn = (S.m[(size_t)t] + 7) / 8;
-                    tiles_dn[(size_t)t] = (uint32_t)ndn;
-                    for (int32_t ty = 0; ty < ndn; ++ty) dn.push_back(NdChainTile{L.node_begin + q, ty, t, S.parent[(size_t)t]});
-                }
-            }
-            if (all_push && !up.empty()) {
-                f->chain_first = first;
-                f->chain_up_tiles = (int32_t)up.size();
-                f->chain_dn_tiles = (int32_t)dn.size();
-                LSA_CHECK(upload(ctx, up, &f->d_chain_up));
-                LSA_CHECK(upload(ctx, dn, &f->d_chain_dn));
-                LSA_CHECK(upload(ctx, tiles_up, &f->d_chain_tiles_up));
-                LSA_CHECK(upload(ctx, tiles_dn, &f->d_chain_tiles_dn));
-                LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_chain_cnt, 2 * (size_t)std::max(nt, 1) * sizeof(uint32_t)));
-                LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_chain_abort, 4 * sizeof(int32_t)));
-                LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_chain_cnt, 0, 2 * (size_t)std::max(nt, 1) * sizeof(uint32_t), ctx->stream));
-                LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_chain_abort, 0, 4 * sizeof(int32_t), ctx->stream));
-                f->chain_epoch = 0;
-            }
-        }
-    }
-    LSA_CHECK(upload(ctx, S.gell, &f->d_gell));
-    LSA_CHECK(upload(ctx, S.idx, &f->d_idx));
-    LSA_CHECK(upload(ctx, S.cmap, &f->d_cmap));
-    LSA_CHECK(upload(ctx, chunk_nodes, &f->d_chunk_nodes));
-    LSA_CHECK(upload(ctx, tiles, &f->d_tiles));
     const size_t nn = (size_t)std::max<int32_t>(S.n, 1);
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_ipiv, nn * sizeof(int32_t)));
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_rowq, nn * sizeof(int32_t)));
@@ -2109,12 +1907,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         }
     }
     f->solve_launches = 0;
-    for (int32_t l = 0; l < S.nlevels; ++l) {
-        const NdLevel& L = f->levels[(size_t)l];
-        if (f->chain_first >= 0 && l >= f->chain_first) continue;
-        f->solve_launches += (L.fwd_tiles > 0) + (L.bwd_tiles > 0);
-    }
-    if (f->chain_first >= 0) f->solve_launches += (f->chain_up_tiles > 0) + (f->chain_dn_tiles > 0);
+    for (const NdLevel& L : f->levels) f->solve_launches += (L.fwd_tiles > 0) + (L.bwd_tiles > 0);
     return LSA_OK;
 }
 
@@ -2409,20 +2202,6 @@ int nd_apply_ordered(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
         // subtree-parallel: the update vectors of all ranks' subtree roots, before the replicated top of the tree
         if ((int32_t)li == S.phase_b_level && S.nranks > 1 && S.xu_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, f->d_ubuf, (size_t)S.xu_slot * sizeof(VT)));
         if (li == f->levels.size()) break;
-        if (f->chain_first >= 0 && (int32_t)li >= f->chain_first) {
-            // the top levels in one launch (nd_chain_kernel): at most one workgroup per CU, all resident
-            if ((int32_t)li == f->chain_first && f->chain_up_tiles > 0) {
-                ++f->chain_epoch;
-                f->chain_dirty = true;
-                uint32_t* cnt = f->d_chain_cnt;
-                hipLaunchKernelGGL((nd_chain_kernel<MT, VT, ORDERED, false>), dim3(f->chain_up_tiles), dim3(256), 0, st,
-                                   (const NdChainTile*)f->d_chain_up, f->chain_up_tiles, (const NdSweepNode*)f->d_lnodes, (const int32_t*)f->d_child_ptr,
-                                   (const int32_t*)f->d_child_idx, (const uint32_t*)f->d_chain_tiles_up, (const uint32_t*)f->d_chain_tiles_dn, cnt,
-                                   cnt + S.nt, f->chain_epoch, f->d_chain_abort, lfac, (const int32_t*)f->d_idx, (const int32_t*)f->d_gell,
-                                   (const int32_t*)f->d_cmap, b, x, ubuf, acc, xb);
-            }
-            continue;
-        }
         const NdLevel& L = f->levels[li];
         if (L.fwd_tiles > 0) {
             const dim3 grid(L.node_count, L.fwd_tiles);
@@ -2437,16 +2216,7 @@ int nd_apply_ordered(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
         // distributed top nodes of the level: every rank produced its slice of their update entries
         if (L.dist_count > 0 && L.ux_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, ubuf + L.ux_base, (size_t)L.ux_slot * sizeof(VT)));
     }
-    if (f->chain_first >= 0 && f->chain_dn_tiles > 0) {
-        uint32_t* cnt = f->d_chain_cnt;
-        hipLaunchKernelGGL((nd_chain_kernel<MT, VT, ORDERED, true>), dim3(f->chain_dn_tiles), dim3(256), 0, st,
-                           (const NdChainTile*)f->d_chain_dn, f->chain_dn_tiles, (const NdSweepNode*)f->d_lnodes_bwd, (const int32_t*)f->d_child_ptr,
-                           (const int32_t*)f->d_child_idx, (const uint32_t*)f->d_chain_tiles_up, (const uint32_t*)f->d_chain_tiles_dn, cnt, cnt + S.nt,
-                           f->chain_epoch, f->d_chain_abort, ufac, (const int32_t*)f->d_idx, (const int32_t*)f->d_gell, (const int32_t*)f->d_cmap, b, x,
-                           ubuf, acc, xb);
-    }
     for (size_t l = f->levels.size(); l-- > 0;) {
-        if (f->chain_first >= 0 && (int32_t)l >= f->chain_first) continue;
         const NdLevel& L = f->levels[l];
         if (L.bwd_tiles > 0) {
             const dim3 grid(L.node_count, L.bwd_tiles);
@@ -2518,22 +2288,6 @@ int ndlu_solve_adjoint_dev(lsa_ctx* ctx, lsa_ndlu* f, int conj, int vdtype, cons
     if (f->dtype == LSA_C128) return conj ? nd_apply_T<cplx, cplx, true>(ctx, f, (const cplx*)b, (cplx*)x) : nd_apply_T<cplx, cplx, false>(ctx, f, (const cplx*)b, (cplx*)x);
     if (vdtype == LSA_C128) return nd_apply_T<double, cplx, false>(ctx, f, (const cplx*)b, (cplx*)x);  // real factors: C^H = C^T
     return nd_apply_T<double, double, false>(ctx, f, (const double*)b, (double*)x);
-}
-
-// The chained sweeps bound their waits; a wait that expired left the abort word set and x unfinished.  Called by whoever has
-// just synchronised with the stream: returns LSA_ERR_TIMEOUT once and puts the chain's state back in order.
-int ndlu_check_abort(lsa_ctx* ctx, lsa_ndlu* f) {
-    if (!f || f->chain_first < 0 || !f->chain_dirty) return LSA_OK;
-    f->chain_dirty = false;
-    int32_t h = 0;
-    LSA_HIP_CHECK(ctx, hipMemcpyAsync(&h, f->d_chain_abort, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    if (h == 0) return LSA_OK;
-    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_chain_cnt, 0, 2 * (size_t)std::max(f->S.nt, 1) * sizeof(uint32_t), ctx->stream));
-    LSA_HIP_CHECK(ctx, hipMemsetAsync(f->d_chain_abort, 0, 4 * sizeof(int32_t), ctx->stream));
-    f->chain_epoch = 0;
-    return lsa_set_error(ctx, LSA_ERR_TIMEOUT, "lsa_ndlu: a dependency wait of the chained sweeps expired (the device was held by other work for seconds, "
-                                               "or a workgroup never became resident); LSA_ND_CHAIN=0 runs one launch per level");
 }
 
 // x = C^-1 b on device pointers (b and x distinct or identical: an aliased right-hand side is copied first)
@@ -2834,7 +2588,7 @@ int lsa_ndlu_solve(lsa_ctx* ctx, lsa_ndlu* f, const lsa_vec* b, lsa_vec* x) {
     if (b->n != f->S.n || x->n != f->S.n || b->dtype != x->dtype) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve: shape/dtype mismatch");
     LSA_CHECK(ndlu_solve_dev(ctx, f, b->dtype, b->d, x->d));
     LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
-    return ndlu_check_abort(ctx, f);
+    return LSA_OK;
 }
 
 int lsa_ndlu_solve_adjoint(lsa_ctx* ctx, lsa_ndlu* f, int conj, const lsa_vec* b, lsa_vec* x) {
@@ -2855,7 +2609,7 @@ int lsa_ndlu_solve_time(lsa_ctx* ctx, lsa_ndlu* f, const lsa_vec* b, lsa_vec* x,
     float ms = 0.f;
     LSA_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_ms = (double)ms / iters;
-    return ndlu_check_abort(ctx, f);
+    return LSA_OK;
 }
 
 int lsa_ndlu_info(const lsa_ndlu* f, int32_t* ntree, int32_t* nlevels, int32_t* max_front, int64_t* factor_entries, int64_t* front_entries,

@@ -217,7 +217,6 @@ int gmres_run(lsa_ctx* ctx, const lsa_mat* C, PcRef pc, int dtype, const void* b
         LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
         beta0 = std::sqrt(((const double*)ctx->pinned)[0]);
         bnorm = std::sqrt(((const double*)ctx->pinned)[1]);
-        if (pc.nd) LSA_CHECK(ndlu_check_abort(ctx, pc.nd));
         use_x0 = true;
         // Iterative refinement before any looser judgement: the residual b - C x is on the device already (W.w), one more
         // pair of sweeps and one product give x += C^-1 (b - C x).  Large 3D factorisations leave ||b - C x|| / ||b|| at 1e-11
@@ -1024,13 +1023,6 @@ int lsa_krylov_extend(lsa_ctx* ctx, lsa_krylov* k, int32_t j0, int32_t j1, void*
             LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
             static const bool timing = getenv("LSA_KRYLOV_TIMING") != nullptr;
             if (timing) fprintf(stderr, "[lsa_krylov] %d steps queued in %.3f ms, waited %.3f ms\n", nb, 1e3 * (tw - tq), 1e3 * (now_s() - tw));
-            if (op->nd) {
-                const int arc = ndlu_check_abort(ctx, op->nd);
-                if (arc != LSA_OK) {
-                    op->st.seconds_solve += now_s() - t0;
-                    return arc;
-                }
-            }
             const double* chk = (const double*)(host + (size_t)k->batch * colb);
             int32_t accepted = 0;
             for (int32_t s = 0; s < nb; ++s, ++accepted) {

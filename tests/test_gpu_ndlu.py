@@ -333,38 +333,3 @@ def test_ndlu_super_blocks_of_128_pivot_columns(hip_ctx, monkeypatch, case, sigm
         assert np.linalg.norm(C @ xs[-1] - b) <= 1e-12 * np.linalg.norm(b)
         assert np.linalg.norm(xs[-1] - xref) <= 1e-10 * np.linalg.norm(xref)
     assert np.array_equal(xs[0], xs[1])
-
-
-@pytest.mark.parametrize("case,sigma", [("S5k", SIGMA), ("S5k", 0.05), ("S30k", SIGMA), ("C9k", -5.0), ("S120k", SIGMA)])
-def test_chained_sweeps_are_bitwise_the_sweeps_level_by_level(hip_ctx, monkeypatch, case, sigma):
-    """The top levels of the forest in ONE launch per direction (nd_chain_kernel: a persistent launch whose tiles hand over
-    through agent-scope atomics and per-node counters) against one launch per level: the same arithmetic in the same order, so
-    the same bits -- over many applies with fresh right-hand sides (a stale read of a hand-over word would show here), real and
-    complex factors, real and complex vectors."""
-    import lsa_hip
-    from synthetic import fem
-
-    monkeypatch.setenv("LSA_ND_NO_CACHE", "1")  # (the chain is laid out at set-up: a parked factorisation would keep its form)
-    es = fem.cube_case(case) if case.startswith("C") else fem.cylinder_case(case)
-    C = sp.csr_matrix((es.A.data - sigma * es.M.data, es.A.indices, es.A.indptr), shape=es.A.shape)
-    dC = lsa_hip.CsrMatrix.from_scipy(hip_ctx, C)
-    rng = np.random.default_rng(3)
-    rhs = [rng.standard_normal(es.n) + (1j * rng.standard_normal(es.n) if (k % 2 or np.iscomplexobj(C.data)) else 0.0) for k in range(40)]
-    out, launches = {}, {}
-    for chain in ("0", "1"):
-        monkeypatch.setenv("LSA_ND_CHAIN", chain)
-        f = lsa_hip.NdLu(hip_ctx, dC, 0)
-        launches[chain] = f.info()["apply_launches"]
-        xs = []
-        for rep in range(3):  # the same right-hand sides three times over: 120 applies on one set of counters
-            xs.append([_solve(hip_ctx, f, b.astype(np.complex128) if np.iscomplexobj(b) else b) for b in rhs])
-        for rep in (1, 2):
-            assert all(np.array_equal(a, b) for a, b in zip(xs[0], xs[rep]))
-        out[chain] = xs[0]
-        del f
-    print(case, sigma, "launches per apply:", launches)
-    assert launches["1"] < launches["0"]
-    for a, b in zip(out["0"], out["1"]):
-        assert np.array_equal(a, b)
-    b0 = rhs[1].astype(np.complex128)
-    assert np.linalg.norm(C @ out["1"][1] - b0) <= 1e-11 * np.linalg.norm(b0)

@@ -1189,7 +1189,7 @@ __device__ __forceinline__ VT gather_updates(const int32_t* __restrict__ ge, int
 // PUSH form: the same sum from the node's slot rows (row c = what child c added to every front position; slots no child maps
 // to were zeroed once and are never written): contiguous loads, no index in between.  Same order of additions as the pull form.
 template <typename VT>
-__device__ __forceinline__ VT slot_sum(const VT* slots, int32_t nchild, int32_t f, int32_t j, VT v) {
+__device__ __forceinline__ VT slot_sum(const VT* __restrict__ slots, int32_t nchild, int32_t f, int32_t j, VT v) {
     int32_t c = 0;
     for (; c + 3 < nchild; c += 4) {
         const VT u0 = slots[(size_t)c * f + j], u1 = slots[(size_t)(c + 1) * f + j], u2 = slots[(size_t)(c + 2) * f + j],
@@ -1205,7 +1205,7 @@ __device__ __forceinline__ VT slot_sum(const VT* slots, int32_t nchild, int32_t 
 
 // downward sweep: the value of front position j goes into the boundary vector of every child that has j in its boundary
 template <typename VT>
-__device__ __forceinline__ void push_down(const int32_t* __restrict__ ge, int32_t nchild, int32_t f, int32_t j, VT* xb, VT val) {
+__device__ __forceinline__ void push_down(const int32_t* __restrict__ ge, int32_t nchild, int32_t f, int32_t j, VT* __restrict__ xb, VT val) {
     for (int32_t c = 0; c < nchild; ++c) {
         const int32_t g = ge[(size_t)c * f + j];
         if (g >= 0) xb[g] = val;
@@ -1219,8 +1219,8 @@ __device__ __forceinline__ void push_down(const int32_t* __restrict__ ge, int32_
 // A root (no boundary) also starts the downward sweep: its rows are final, they go to its children's boundary vectors.
 template <typename MT, typename VT, int LPR, bool ORDERED>
 __device__ __forceinline__ void nd_fwd_tile(const NdSweepNode& nd, int32_t r0, VT* vs, const MT* __restrict__ lfac, const int32_t* __restrict__ idx,
-                                            const int32_t* __restrict__ gell, const int32_t* __restrict__ cmap, const VT* __restrict__ rhs, VT* x,
-                                            VT* ubuf, VT* acc, VT* xb) {
+                                            const int32_t* __restrict__ gell, const int32_t* __restrict__ cmap, const VT* __restrict__ rhs,
+                                            VT* __restrict__ x, VT* __restrict__ ubuf, VT* __restrict__ acc, VT* __restrict__ xb) {
     const int32_t m = nd.m, f = nd.f;
     // rows of the packed L on this rank: its own rows of the inverse, then its boundary rows (m and f - m of them unless the node
     // is distributed: then orows rows from orow0 and brow rows from brow0)
@@ -1248,18 +1248,18 @@ __device__ __forceinline__ void nd_fwd_tile(const NdSweepNode& nd, int32_t r0, V
     if (sl == 0) {
         if (ra >= mr && ra < floc) {
             const int32_t jg = m + nd.brow0 + ra - mr;
-            ua = push ? slot_sum(slots, nd.nchild, f, jg, ua) : gather_updates(ge, nd.nchild, f, jg, (const VT*)ubuf, ua);
+            ua = push ? slot_sum(slots, nd.nchild, f, jg, ua) : gather_updates(ge, nd.nchild, f, jg, ubuf, ua);
         }
         if (rb >= mr && rb < floc) {
             const int32_t jg = m + nd.brow0 + rb - mr;
-            ub = push ? slot_sum(slots, nd.nchild, f, jg, ub) : gather_updates(ge, nd.nchild, f, jg, (const VT*)ubuf, ub);
+            ub = push ? slot_sum(slots, nd.nchild, f, jg, ub) : gather_updates(ge, nd.nchild, f, jg, ubuf, ub);
         }
     }
     for (int32_t c0 = 0; c0 < m; c0 += kCH) {
         const int32_t cn = min(kCH, m - c0);
         for (int32_t j = tid; j < cn; j += 256) {
             const VT v = rhs[ORDERED ? nd.own0 + c0 + j : ix[c0 + j]];
-            vs[j] = push ? slot_sum(slots, nd.nchild, f, c0 + j, v) : gather_updates(ge, nd.nchild, f, c0 + j, (const VT*)ubuf, v);
+            vs[j] = push ? slot_sum(slots, nd.nchild, f, c0 + j, v) : gather_updates(ge, nd.nchild, f, c0 + j, ubuf, v);
         }
         __syncthreads();
         if (c0 == 0) two_row_dot_prefetched<LPR>(La, Lb, vs, cn, sl, acc0, acc1, pa, pb);
@@ -1306,7 +1306,8 @@ __global__ __launch_bounds__(256) void nd_fwd_kernel(const NdSweepNode* __restri
 // boundary entries the node received.
 template <typename MT, typename VT, int LPR, bool ORDERED>
 __device__ __forceinline__ void nd_bwd_tile(const NdSweepNode& nd, int32_t r0, int32_t ty, VT* vs, const MT* __restrict__ ufac,
-                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ gell, VT* x, VT* xb) {
+                                            const int32_t* __restrict__ idx, const int32_t* __restrict__ gell, VT* __restrict__ x,
+                                            VT* __restrict__ xb) {
     constexpr int ROWS = 512 / LPR;
     const int32_t m = nd.m, f = nd.f, b = f - m;
     const int32_t* ix = idx + nd.idx_off;
@@ -1871,6 +1872,11 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
         if (f->xstage_slot > 0) LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_xstage, (size_t)f->xstage_slot * (size_t)S.nranks * es));
         if (S.xg_entries > 0) LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_xg, (size_t)S.xg_entries * 16));
     }
+    LSA_CHECK(upload(ctx, S.gell, &f->d_gell));
+    LSA_CHECK(upload(ctx, S.idx, &f->d_idx));
+    LSA_CHECK(upload(ctx, S.cmap, &f->d_cmap));
+    LSA_CHECK(upload(ctx, chunk_nodes, &f->d_chunk_nodes));
+    LSA_CHECK(upload(ctx, tiles, &f->d_tiles));
     const size_t nn = (size_t)std::max<int32_t>(S.n, 1);
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_ipiv, nn * sizeof(int32_t)));
     LSA_HIP_ALLOC(ctx, hipMalloc((void**)&f->d_rowq, nn * sizeof(int32_t)));

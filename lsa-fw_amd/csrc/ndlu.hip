@@ -774,88 +774,13 @@ __global__ __launch_bounds__(256) void nd_unperm_kernel(const int32_t* __restric
     }
 }
 
-// batched dense products of a chunk (row-major, 64 x 64 tiles, 4 x 4 per thread); inv = the first m rows of the packed L:
+// Batched dense products of a chunk (row-major operands, 64 x 64 tiles); inv = the inverse of the node's pivot block:
 //   KIND 0:  L[m:] = -F21 inv     (b x m)      KIND 1:  F22 += L[m:] F12   (b x b, in the working front)      KIND 2:  U = inv F12   (m x b)
-template <typename T, int KIND>
-__global__ __launch_bounds__(256) void nd_gemm_kernel(const int32_t* __restrict__ tiles, const NdNodeDev* __restrict__ nodes,
-                                                      T* __restrict__ front, T* __restrict__ lfac, T* __restrict__ ufac) {
-    constexpr int BK = 8;
-    __shared__ T As[BK][kGT + 1];
-    __shared__ T Bs[BK][kGT + 1];
-    const int32_t t = tiles[2 * blockIdx.x], packed = tiles[2 * blockIdx.x + 1];
-    const int32_t tm = packed >> 16, tn = packed & 0xFFFF;
-    const NdNodeDev nd = nodes[t];
-    const int32_t m = nd.m, f = nd.f, b = f - m;
-    T* F = front + nd.front_off;
-    T* inv = nd.inv_off < 0 ? lfac + nd.lfac_off : front + nd.inv_off;  // the whole inverse (a distributed node: in the working arena)
-    T* invrows = lfac + nd.lfac_off;                                    // this rank's own rows of it (all of them unless distributed)
-    T* S1 = invrows + (size_t)nd.orows * m;
-    T* S2 = ufac + nd.ufac_off;
-    const T *A, *B;
-    T* C;
-    int32_t M, N, K, lda, ldb, ldc;
-    // (a distributed top node: this rank's boundary rows of F21 / F22 and its own rows of U; F12 is whole on every rank)
-    if (KIND == 0) {
-        A = F + (size_t)m * f, lda = f, B = inv, ldb = m, C = S1, ldc = m, M = nd.brow, N = m, K = m;
-    } else if (KIND == 1) {
-        A = S1, lda = m, B = F + m, ldb = f, C = F + (size_t)m * f + m, ldc = f, M = nd.brow, N = b, K = m;
-    } else {
-        A = invrows, lda = m, B = F + m, ldb = f, C = S2, ldc = b, M = nd.orows, N = b, K = m;
-    }
-    const int32_t row0 = tm * kGT, col0 = tn * kGT;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    T acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = scalar_traits<T>::zero();
-    for (int32_t kk = 0; kk < K; kk += BK) {
-        // A tile: 64 rows x 8 k (2 per thread); B tile: 8 k x 64 cols (2 per thread)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int e = tid + 256 * s;
-            const int ar = e >> 3, ak = e & 7;
-            const int32_t gr = row0 + ar, gk = kk + ak;
-            As[ak][ar] = (gr < M && gk < K) ? A[(size_t)gr * lda + gk] : scalar_traits<T>::zero();
-            const int bk = e >> 6, bc = e & 63;
-            const int32_t gk2 = kk + bk, gc = col0 + bc;
-            Bs[bk][bc] = (gk2 < K && gc < N) ? B[(size_t)gk2 * ldb + gc] : scalar_traits<T>::zero();
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < BK; ++k) {
-            T av[4], bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = As[k][ty * 4 + i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bv[j] = Bs[k][tx + 16 * j];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) fma_acc(acc[i][j], av[i], bv[j]);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int32_t gr = row0 + ty * 4 + i;
-        if (gr >= M) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int32_t gc = col0 + tx + 16 * j;
-            if (gc >= N) continue;
-            T* c = C + (size_t)gr * ldc + gc;
-            if (KIND == 0) *c = s_sub(scalar_traits<T>::zero(), acc[i][j]);
-            else if (KIND == 1) *c = s_add(*c, acc[i][j]);
-            else *c = acc[i][j];
-        }
-    }
-}
-
-// The same three products on the matrix cores: v_mfma_f64_16x16x4_f64, one wavefront per 32 x 32 quarter of the 64 x 64 tile
+// (a distributed top node: this rank's rows of each, see NdNodeDev)
+// On the matrix cores: v_mfma_f64_16x16x4_f64, one wavefront per 32 x 32 quarter of the 64 x 64 tile
 // (2 x 2 instruction tiles; complex scalars as real and imaginary planes, four instructions per complex tile product).
-// The vector kernel above reads 8 LDS values per 16 multiply-adds and is bound by the LDS array at about a third of the FP64
-// rate; here a k-step of 4 costs a wavefront 4 LDS reads for 4 (real) or 16 (complex) instructions of 64 cycles each.
+// A 4 x 4-per-thread FMA kernel (round 2's) reads 8 LDS values per 16 multiply-adds and is bound by the LDS array at about a third
+// of the FP64 rate; here a k-step of 4 costs a wavefront 4 LDS reads for 4 (real) or 16 (complex) instructions of 64 cycles each.
 // Operand maps (cdna_hip_programming.md, "Fragment layout"): lane l holds A[l & 15][l >> 4], B[l >> 4][l & 15]; result
 // register r of lane l is C[(l >> 4) + 4 r][l & 15].
 // LDS images: A row-major with a row of BK + 1 doubles (16 rows x 2 k per half-wave: 32 distinct bank pairs), B k-major with a
@@ -2128,15 +2053,10 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
         if (L.unperm.count > 0)
             hipLaunchKernelGGL((nd_unperm_kernel<T>), dim3(L.unperm.count), dim3(256), 0, st, tl + 2 * L.unperm.off, f->d_nodes, front, f->d_ipiv,
                                f->d_rowq, lfac);
-        static const bool vector_gemm = getenv("LSA_ND_GEMM") && !strcmp(getenv("LSA_ND_GEMM"), "vector");  // (A/B measurement aid)
         auto product = [&](auto kind) {
             constexpr int KIND = decltype(kind)::value;
             if (L.gemm[KIND].count == 0) return;
-            if (vector_gemm)
-                hipLaunchKernelGGL((nd_gemm_kernel<T, KIND>), dim3(L.gemm[KIND].count), dim3(256), 0, st, tl + 2 * L.gemm[KIND].off, f->d_nodes, front, lfac, ufac);
-            else
-                hipLaunchKernelGGL((nd_gemm_mfma_kernel<T, KIND>), dim3(L.gemm[KIND].count), dim3(256), 0, st, tl + 2 * L.gemm[KIND].off, f->d_nodes, front, lfac,
-                                   ufac);
+            hipLaunchKernelGGL((nd_gemm_mfma_kernel<T, KIND>), dim3(L.gemm[KIND].count), dim3(256), 0, st, tl + 2 * L.gemm[KIND].off, f->d_nodes, front, lfac, ufac);
         };
         product(std::integral_constant<int, 0>{});
         product(std::integral_constant<int, 1>{});

@@ -218,6 +218,12 @@ int lsa_ndlu_solve(lsa_ctx *ctx, lsa_ndlu *f, const lsa_vec *b, lsa_vec *x);
  * factorisation and no transposed matrix. */
 int lsa_ndlu_solve_adjoint(lsa_ctx *ctx, lsa_ndlu *f, int conj, const lsa_vec *b, lsa_vec *x);
 int lsa_ndlu_solve_time(lsa_ctx *ctx, lsa_ndlu *f, const lsa_vec *b, lsa_vec *x, int iters, double *avg_ms);
+/* Inertia (numbers of negative, zero, positive eigenvalues) of a REAL SYMMETRIC C from its factorisation: what SLEPc's spectrum
+ * slicing takes from the symmetric-indefinite factorisation behind EPS.setInterval / EPS_ALL (Solver/utils.py:248-254: the
+ * number of eigenvalues of a definite pencil below sigma is the number of negative eigenvalues of A - sigma M).  Sum over the
+ * tree nodes of the inertia of their pivot blocks, each evaluated on the host (O(m^3)): for the Hermitian problems of the
+ * interval sweep.  Real factors on one rank only; the symmetry of C is the caller's statement. */
+int lsa_ndlu_inertia(lsa_ctx *ctx, lsa_ndlu *f, int64_t *negative, int64_t *zero, int64_t *positive);
 /* front_entries: scalars of the device buffers (packed factors + the working fronts of one chunk + the update arena);
  * apply_bytes: algorithmic bytes of one solve (every factor scalar once + the vectors); apply_launches: dependent
  * launches of one solve (two per tree level, less one: the roots have no downward step) */
@@ -360,6 +366,9 @@ int lsa_eigs_sinvert(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *M, const dou
  *   lsa_dense_schur_reorder: the diagonal entries with select[k] != 0 move to the leading block (orders kept), T and Q updated
  *   lsa_dense_tri_eigenvectors: right eigenvectors of the upper triangular T, unit 2-norm columns of S */
 int lsa_dense_schur(int32_t n, void *A, int32_t lda, void *Q, int32_t ldq);
+/* Inertia of a dense real symmetric matrix (column-major, both triangles read and symmetrised; host only): Bunch-Kaufman diagonal
+ * pivoting; pivots below tol_rel * max|A| count as zero.  The building block of lsa_ndlu_inertia. */
+int lsa_dense_sym_inertia(int32_t n, const double *A, int32_t lda, double tol_rel, int64_t *negative, int64_t *zero, int64_t *positive);
 int lsa_dense_schur_reorder(int32_t n, void *T, int32_t ldt, void *Q, int32_t ldq, const int32_t *select, int32_t *nselected);
 int lsa_dense_tri_eigenvectors(int32_t n, const void *T, int32_t ldt, void *S, int32_t lds);
 

@@ -778,12 +778,56 @@ class iEpsSolver:
                 sigma = covered + max(0.5 * radius, 1e-6 * span)
             else:
                 raise RuntimeError("interval sweep did not cover [a, b] in 200 shifts")
+            # ---- the proof SLEPc's spectrum slicing gives: inertia counts.  For a real symmetric pair the exact LU is a block
+            # congruence, so the number of eigenvalues below a shift is the number of negative eigenvalues of A - shift M, read
+            # off the pivot blocks of its factorisation (lsa_ndlu_inertia).  The sweep above is complete iff it found
+            # count(b) - count(a) pairs; a deficit is localised by bisection on the counts and closed by solves inside it.
+            proof = None
+            if self._can_count_eigenvalues():
+                def in_range(lo, hi):
+                    return sum(1 for lv in found_lam if lo < lv <= hi)
+
+                def close(lo, hi, n_lo, n_hi, depth):
+                    if in_range(lo, hi) >= n_hi - n_lo or depth > 14 or hi - lo <= 1e-10 * max(1.0, abs(hi)):
+                        return
+                    mid = 0.5 * (lo + hi)
+                    n_mid, mid = self._count_below(mid, 1e-7 * (hi - lo))
+                    seed0 = self._seed
+                    try:  # a solve in the middle of the deficient interval, fresh start vectors
+                        self._target = complex(mid)
+                        self._prepared["sig"], self._prepared["sigma"] = self._signature(), self._target
+                        for rep in range(4):
+                            self._seed = seed0 + 104729 * (depth + 1) + 7919 * rep
+                            self.solve()
+                            added[0] = 0
+                            merge(np.real(self._eigenvalues), self._eigenvectors)
+                            if in_range(lo, hi) >= n_hi - n_lo:
+                                break
+                    finally:
+                        self._seed = seed0
+                    close(lo, mid, n_lo, n_mid, depth + 1)
+                    close(mid, hi, n_mid, n_hi, depth + 1)
+
+                n_a, a_used = self._count_below(a, 1e-9 * span)
+                n_b, b_used = self._count_below(b, 1e-9 * span)
+                close(a_used, b_used, n_a, n_b, 0)
+                proof = {"expected": int(n_b - n_a), "found": in_range(a_used, b_used)}
         finally:
             self._which, self._st_type, self._target, self._nev, self._ncv = saved
             if getattr(self, "_prepared", None) is not None:
                 self._prepared["sig"] = None  # the next solve() prepares for its own settings
-        logger.warning("iEpsWhich.ALL on [%g, %g]: %d eigenvalues found by a sweep of shift-invert solves; completeness is heuristic "
-                       "(no inertia count backs it, unlike SLEPc's spectrum slicing) -- a multiple eigenvalue can be under-counted.", a, b, len(found_lam))
+        if proof is not None and proof["found"] == proof["expected"]:
+            logger.info("iEpsWhich.ALL on [%g, %g]: %d eigenvalues, complete: the inertia of A - sigma M at the end points counts %d.", a, b,
+                        len(found_lam), proof["expected"])
+        elif proof is not None:
+            logger.warning("iEpsWhich.ALL on [%g, %g]: %d eigenvalues found, but the inertia counts at the end points say %d: the set is "
+                           "%s.", a, b, proof["found"], proof["expected"], "incomplete" if proof["found"] < proof["expected"] else "over-counted")
+        else:
+            logger.warning("iEpsWhich.ALL on [%g, %g]: %d eigenvalues found by a sweep of shift-invert solves; completeness is heuristic "
+                           "(inertia counts need a real symmetric pair and the exact LU on one GPU) -- a multiple eigenvalue can be "
+                           "under-counted.", a, b, len(found_lam))
+        stats_total["interval_expected"] = -1 if proof is None else proof["expected"]
+        stats_total["interval_complete"] = int(proof is not None and proof["found"] == proof["expected"])
         order = np.argsort(found_lam)
         self._eigenvalues = np.array(found_lam, dtype=np.complex128)[order]
         self._eigenvectors = np.asfortranarray(np.column_stack([found_vec[i] for i in order])) if found_lam else np.zeros((n, 0), dtype=np.complex128)
@@ -791,6 +835,38 @@ class iEpsSolver:
         self._residual_estimates = np.zeros(len(found_lam))
         self._restarts = restarts
         self._stats = stats_total
+
+    def _can_count_eigenvalues(self) -> bool:
+        """Inertia counts are available for a real symmetric pair factored by the exact LU on one GPU."""
+        prep = getattr(self, "_prepared", None)
+        if prep is None or prep["part"] is not None or prep["pc_code"] != 2:
+            return False
+        A = self._A.as_scipy_array()
+        M = None if self._M is None else self._M.as_scipy_array()
+        return A.dtype.kind != "c" and (M is None or M.dtype.kind != "c")
+
+    def _count_below(self, shift: float, nudge: float) -> tuple[int, float]:
+        """Number of eigenvalues of the (definite, real symmetric) pair below ``shift``: the negative eigenvalues of
+        ``A - shift M``, from the pivot blocks of its exact LU (``lsa_ndlu_inertia``; the reference reaches the same count
+        through SLEPc's spectrum slicing, ``Solver/utils.py:248-254``).  A shift that sits on an eigenvalue (zero pivots) is
+        moved by ``nudge`` and counted again; returns the count and the shift used."""
+        import lsa_hip
+
+        prep = self._prepared
+        ctx, perm = prep["ctx"], prep["perm"]
+        A = _permute(sp.csr_matrix(self._A.as_scipy_array()), perm)
+        M = sp.identity(A.shape[0], format="csr") if self._M is None else _permute(sp.csr_matrix(self._M.as_scipy_array()), perm)
+        for attempt in range(6):
+            K = sp.csr_matrix(A - shift * M)
+            K.sort_indices()
+            dK = lsa_hip.CsrMatrix.from_scipy(ctx, K.astype(np.float64))
+            f = lsa_hip.NdLu(ctx, dK, 0)
+            neg, zero, _pos = f.inertia()
+            del f, dK
+            if zero == 0:
+                return int(neg), float(shift)
+            shift += nudge * (attempt + 1)
+        raise RuntimeError(f"inertia count: A - sigma M stays singular around sigma = {shift:g}")
 
     def residuals(self) -> np.ndarray:
         """Relative residuals ``||A v - lam M v|| / (||A v|| + |lam| ||M v||)`` of the converged pairs, evaluated on the

@@ -480,6 +480,98 @@ int lsa_dense_tri_eigenvectors(int32_t n, const void* T, int32_t ldt, void* S, i
     return LSA_OK;
 }
 
+// ---- inertia of a dense real symmetric matrix (host): Bunch-Kaufman diagonal pivoting -------------------------------------
+// What SLEPc's spectrum slicing asks of the factorisation behind set_interval / iEpsWhich.ALL (Solver/utils.py:248-254): the
+// number of negative eigenvalues of A - sigma M = the number of eigenvalues of the definite pencil below sigma (Sylvester).  The
+// multifrontal LU is a block congruence C = L D L^T with D = diag(pivot blocks) when C is symmetric, so the inertia of C is the
+// sum over the tree nodes of the inertia of their (dense, symmetric) pivot blocks -- lsa_ndlu_inertia hands them to this routine.
+// A = P L D L^T P^T with 1 x 1 and 2 x 2 diagonal blocks in D (a 2 x 2 block of the algorithm has one eigenvalue of each sign);
+// the whole symmetric matrix is kept and updated (the pivot blocks of a forest are a few hundred rows; O(2 n^3 / 3)).
+// Pivots below tol_rel * max|A| count as zero.  Returns negative / zero / positive counts.
+int lsa_dense_sym_inertia(int32_t n, const double* A, int32_t lda, double tol_rel, int64_t* negative, int64_t* zero, int64_t* positive) {
+    if (n < 0 || (n > 0 && !A) || lda < std::max(1, n) || !negative || !zero || !positive) return LSA_ERR_ARG;
+    *negative = *zero = *positive = 0;
+    if (n == 0) return LSA_OK;
+    std::vector<double> w((size_t)n * n);
+    double amax = 0.0;
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            const double v = 0.5 * (A[(size_t)j * lda + i] + A[(size_t)i * lda + j]);  // (rounding leaves a computed inverse unsymmetric in the last bits)
+            if (!std::isfinite(v)) return LSA_ERR_NONFINITE;
+            w[(size_t)j * n + i] = v;
+            amax = std::max(amax, std::fabs(v));
+        }
+    auto W = [&](int i, int j) -> double& { return w[(size_t)j * n + i]; };
+    auto swap_sym = [&](int p, int q) {  // rows and columns p <-> q of the symmetric matrix
+        if (p == q) return;
+        for (int j = 0; j < n; ++j) std::swap(W(p, j), W(q, j));
+        for (int i = 0; i < n; ++i) std::swap(W(i, p), W(i, q));
+    };
+    const double alpha = (1.0 + std::sqrt(17.0)) / 8.0, tiny = std::max(tol_rel, 0.0) * amax;
+    int k = 0;
+    while (k < n) {
+        const double absakk = std::fabs(W(k, k));
+        int imax = k;
+        double colmax = 0.0;
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(W(i, k)) > colmax) colmax = std::fabs(W(i, k)), imax = i;
+        int step = 1;
+        if (std::max(absakk, colmax) <= tiny) {  // the whole column vanishes: a zero eigenvalue (to the tolerance)
+            ++*zero;
+            ++k;
+            continue;
+        }
+        if (absakk < alpha * colmax) {
+            double rowmax = 0.0;
+            for (int j = k; j < n; ++j)
+                if (j != imax) rowmax = std::max(rowmax, std::fabs(W(imax, j)));
+            if (absakk >= alpha * colmax * (colmax / rowmax)) {
+                // 1 x 1 pivot in place
+            } else if (std::fabs(W(imax, imax)) >= alpha * rowmax) {
+                swap_sym(k, imax);  // 1 x 1 pivot, the diagonal entry of row imax
+            } else {
+                swap_sym(k + 1, imax);  // 2 x 2 pivot: rows k and imax
+                step = 2;
+            }
+        }
+        if (step == 1) {
+            const double d = W(k, k);
+            if (std::fabs(d) <= tiny) ++*zero;
+            else if (d < 0.0) ++*negative;
+            else ++*positive;
+            if (std::fabs(d) > tiny) {
+                const double dinv = 1.0 / d;
+                for (int j = k + 1; j < n; ++j) {
+                    const double f = W(k, j) * dinv;
+                    if (f == 0.0) continue;
+                    for (int i = k + 1; i < n; ++i) W(i, j) -= W(i, k) * f;
+                }
+            }
+        } else {
+            // D = [a b; b c] with |b| the largest entry of its rows: det < 0, one eigenvalue of each sign
+            const double a = W(k, k), b = W(k + 1, k), c = W(k + 1, k + 1), det = a * c - b * b;
+            if (std::fabs(det) <= tiny * tiny) {
+                *zero += 2;
+            } else {
+                if (det < 0.0) {
+                    ++*negative;
+                    ++*positive;
+                } else if (a + c < 0.0) *negative += 2;
+                else *positive += 2;
+                for (int j = k + 2; j < n; ++j) {
+                    // column j of the update: W22 -= W21 D^-1 W12
+                    const double u = W(k, j), v = W(k + 1, j);
+                    const double f0 = (c * u - b * v) / det, f1 = (a * v - b * u) / det;
+                    if (f0 == 0.0 && f1 == 0.0) continue;
+                    for (int i = k + 2; i < n; ++i) W(i, j) -= W(i, k) * f0 + W(i, k + 1) * f1;
+                }
+            }
+        }
+        k += step;
+    }
+    return LSA_OK;
+}
+
 static_assert(sizeof(lsa_ks_result) == 56 && sizeof(lsa_ks_options) == 88, "lsa_ks_options layout is part of the C-ABI (tests/test_abi.py)");
 
 int lsa_krylov_solve(lsa_ctx* ctx, lsa_krylov* k, const lsa_ks_options* o, const void* v0, const double* mask, int32_t max_out, void* theta_out,

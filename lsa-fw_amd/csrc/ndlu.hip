@@ -1414,7 +1414,7 @@ struct lsa_ndlu {
     int32_t *d_dist_nodes = nullptr, *d_child_ptr = nullptr, *d_child_idx = nullptr;  // distributed nodes by level; children of every node
     void *d_xstage = nullptr, *d_xg = nullptr;          // staging of update rows on their way to distributed parents; own-row exchange buffer of the sweeps
     int64_t xstage_slot = 0;                            // scalars per rank of d_xstage
-    std::vector<int64_t> h_upd_off;                     // per node: its update matrix in the update arena (host copy of the plan)
+    std::vector<int64_t> h_upd_off, h_lfac_off;         // per node: its update matrix in the update arena, its packed L (host copies of the plan)
     int64_t chunk_node_upd_off(int32_t t) const { return h_upd_off[(size_t)t]; }
     int32_t* d_gell = nullptr;
     int32_t *d_idx = nullptr, *d_cmap = nullptr, *d_tiles = nullptr, *d_chunk_nodes = nullptr;
@@ -1552,6 +1552,7 @@ int nd_setup(lsa_ctx* ctx, lsa_ndlu* f, int64_t free_agreed = 0) {
     }
     f->xstage_slot = P.xstage_slot;
     f->h_upd_off = P.upd_off;
+    f->h_lfac_off = P.lfac_off;
     f->lfac_entries = P.lfac_entries;
     f->ufac_entries = P.ufac_entries;
     f->acc_entries = P.acc_entries;
@@ -2535,6 +2536,35 @@ int lsa_ndlu_solve_time(lsa_ctx* ctx, lsa_ndlu* f, const lsa_vec* b, lsa_vec* x,
     float ms = 0.f;
     LSA_HIP_CHECK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     *avg_ms = (double)ms / iters;
+    return LSA_OK;
+}
+
+// Inertia of a REAL SYMMETRIC C from its factorisation: the multifrontal elimination is a block congruence C = L D L^T with D
+// the pivot blocks (however each of them was inverted), so inertia(C) = sum over the tree nodes of the inertia of their pivot
+// blocks = of the inverses the factors hold (first m rows of the packed L).  The blocks come to the host one by one
+// (lsa_dense_sym_inertia: Bunch-Kaufman, O(m^3) each): meant for the interval sweep behind iEpsWhich.ALL on Hermitian
+// problems (Solver/utils.py:248-254), whose pivot blocks are a few hundred rows, not for the 3D fronts of the flow problems.
+int lsa_ndlu_inertia(lsa_ctx* ctx, lsa_ndlu* f, int64_t* negative, int64_t* zero, int64_t* positive) {
+    if (!ctx || !f || !negative || !zero || !positive) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_inertia: null argument");
+    if (f->dtype != LSA_F64) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_inertia: needs real factors (a real symmetric matrix)");
+    if (f->S.nranks != 1) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_inertia: not available for a forest cut over ranks");
+    *negative = *zero = *positive = 0;
+    const NdSymbolic& S = f->S;
+    std::vector<double> blk;
+    LSA_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int32_t t = 0; t < S.nt; ++t) {
+        const int32_t m = S.m[(size_t)t];
+        if (m <= 0) continue;
+        blk.resize((size_t)m * m);
+        // (the plan's offset of the node's packed L: recomputed as nd_memory_plan lays it out -- f x m scalars per node, in node order)
+        LSA_HIP_CHECK(ctx, hipMemcpy(blk.data(), (const double*)f->d_lfac + f->h_lfac_off[(size_t)t], (size_t)m * m * sizeof(double), hipMemcpyDeviceToHost));
+        int64_t ng = 0, ze = 0, ps = 0;
+        const int rc = lsa_dense_sym_inertia(m, blk.data(), m, 1e-13, &ng, &ze, &ps);
+        if (rc != LSA_OK) return lsa_set_error(ctx, rc, "lsa_ndlu_inertia: the pivot block of tree node %d holds non-finite values", t);
+        *negative += ng;
+        *zero += ze;
+        *positive += ps;
+    }
     return LSA_OK;
 }
 

@@ -136,6 +136,8 @@ SIGNATURES = {
     "lsa_nd_analyse_tree": (ctypes.c_int, [_I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _I32, _PP]),
     "lsa_nd_sym_export_dist": (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "lsa_nd_sym_export_top": (ctypes.c_int, [_P, _P, _P, _P, _P]),
+    "lsa_ndlu_inertia": (ctypes.c_int, [_P, _P, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
+    "lsa_dense_sym_inertia": (ctypes.c_int, [_I32, _P, _I32, _DBL, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64)]),
     "lsa_nd_sym_error": (ctypes.c_char_p, [_P]),
     "lsa_nd_sym_destroy": (None, [_P]),
     "lsa_nd_sym_info": (ctypes.c_int, [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I64),
@@ -669,6 +671,13 @@ class NdLu:
         ms = _DBL(0.0)
         self.ctx.check(self.ctx._lib.lsa_ndlu_solve_time(self.ctx.handle, self.handle, b.handle, x.handle, int(iters), ctypes.byref(ms)))
         return ms.value
+
+    def inertia(self) -> tuple[int, int, int]:
+        """(negative, zero, positive) eigenvalue counts of a REAL SYMMETRIC matrix from its factors (``lsa_ndlu_inertia``): for
+        ``C = A - sigma M`` of a definite pencil, ``negative`` is the number of eigenvalues below ``sigma``."""
+        ng, ze, ps = _I64(0), _I64(0), _I64(0)
+        self.ctx.check(self.ctx._lib.lsa_ndlu_inertia(self.ctx.handle, self.handle, ctypes.byref(ng), ctypes.byref(ze), ctypes.byref(ps)))
+        return ng.value, ze.value, ps.value
 
     def __del__(self):
         if getattr(self, "handle", None) and getattr(self.ctx, "handle", None):

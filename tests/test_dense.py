@@ -94,3 +94,36 @@ def test_reordering_and_triangular_eigenvectors():
     X = Q @ S  # eigenvectors of A
     assert np.abs(A @ X - X * np.diag(T)[None, :]).max() <= 1e-11 * np.abs(A).max()
     assert lib.lsa_dense_schur(-1, None, 1, None, 1) != 0  # bad arguments are refused, not dereferenced
+
+
+@pytest.mark.parametrize("n,kind", [(1, "pos"), (2, "indef"), (7, "random"), (40, "random"), (150, "random"), (60, "zero-diagonal"), (33, "singular")])
+def test_symmetric_inertia_matches_the_eigenvalue_signs(n, kind):
+    """``lsa_dense_sym_inertia`` (Bunch-Kaufman diagonal pivoting on the host: what ``lsa_ndlu_inertia`` applies to the pivot
+    blocks of the forest) against the signs of numpy's eigenvalues: definite, indefinite, a saddle-point block with a zero diagonal
+    (2 x 2 pivots), a singular matrix; both triangles are read and symmetrised (a computed inverse is unsymmetric in the last bits)."""
+    import ctypes
+
+    lib = lsa_hip.load_library()
+    rng = np.random.default_rng(n)
+    if kind == "pos":
+        A = np.array([[3.0]])
+    elif kind == "indef":
+        A = np.array([[0.0, 2.0], [2.0, 0.0]])
+    elif kind == "zero-diagonal":
+        B = rng.standard_normal((n // 3, n - n // 3))
+        K = rng.standard_normal((n - n // 3, n - n // 3))
+        A = np.block([[K @ K.T + np.eye(n - n // 3), B.T], [B, np.zeros((n // 3, n // 3))]])
+    elif kind == "singular":
+        X = rng.standard_normal((n, n - 3))
+        A = X @ np.diag(rng.standard_normal(n - 3)) @ X.T
+    else:
+        X = rng.standard_normal((n, n))
+        A = X + X.T
+    w = np.linalg.eigvalsh(A)
+    scale = np.abs(w).max()
+    want = (int(np.sum(w < -1e-10 * scale)), int(np.sum(np.abs(w) <= 1e-10 * scale)), int(np.sum(w > 1e-10 * scale)))
+    noisy = np.asfortranarray(A + 1e-16 * scale * rng.standard_normal(A.shape))  # (not exactly symmetric)
+    ng, ze, ps = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    assert lib.lsa_dense_sym_inertia(n, noisy.ctypes.data_as(ctypes.c_void_p), n, 1e-12, ctypes.byref(ng), ctypes.byref(ze), ctypes.byref(ps)) == 0
+    assert (ng.value, ze.value, ps.value) == want
+    assert lib.lsa_dense_sym_inertia(-1, None, 1, 0.0, ctypes.byref(ng), ctypes.byref(ze), ctypes.byref(ps)) != 0

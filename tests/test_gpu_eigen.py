@@ -387,6 +387,8 @@ def test_all_eigenvalues_in_an_interval():
     got = np.array([solver.solver.get_eigenvalue(i) for i in range(solver.solver.get_num_converged())])
     want = exact[(exact >= 7.5) & (exact <= 19.5)]
     assert len(got) == len(want) == 12 and np.allclose(got, want, atol=1e-8) and np.all(np.diff(got) > 0)
+    # ... and complete by count, as with SLEPc's slicing: the inertia of A - sigma I at the end points (lsa_ndlu_inertia)
+    assert solver.solver.stats["interval_expected"] == 12 and solver.solver.stats["interval_complete"] == 1
     for i in range(len(got)):  # eigenvectors come with the values
         v = solver.solver.get_eigenvector_array(i)
         assert np.linalg.norm(A @ v - got[i] * v) <= 1e-7
@@ -400,9 +402,10 @@ def test_all_eigenvalues_in_an_interval():
     ms.solver.solve()
     gm = np.array([ms.solver.get_eigenvalue(i) for i in range(ms.solver.get_num_converged())])
     assert len(gm) == 4 and np.allclose(gm[:3], ref["published"], atol=5e-7)
+    assert ms.solver.stats["interval_expected"] == 4 and ms.solver.stats["interval_complete"] == 1  # (generalised: inertia of A - sigma M)
     assert abs(gm[3] - fem.membrane_analytic(4)[3]) <= 2e-3
     # a double eigenvalue (two shifts return differently rotated bases of its eigenspace: counted twice, not three or four
-    # times) beside simple ones; the sweep says that its completeness is heuristic
+    # times) beside simple ones; the inertia counts say that all eight were found
     import logging
 
     D = np.diag([1.0, 2.0, 3.0, 5.0, 5.0, 6.0, 7.5, 7.5, 9.0, 12.0] + list(np.linspace(20.0, 60.0, 30)))
@@ -425,6 +428,23 @@ def test_all_eigenvalues_in_an_interval():
     assert np.allclose(gd, [2.0, 3.0, 5.0, 5.0, 6.0, 7.5, 7.5, 9.0], atol=1e-8), gd
     Vd = np.column_stack([dbl.solver.get_eigenvector_array(i) for i in range(len(gd))])
     assert np.linalg.matrix_rank(Vd, tol=1e-6) == len(gd)  # the copies of a double eigenvalue are independent vectors
+    assert any("complete" in r.getMessage() for r in records) and dbl.solver.stats["interval_expected"] == 8 and dbl.solver.stats["interval_complete"] == 1
+    # a complex Hermitian matrix has no real symmetric factorisation to count with: the sweep runs, and says that it is heuristic
+    rngc = np.random.default_rng(9)
+    Uc = np.linalg.qr(rngc.standard_normal((30, 30)) + 1j * rngc.standard_normal((30, 30)))[0]
+    Ah = Uc @ np.diag(np.arange(1.0, 31.0)) @ Uc.conj().T
+    Ah = 0.5 * (Ah + Ah.conj().T)
+    ch = EigenSolver(Ah, None, EigensolverConfig(problem_type=iEpsProblemType.HEP, num_eig=3, atol=1e-10, ncv=12))
+    ch.solver.set_interval(4.5, 9.5)
+    ch.solver.set_which_eigenpairs(iEpsWhich.ALL)
+    records.clear()
+    logging.getLogger("Solver.utils").addHandler(handler)
+    try:
+        ch.solver.solve()
+    finally:
+        logging.getLogger("Solver.utils").removeHandler(handler)
+    gc_ = np.array([ch.solver.get_eigenvalue(i) for i in range(ch.solver.get_num_converged())])
+    assert np.allclose(gc_, [5.0, 6.0, 7.0, 8.0, 9.0], atol=1e-8) and ch.solver.stats["interval_complete"] == 0
     assert any("heuristic" in r.getMessage() for r in records)
     # not Hermitian: refused like SLEPc; no interval: refused
     bad = EigenSolver(A + np.triu(np.ones((40, 40)), 2), None, EigensolverConfig(problem_type=iEpsProblemType.NHEP, num_eig=2, atol=1e-8))

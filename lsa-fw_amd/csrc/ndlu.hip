@@ -2024,19 +2024,26 @@ int nd_numeric(lsa_ctx* ctx, lsa_ndlu* f, const lsa_mat* C) {
         // their owner -- slot by slot (fixed order of the sums: the replicated pivot blocks stay bitwise alike).
         for (const auto& step : L.xsteps) {
             T* stage = (T*)f->d_xstage;
+            // (the slots of a step are as wide as its largest piece, not as the buffer allows: the exchange moves what travels)
+            int64_t stride = 0;
+            for (int r = 0; r < S.nranks; ++r) {
+                const NdChunk::XPiece& pc = step[(size_t)r];
+                if (pc.nrows > 0) stride = std::max(stride, (int64_t)pc.nrows * (S.f[(size_t)pc.child] - S.m[(size_t)pc.child]));
+            }
+            if (stride == 0) continue;
             const NdChunk::XPiece& mine = step[(size_t)S.rank];
             if (mine.nrows > 0) {
                 const int32_t bc = S.f[(size_t)mine.child] - S.m[(size_t)mine.child];
                 const int64_t src_off = f->chunk_node_upd_off(mine.child) + (int64_t)(mine.row0 - S.brow0[(size_t)mine.child]) * bc;
-                LSA_HIP_CHECK(ctx, hipMemcpyAsync(stage + (size_t)S.rank * (size_t)f->xstage_slot, upd + src_off, (size_t)mine.nrows * (size_t)bc * sizeof(T),
+                LSA_HIP_CHECK(ctx, hipMemcpyAsync(stage + (size_t)S.rank * (size_t)stride, upd + src_off, (size_t)mine.nrows * (size_t)bc * sizeof(T),
                                                   hipMemcpyDeviceToDevice, st));
             }
-            LSA_CHECK(k_allgather_inplace(ctx, stage, (size_t)f->xstage_slot * sizeof(T)));
+            LSA_CHECK(k_allgather_inplace(ctx, stage, (size_t)stride * sizeof(T)));
             for (int r = 0; r < S.nranks; ++r) {
                 const NdChunk::XPiece& pc = step[(size_t)r];
                 if (pc.nrows <= 0) continue;
                 hipLaunchKernelGGL((nd_extend_add_staged_kernel<T>), dim3((pc.nrows + 15) / 16), dim3(256), 0, st, f->d_nodes, f->d_cmap, front,
-                                   (const T*)(stage + (size_t)r * (size_t)f->xstage_slot), pc.child, pc.row0, pc.nrows);
+                                   (const T*)(stage + (size_t)r * (size_t)stride), pc.child, pc.row0, pc.nrows);
             }
         }
         if (L.max_m >= f->tp_min) LSA_CHECK(launch_level_tp<T>(ctx, f, L, tiny2));

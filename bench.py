@@ -407,7 +407,8 @@ def roofline_3d(args, device):
     return out
 
 
-def run_sharded_children(args, rank: int, world: int, local_rank: int):
+def run_sharded_children(args, rank: int, world: int, local_rank: int, case: str | None = None, k: int | None = None, ncv: int | None = None,
+                         timeout: float | None = None, port_offset: int = 37, steps: int | None = None):
     """config.sharded at N > 1: every rank starts ONE child process (this file with --sharded-child) that joins a process
     group of its own on another port and solves the sharded problem together with the other ranks' children.  The parent waits
     at most --sharded-timeout seconds and then ends exactly the child it started: whatever the never-exercised multi-rank RCCL
@@ -416,20 +417,23 @@ def run_sharded_children(args, rank: int, world: int, local_rank: int):
 
     env = dict(os.environ)
     env.update({"RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_RANK": str(local_rank), "MASTER_ADDR": os.environ.get("MASTER_ADDR", "127.0.0.1"),
-                "MASTER_PORT": str(int(os.environ.get("MASTER_PORT", "29500")) + 37)})
+                "MASTER_PORT": str(int(os.environ.get("MASTER_PORT", "29500")) + port_offset)})
     for var in ("TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT", "TORCHELASTIC_MAX_RESTARTS", "TORCHELASTIC_USE_AGENT_STORE"):
         env.pop(var, None)  # the child group has its own TCP store (rank 0's child hosts it)
-    cmd = [sys.executable, str(ROOT / "bench.py"), "--sharded-child", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
-           "--case", args.sharded_case, "--k", str(args.k), "--ncv", str(args.ncv), "--atol", str(args.atol), "--no-roofline", "--no-cpu-baseline"]
+    case = case or args.sharded_case
+    limit = args.sharded_timeout if timeout is None else timeout
+    cmd = [sys.executable, str(ROOT / "bench.py"), "--sharded-child", "--gpus", str(world), "--steps", str(args.steps if steps is None else steps),
+           "--warmup", str(args.warmup), "--case", case, "--k", str(k or args.k), "--ncv", str(ncv or args.ncv), "--atol", str(args.atol), "--no-roofline",
+           "--no-cpu-baseline"]
     t0 = time.perf_counter()
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
-        so, se = proc.communicate(timeout=args.sharded_timeout)
+        so, se = proc.communicate(timeout=limit)
     except subprocess.TimeoutExpired:
         proc.kill()
         so, se = proc.communicate()
-        log(f"rank {rank}: the sharded child did not finish in {args.sharded_timeout:.0f} s and was ended; its last words: {se[-600:]!r}")
-        return {"error": f"no result within {args.sharded_timeout:.0f} s (child ended by its parent)", "seconds": time.perf_counter() - t0} if rank == 0 else None
+        log(f"rank {rank}: the sharded child ({case}) did not finish in {limit:.0f} s and was ended; its last words: {se[-600:]!r}")
+        return {"error": f"no result within {limit:.0f} s (child ended by its parent)", "seconds": time.perf_counter() - t0} if rank == 0 else None
     if rank != 0:
         return None
     lines = [ln for ln in so.splitlines() if ln.startswith("{")]
@@ -462,6 +466,8 @@ def main() -> None:
                          "row-sharded over the ranks as the headline")
     ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)  # child process of the config.sharded leg
     ap.add_argument("--sharded-timeout", type=float, default=270.0, help="seconds the sharded child processes may take (N > 1)")
+    ap.add_argument("--sharded-3d-case", default="C300k", help="N > 1: a second sharded leg on the 3D discretisation (config.sharded_3d; '' = none)")
+    ap.add_argument("--sharded-3d-timeout", type=float, default=200.0, help="seconds that leg may take")
     ap.add_argument("--sharded-case", default="S500k")
     ap.add_argument("--sweep", action="store_true", help="replicas layout: one shift of the Re-sweep table per rank instead of N copies of the Re = 50 solve")
     ap.add_argument("--no-other-pc", action="store_true", help="skip the single timed solve of the other inner-solver variant")
@@ -505,7 +511,7 @@ def main() -> None:
         from datetime import timedelta
 
         # (a child lives at most --sharded-timeout seconds; the parents wait for their children inside barriers of THEIR group)
-        pg_timeout = timedelta(seconds=120 if args.sharded_child else max(600.0, 2.0 * args.sharded_timeout + 120.0))
+        pg_timeout = timedelta(seconds=120 if args.sharded_child else max(600.0, 2.0 * (args.sharded_timeout + args.sharded_3d_timeout) + 120.0))
         if backend == "nccl":
             dist_mod.init_process_group("nccl", device_id=torch.device("cuda", dev), timeout=pg_timeout)
         else:
@@ -528,8 +534,9 @@ def main() -> None:
     sharded = layout == "sharded"
     if args.case is None:
         args.case = args.sharded_case if sharded else "S30k"
-    es = fem.cylinder_case(args.case)
-    sigma = SWEEP_SIGMAS[(2 + rank) % len(SWEEP_SIGMAS)] if args.sweep else SWEEP_SIGMAS[2]
+    cube = args.case.startswith("C")  # the 3D discretisation of BASELINE config 4 (the second sharded leg of an N > 1 run)
+    es = fem.cube_case(args.case) if cube else fem.cylinder_case(args.case)
+    sigma = complex(fem.SIGMA_CUBE) if cube else SWEEP_SIGMAS[(2 + rank) % len(SWEEP_SIGMAS)] if args.sweep else SWEEP_SIGMAS[2]
     log(f"rank {rank}/{world}: {args.case} n={es.n} nnz={es.A.nnz} sigma={sigma} layout={layout}")
 
     def barrier():
@@ -621,11 +628,16 @@ def main() -> None:
             total_pairs = float(p.item())
     lam_gpu = np.array([solver.solver.get_eigenvalue(i) for i in range(min(args.k, solver.solver.get_num_converged()))])
     solver.solver.release()
-    sharded_rec = None
+    sharded_rec = sharded_3d = None
     if world > 1 and not sharded and not args.sharded_child and not args.no_other_pc and args.sharded_timeout > 0:
         barrier()  # every parent has released its solver: the children find the GPUs free
         sharded_rec = run_sharded_children(args, rank, world, local_rank)
         barrier()
+        if args.sharded_3d_case and args.sharded_3d_timeout > 0:
+            # BASELINE config 4's discretisation over the ranks, top fronts of the forest distributed: informative only
+            sharded_3d = run_sharded_children(args, rank, world, local_rank, case=args.sharded_3d_case, k=10, ncv=40, timeout=args.sharded_3d_timeout,
+                                              port_offset=53, steps=min(args.steps, 3))
+            barrier()
     replicas = None
     if sharded and not args.no_other_pc:
         # secondary figure: the same N GPUs as N independent solves of the N = 1 workload (no data-path collective)
@@ -682,7 +694,8 @@ def main() -> None:
             "dtype": "c128",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.case}: synthetic 2D cylinder-flow Taylor-Hood pair, n={es.n}, nnz={es.A.nnz}, Re=50, "
+                "workload": f"{args.case}: synthetic " + ("3D unit-cube duct Taylor-Hood pair (BASELINE config 4's discretisation)" if cube else "2D cylinder-flow Taylor-Hood pair")
+                            + f", n={es.n}, nnz={es.A.nnz}, Re={10 if cube else 50}, "
                             f"sigma={sigma.real:g}{sigma.imag:+g}j, k={args.k}, ncv={args.ncv}, outer tol {args.atol:g}, "
                             + ("inner solves: exact nested-dissection multifrontal LU (verified against b - C x, GMRES-wrapped)" if args.pc == "lu"
                                else f"inner solves: ILU({args.ilu_levels})-GMRES({args.restart}), blocked SpTRSV"),
@@ -707,6 +720,7 @@ def main() -> None:
                 "speedup_over_one_gpu_same_workload": (total_pairs / elapsed) / (replicas["eigenpairs_per_s"] / world)
                 if (sharded and replicas and "eigenpairs_per_s" in replicas) else None,
                 "sharded": sharded_rec,
+                "sharded_3d": sharded_3d,
                 "setup": setup,
                 "prepare_ms": setup.get("prepare_ms"),
                 "cold_first_solve_ms": setup.get("cold_first_solve_ms"),

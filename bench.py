@@ -730,6 +730,11 @@ def main() -> None:
                 "op_applies_per_solve": stats.get("op_applies"),
                 "gmres_iters_per_solve": stats.get("gmres_iters"),
                 "seconds_factor": stats.get("seconds_factor"),
+                # phases of the last timed solve inside the library's Krylov-Schur loop: Arnoldi steps (GPU), the host's dense
+                # algebra on the projected matrix (Schur forms, reordering), basis updates and Ritz vectors (GPU)
+                "seconds_expand": stats.get("seconds_expand"),
+                "seconds_dense": stats.get("seconds_dense"),
+                "seconds_restart": stats.get("seconds_restart"),
             },
         }
         if world == 1 and not args.no_other_pc:

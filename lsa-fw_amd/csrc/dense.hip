@@ -57,6 +57,17 @@ inline Z zsqrt(Z a) {
 
 // rotation R = [c s; -conj(s) c] (c real) with R [f; g] = [r; 0]
 inline void givens(Z f, Z g, double& c, Z& s, Z& r) {
+    // both entries of ordinary size (LAPACK 3.10's zlartg, unscaled branch): one square root and one division on the chain
+    // from one rotation of a QR sweep to the next
+    const double f2 = abs2(f), g2 = abs2(g);
+    if (f2 > 1e-200 && f2 < 1e200 && g2 > 1e-200 && g2 < 1e200) {
+        const double h2 = f2 + g2, d = std::sqrt(f2 * h2), id = 1.0 / d;
+        c = f2 * id;
+        const Z fd = id * f;
+        s = fd * conj(g);
+        r = (h2 * id) * f;
+        return;
+    }
     const double ng = zabs(g);
     if (ng == 0.0) {
         c = 1.0;
@@ -110,7 +121,7 @@ inline void rot_cols(const Mat& A, int p, int q, int i0, int i1, double c, Z s) 
 // Row-oriented, from the bottom: row r keeps only its entry in column r - 1 of those left of the diagonal, by a Householder
 // reflector on the coordinates 0 .. r - 1.  Rows that conform already cost nothing, so the matrix of a Krylov-Schur restart
 // (triangle of k rows, one full row, Hessenberg below) costs the reduction of a k x k matrix, not of the whole.
-void hessenberg_reduce(int n, const Mat& A, const Mat& Q) {
+__attribute__((always_inline)) inline void hessenberg_reduce_body(int n, const Mat& A, const Mat& Q) {
     std::vector<Z> v((size_t)n), w((size_t)n);
     for (int r = n - 1; r >= 2; --r) {
         // x = A[r, 0:r]: wanted x^T P = gamma e_{r-1}^T with P = I - tp v v^H on the coordinates 0 .. r - 1
@@ -156,10 +167,37 @@ void hessenberg_reduce(int n, const Mat& A, const Mat& Q) {
         }
     }
 }
+// the same body built for the host's vector width (the loops are complex axpys and dot products down contiguous columns)
+void hessenberg_reduce_generic(int n, const Mat& A, const Mat& Q) { hessenberg_reduce_body(n, A, Q); }
+#if !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("avx2,fma"))) void hessenberg_reduce_avx2(int n, const Mat& A, const Mat& Q) { hessenberg_reduce_body(n, A, Q); }
+__attribute__((target("avx512f,avx512dq,fma"), min_vector_width(512))) void hessenberg_reduce_avx512(int n, const Mat& A, const Mat& Q) {
+    hessenberg_reduce_body(n, A, Q);
+}
+#endif
+void hessenberg_reduce(int n, const Mat& A, const Mat& Q) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    __builtin_cpu_init();
+    static const char* isa = getenv("LSA_DENSE_ISA");
+    static const bool want512 = !isa || !strcmp(isa, "avx512"), want256 = want512 || !strcmp(isa, "avx2");
+    static const int level = (want512 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("fma")) ? 2
+                             : (want256 && __builtin_cpu_supports("avx2") && __builtin_cpu_supports("fma"))                                     ? 1
+                                                                                                                                                 : 0;
+    if (level == 2) return hessenberg_reduce_avx512(n, A, Q);
+    if (level == 1) return hessenberg_reduce_avx2(n, A, Q);
+#endif
+    hessenberg_reduce_generic(n, A, Q);
+}
 
 // [x; y] <- R [x; y] element-wise on split (real / imaginary) contiguous arrays: the inner loops of the QR sweeps.
-// R = [c s; -conj(s) c].  Two builds of the same body: the portable one and one for AVX2 + FMA hosts, picked at run time.
+// R = [c s; -conj(s) c].  The arrays start on 64-byte lines and `len` is a multiple of 8 (rows and columns of the work
+// layout are padded to that).  Two builds of the same body: the portable one and one for AVX2 + FMA hosts, picked at run time.
 #define LSA_ROT_BODY                                                     \
+    xr = (double*)__builtin_assume_aligned(xr, 64);                      \
+    xi = (double*)__builtin_assume_aligned(xi, 64);                      \
+    yr = (double*)__builtin_assume_aligned(yr, 64);                      \
+    yi = (double*)__builtin_assume_aligned(yi, 64);                      \
+    len &= ~7; /* callers pass whole 64-byte lines: no peeled head, no scalar tail */ \
     for (int j = 0; j < len; ++j) {                                      \
         const double ar = xr[j], ai = xi[j], br = yr[j], bi = yi[j];     \
         xr[j] = c * ar + (sr * br - si * bi);                            \
@@ -184,6 +222,21 @@ __attribute__((target("avx512f,avx512dq,fma"), min_vector_width(512))) void rot_
 #endif
 #undef LSA_ROT_BODY
 typedef void (*rot_pair_fn)(int, double*, double*, double*, double*, double, double, double);
+
+// columns k, k + 1 of one row of the split planes (pr, pi point at column k): [a b] <- [a b] R^H, R^H = [c -s; conj(s) c], i.e.
+// a' = c a + conj(s) b, b' = c b - s a.  The two columns are neighbours in memory: one 16-byte vector per plane, with
+// cc = {c, c}, srn = {Re s, -Re s}, sii = {Im s, Im s}.
+typedef double v2d __attribute__((ext_vector_type(2)));
+inline void rot_cols2(double* pr, double* pi, v2d cc, v2d srn, v2d sii) {
+    v2d vr, vi;
+    memcpy(&vr, pr, sizeof vr);
+    memcpy(&vi, pi, sizeof vi);
+    const v2d wr = __builtin_shufflevector(vr, vr, 1, 0), wi = __builtin_shufflevector(vi, vi, 1, 0);
+    const v2d nr = cc * vr + (srn * wr + sii * wi);
+    const v2d ni = cc * vi + (srn * wi - sii * wr);
+    memcpy(pr, &nr, sizeof nr);
+    memcpy(pi, &ni, sizeof ni);
+}
 rot_pair_fn pick_rot_pair() {
 #if !defined(__HIP_DEVICE_COMPILE__)
     __builtin_cpu_init();
@@ -208,9 +261,9 @@ rot_pair_fn pick_rot_pair() {
 bool hessenberg_qr(int n, const Mat& H, const Mat& Q) {
     static const rot_pair_fn rot_pair = pick_rot_pair();
     const double ulp = 2.220446049250313e-16, smlnum = 2.2250738585072014e-308 * (n / ulp);
-    const int ld = (n + 3) & ~3;
-    std::vector<double> store((size_t)4 * ld * std::max(n, 1));
-    double* hr = store.data();            // hr[i * ld + j] = Re H(i, j)
+    const int ld = (n + 7) & ~7;  // whole 64-byte lines per row of H / column of Q; the padding holds zeros and stays zero
+    std::vector<double> store((size_t)4 * ld * std::max(n, 1) + 8, 0.0);
+    double* hr = (double*)(((uintptr_t)store.data() + 63) & ~(uintptr_t)63);  // hr[i * ld + j] = Re H(i, j)
     double* hi = hr + (size_t)ld * n;
     double* qr = hi + (size_t)ld * n;     // qr[j * ld + i] = Re Q(i, j)
     double* qi = qr + (size_t)ld * n;
@@ -286,27 +339,23 @@ bool hessenberg_qr(int n, const Mat& H, const Mat& Q) {
             rc[(size_t)k] = c;
             rsr[(size_t)k] = s.re;
             rsi[(size_t)k] = s.im;
+            // rows k, k + 1 <- R rows, from the 64-byte line that holds column k to the end of the padded row (contiguous whole
+            // vectors; left of column k - 1 both rows hold zeros, and column k - 1 -- the bulge -- gets its exact values below)
+            const int k0 = k & ~7;
+            rot_pair(ld - k0, hr + (size_t)k * ld + k0, hi + (size_t)k * ld + k0, hr + (size_t)(k + 1) * ld + k0, hi + (size_t)(k + 1) * ld + k0, c, s.re, s.im);
             if (k > l) {
                 seth(k, k - 1, r);
                 seth(k + 1, k - 1, {0.0, 0.0});
             }
-            // rows k, k + 1 <- R rows, columns k .. n - 1 (contiguous)
-            rot_pair(n - k, hr + (size_t)k * ld + k, hi + (size_t)k * ld + k, hr + (size_t)(k + 1) * ld + k, hi + (size_t)(k + 1) * ld + k, c, s.re, s.im);
             // columns k, k + 1 <- columns R^H, rows l .. min(k + 2, ihi) (the window; strided).  With R^H = [c -s; conj(s) c]:
             // new_k = c a + conj(s) b,  new_k1 = c b - s a
             const int i1 = std::min(k + 2, ihi);
-            for (int i = l; i <= i1; ++i) {
-                double* pr = hr + (size_t)i * ld + k;
-                double* pi = hi + (size_t)i * ld + k;
-                const double ar = pr[0], ai = pi[0], br = pr[1], bi = pi[1];
-                pr[0] = c * ar + (s.re * br + s.im * bi);
-                pi[0] = c * ai + (s.re * bi - s.im * br);
-                pr[1] = c * br - (s.re * ar - s.im * ai);
-                pi[1] = c * bi - (s.re * ai + s.im * ar);
-            }
+            const v2d cc = {c, c}, srn = {s.re, -s.re}, sii = {s.im, s.im};
+            for (int i = l; i <= i1; ++i) rot_cols2(hr + (size_t)i * ld + k, hi + (size_t)i * ld + k, cc, srn, sii);
             // columns k, k + 1 of Q <- columns R^H (contiguous): in the form of rot_pair, [x; y] <- [c conj(s); -s c] [x; y],
-            // i.e. the rotation with s replaced by conj(s)
-            rot_pair(n, qr + (size_t)k * ld, qi + (size_t)k * ld, qr + (size_t)(k + 1) * ld, qi + (size_t)(k + 1) * ld, c, s.re, -s.im);
+            // i.e. the rotation with s replaced by conj(s).  (Tried: Q's rotations of a whole sweep after the sweep, eight rows at
+            // a time with column k carried in registers -- half the loads and stores, and slower: 2.16-2.28 against 1.99-2.06 ms.)
+            rot_pair(ld, qr + (size_t)k * ld, qi + (size_t)k * ld, qr + (size_t)(k + 1) * ld, qi + (size_t)(k + 1) * ld, c, s.re, -s.im);
             if (k + 1 < ihi) {
                 x = h(k + 1, k);
                 y = h(k + 2, k);
@@ -316,16 +365,8 @@ bool hessenberg_qr(int n, const Mat& H, const Mat& Q) {
         for (int i0 = 0; i0 < l; i0 += 4) {
             const int ni = std::min(4, l - i0);
             for (int k = l; k < ihi; ++k) {
-                const double c = rc[(size_t)k], sr = rsr[(size_t)k], si = rsi[(size_t)k];
-                for (int u = 0; u < ni; ++u) {
-                    double* pr = hr + (size_t)(i0 + u) * ld + k;
-                    double* pi = hi + (size_t)(i0 + u) * ld + k;
-                    const double ar = pr[0], ai = pi[0], br = pr[1], bi = pi[1];
-                    pr[0] = c * ar + (sr * br + si * bi);
-                    pi[0] = c * ai + (sr * bi - si * br);
-                    pr[1] = c * br - (sr * ar - si * ai);
-                    pi[1] = c * bi - (sr * ai + si * ar);
-                }
+                const v2d cc = {rc[(size_t)k], rc[(size_t)k]}, srn = {rsr[(size_t)k], -rsr[(size_t)k]}, sii = {rsi[(size_t)k], rsi[(size_t)k]};
+                for (int u = 0; u < ni; ++u) rot_cols2(hr + (size_t)(i0 + u) * ld + k, hi + (size_t)(i0 + u) * ld + k, cc, srn, sii);
             }
         }
     }

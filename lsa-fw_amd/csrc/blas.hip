@@ -264,7 +264,26 @@ __global__ __launch_bounds__(kThreads) void cgs_dot_kernel(int64_t n, int j, int
     for (int c = 0; c < kColTile; ++c) acc[c] = scalar_traits<T>::zero();
     const int nc = (j - c0 < kColTile) ? (j - c0) : kColTile;
     if (nc == kColTile) {
-        for (int64_t i = r0 + threadIdx.x; i < r1; i += kThreads) {
+        int64_t i = r0 + threadIdx.x;
+        {
+            // two rows per thread and trip: 2 x kColTile loads in flight per lane (12.5 -> 10.0 us per launch at 30 k rows, j
+            // averaged over a restart cycle; the order of the additions into acc[c] is that of a one-row loop)
+            for (; i + kThreads < r1; i += 2 * kThreads) {
+                const T wa = w[i], wb = w[i + kThreads];
+                T va[kColTile], vb[kColTile];
+#pragma unroll
+                for (int c = 0; c < kColTile; ++c) {
+                    va[c] = V[i + (int64_t)(c0 + c) * ldv];
+                    vb[c] = V[i + kThreads + (int64_t)(c0 + c) * ldv];
+                }
+#pragma unroll
+                for (int c = 0; c < kColTile; ++c) {
+                    fma_conj_acc(acc[c], va[c], wa);
+                    fma_conj_acc(acc[c], vb[c], wb);
+                }
+            }
+        }
+        for (; i < r1; i += kThreads) {
             const T wv = w[i];
 #pragma unroll
             for (int c = 0; c < kColTile; ++c) fma_conj_acc(acc[c], V[i + (int64_t)(c0 + c) * ldv], wv);
@@ -311,7 +330,11 @@ __global__ __launch_bounds__(kThreads) void cgs_dot_kernel(int64_t n, int j, int
 
 // w -= V h.  Workgroup = 64 rows; four lanes share a row (lane q of the four takes the columns c = q mod 4) so that a thread
 // keeps a quarter of the row's loads in flight at once: with a thread per row the j loads of a row are a chain of j / 4
-// dependent batches (17.8 us per launch at 30 k rows and j = 60, on half of the CUs).
+// dependent batches (17.8 us per launch at 30 k rows and j = 60, on half of the CUs).  What a launch of this size costs is its
+// chain of dependent round trips (round 4: 12.6 -> 9.4 us): the first eight basis entries of a thread are requested before the
+// coefficients exist, the partial sums of the coefficients are requested sixteen at a time instead of one after the other, and
+// the last columns of a row are one more batch of predicated loads instead of a loop of single ones.  The additions keep their
+// order.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void cgs_axpy_kernel(int64_t n, int j, const T* __restrict__ V, int64_t ldv, const T* __restrict__ part,
                                                             int nchunks, int ldp, T* __restrict__ w, T* __restrict__ h_out,
@@ -319,12 +342,28 @@ __global__ __launch_bounds__(kThreads) void cgs_axpy_kernel(int64_t n, int j, co
                                                             double* __restrict__ chk_out) {
     __shared__ double wn[4];
     __shared__ T hs[kFuseCols];
+    // thread -> (row, column class): 16 consecutive lanes are 16 consecutive rows (one 256-byte segment per column), the four
+    // groups of 16 lanes of a wave are the four column classes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4;
+    const int64_t i = (int64_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
+    T v0[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v0[u] = (i < n && q + 4 * u < j) ? V[i + (int64_t)(q + 4 * u) * ldv] : scalar_traits<T>::zero();
     {
         // h[c] = sum over the chunks, in chunk order inside each of two interleaved halves, then half 0 + half 1
         const int c = threadIdx.x >> 1, half = threadIdx.x & 1;
         T acc = scalar_traits<T>::zero();
-        if (c < j)
-            for (int k = half; k < nchunks; k += 2) acc = s_add(acc, part[(int64_t)k * ldp + c]);
+        if (c < j) {
+            for (int k0 = half; k0 < nchunks; k0 += 32) {
+                T pv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) pv[u] = (k0 + 2 * u < nchunks) ? part[(int64_t)(k0 + 2 * u) * ldp + c] : scalar_traits<T>::zero();
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (k0 + 2 * u < nchunks) acc = s_add(acc, pv[u]);
+            }
+        }
         T other;
         if constexpr (sizeof(T) == 16) other = cplx{__shfl_xor(acc.re, 1), __shfl_xor(acc.im, 1)};
         else other = __shfl_xor(acc, 1);
@@ -340,22 +379,19 @@ __global__ __launch_bounds__(kThreads) void cgs_axpy_kernel(int64_t n, int j, co
         }
     }
     __syncthreads();
-    // thread -> (row, column class): 16 consecutive lanes are 16 consecutive rows (one 256-byte segment per column), the four
-    // groups of 16 lanes of a wave are the four column classes
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane >> 4;
-    const int64_t i = (int64_t)blockIdx.x * 64 + wave * 16 + (lane & 15);
     T acc = scalar_traits<T>::zero();
     if (i < n) {
-        int c = q;
-        for (; c + 28 < j; c += 32) {  // eight loads in flight
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (q + 4 * u < j) fma_acc(acc, hs[q + 4 * u], v0[u]);
+        for (int c = q + 32; c < j; c += 32) {
             T v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = V[i + (int64_t)(c + 4 * u) * ldv];
+            for (int u = 0; u < 8; ++u) v[u] = (c + 4 * u < j) ? V[i + (int64_t)(c + 4 * u) * ldv] : scalar_traits<T>::zero();
 #pragma unroll
-            for (int u = 0; u < 8; ++u) fma_acc(acc, hs[c + 4 * u], v[u]);
+            for (int u = 0; u < 8; ++u)
+                if (c + 4 * u < j) fma_acc(acc, hs[c + 4 * u], v[u]);
         }
-        for (; c < j; c += 4) fma_acc(acc, hs[c], V[i + (int64_t)c * ldv]);
     }
     // the four partial sums of a row sit 16 lanes apart: bring them together in class order (fixed order of additions)
     T a1, a2, a3;

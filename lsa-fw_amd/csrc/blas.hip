@@ -337,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void cgs_dot_kernel(int64_t n, int j, int
 // order.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void cgs_axpy_kernel(int64_t n, int j, const T* __restrict__ V, int64_t ldv, const T* __restrict__ part,
-                                                            int nchunks, int ldp, T* __restrict__ w, T* __restrict__ h_out,
+                                                            int nchunks, int ldp, const T* w_in, T* w, T* __restrict__ h_out,
                                                             double* __restrict__ nrm_part, const double* __restrict__ chk_part,
                                                             double* __restrict__ chk_out) {
     __shared__ double wn[4];
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(kThreads) void cgs_axpy_kernel(int64_t n, int j, co
     double nrm = 0.0;
     if (q == 0 && i < n) {
         const T tot = s_add(s_add(acc, a1), s_add(a2, a3));
-        const T r = s_sub(w[i], tot);
+        const T r = s_sub(w_in[i], tot);  // (w_in == w: in place; the tail form keeps the solve's result for its check)
         w[i] = r;
         nrm = s_abs2(r);
     }
@@ -438,6 +438,106 @@ __global__ __launch_bounds__(kThreads) void cgs_scale_kernel(int64_t n, const T*
     const double s = 1.0 / sqrt(tot);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = s_mul(s, x[i]);
+}
+
+// The last launch of an Arnoldi step of OP = C^-1 M in the tail form: what cgs_scale_kernel does (||w|| from the partials of the
+// second update, v_next = w / ||w||, the Hessenberg column), and in the same walk over the rows of the pattern M and C share
+//   t[r] <- (M v_next)[r]                       the next step's right-hand side,
+//   |t[r] - (C y)[r]|^2, |t[r]|^2               this step's check of the inner solve (t[r] read before it is replaced),
+// a sub-wave of LPR lanes per row exactly as spmv_subwave_kernel walks it: entries lane, lane + LPR, ... in order, butterfly over
+// the sub-wave -- the products are bit for bit those of k_spmv on v_next and y.  Up to three trips of a row are requested at once.
+// (Requesting the row's entries ahead of the norm's partial sums changed nothing: 12.4 / 13.2 us; the two gathers per entry bound it.)
+template <typename MT, int LPR>
+__global__ __launch_bounds__(kThreads) void cgs_tail_kernel(int32_t n, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                            const MT* __restrict__ mval, const cplx* __restrict__ cval,
+                                                            const cplx* __restrict__ w, const cplx* __restrict__ y,
+                                                            const double* __restrict__ nrm_part, int nparts, cplx* __restrict__ vnext, cplx* t,
+                                                            int j, const cplx* __restrict__ h1, const cplx* __restrict__ h2,
+                                                            cplx* __restrict__ hout, double* __restrict__ chk_part) {
+    __shared__ double smem[4];
+    __shared__ double tot_s;
+    __shared__ double csum[4][2];
+    double a = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += kThreads) a += nrm_part[k];
+    const double tsum = block_sum<double>(a, smem);
+    if (threadIdx.x == 0) tot_s = tsum;
+    __syncthreads();
+    const double tot = tot_s;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < j; c += kThreads) hout[c] = s_add(h1[c], h2[c]);
+        if (threadIdx.x == 0) s_from(hout[j], sqrt(tot), 0.0);
+    }
+    const double s = 1.0 / sqrt(tot);
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int32_t lane = (int32_t)(gid % LPR);
+    const int64_t row_stride = ((int64_t)gridDim.x * blockDim.x) / LPR;
+    double rw = 0.0, rb = 0.0;
+    for (int64_t row = gid / LPR; row < n; row += row_stride) {
+        const int32_t p0 = rp[row], p1 = rp[row + 1];
+        cplx am = cplx{0.0, 0.0}, ac = cplx{0.0, 0.0};
+        for (int32_t p = p0 + lane; p < p1; p += 3 * LPR) {
+            int32_t c[3];
+            MT vm[3];
+            cplx vc[3], xw[3], xy[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const bool in = p + u * LPR < p1;
+                c[u] = in ? ci[p + u * LPR] : 0;
+                vm[u] = in ? mval[p + u * LPR] : scalar_traits<MT>::zero();
+                vc[u] = in ? cval[p + u * LPR] : cplx{0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const bool in = p + u * LPR < p1;
+                xw[u] = in ? w[c[u]] : cplx{0.0, 0.0};
+                xy[u] = in ? y[c[u]] : cplx{0.0, 0.0};
+            }
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (p + u * LPR < p1) {
+                    fma_acc(am, vm[u], s_mul(s, xw[u]));
+                    fma_acc(ac, vc[u], xy[u]);
+                }
+        }
+#pragma unroll
+        for (int m = LPR / 2; m > 0; m >>= 1) {
+            am = s_add(am, cplx{__shfl_xor(am.re, m, 64), __shfl_xor(am.im, m, 64)});
+            ac = s_add(ac, cplx{__shfl_xor(ac.re, m, 64), __shfl_xor(ac.im, m, 64)});
+        }
+        if (lane == 0) {
+            const cplx told = t[row];
+            rw += s_abs2(s_sub(told, ac));
+            rb += s_abs2(told);
+            t[row] = am;
+            vnext[row] = s_mul(s, w[row]);
+        }
+    }
+    rw = wave_sum_dpp(rw);
+    rb = wave_sum_dpp(rb);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        csum[wave][0] = rw;
+        csum[wave][1] = rb;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) chk_part[2 * blockIdx.x + threadIdx.x] = (csum[0][threadIdx.x] + csum[1][threadIdx.x]) + (csum[2][threadIdx.x] + csum[3][threadIdx.x]);
+}
+
+// checks[2 s], checks[2 s + 1] = the sums of slot s's pairs (one workgroup per slot, fixed order)
+__global__ __launch_bounds__(kThreads) void cgs_tail_checks_kernel(int nparts, const double* __restrict__ parts, double* __restrict__ checks) {
+    __shared__ double smem[4];
+    const double* p = parts + (size_t)blockIdx.x * 2 * (size_t)nparts;
+    double a = 0.0, b = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += kThreads) {
+        a += p[2 * k];
+        b += p[2 * k + 1];
+    }
+    const double sa = block_sum<double>(a, smem);
+    const double sb = block_sum<double>(b, smem);
+    if (threadIdx.x == 0) {
+        checks[2 * blockIdx.x] = sa;
+        checks[2 * blockIdx.x + 1] = sb;
+    }
 }
 
 // ---- Ritz vectors: unit norm and a canonical phase for all columns in two launches --------------------------------------------
@@ -895,13 +995,82 @@ int k_cgs2_fused(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64
         hipLaunchKernelGGL((cgs_dot_kernel<T>), dgrid, dim3(kThreads), 0, ctx->stream, n, j, rpb, (const T*)V, ldv, (const T*)w, (T*)part1, kFuseCols,
                            (const T*)chk_b, (const T*)chk_z, chk_out ? chk_part : (double*)nullptr);
         hipLaunchKernelGGL((cgs_axpy_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, j, (const T*)V, ldv, (const T*)part1, nchunks, kFuseCols,
-                           (T*)w, (T*)h1, (double*)nullptr, (const double*)chk_part, chk_out);
+                           (const T*)w, (T*)w, (T*)h1, (double*)nullptr, (const double*)chk_part, chk_out);
         hipLaunchKernelGGL((cgs_dot_kernel<T>), dgrid, dim3(kThreads), 0, ctx->stream, n, j, rpb, (const T*)V, ldv, (const T*)w, (T*)part2, kFuseCols,
                            (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
         hipLaunchKernelGGL((cgs_axpy_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, j, (const T*)V, ldv, (const T*)part2, nchunks, kFuseCols,
-                           (T*)w, (T*)h2, nrm_part, (const double*)nullptr, (double*)nullptr);
+                           (const T*)w, (T*)w, (T*)h2, nrm_part, (const double*)nullptr, (double*)nullptr);
         hipLaunchKernelGGL((cgs_scale_kernel<T>), dim3(stream_blocks(ctx, n)), dim3(kThreads), 0, ctx->stream, n, (const T*)w, (const double*)nrm_part, blocks, (T*)vnext,
                            j, (const T*)h1, (const T*)h2, (T*)hcol_dev);
     });
     return check_launch(ctx, "cgs2_fused");
+}
+
+static bool cgs2_fused_shape(int64_t n, int j, int64_t* rpb_out) {
+    if (j <= 0 || j > kFuseCols || n <= 0) return false;
+    int64_t rpb = (n + kFuseChunks - 1) / kFuseChunks;
+    rpb = ((rpb + kThreads - 1) / kThreads) * kThreads;
+    if (rpb < 1024) rpb = 1024;
+    if (rpb > 4096) return false;
+    if (rpb_out) *rpb_out = rpb;
+    return true;
+}
+
+bool k_cgs2_tail_fits(lsa_ctx* ctx, int64_t n, int jmax, const lsa_mat* M, const lsa_mat* C) {
+    (void)ctx;
+    if (!M || !C || !cgs2_fused_shape(n, jmax, nullptr)) return false;
+    if (C->dtype != LSA_C128 || M->n != n || C->n != n || M->ncols != n || C->ncols != n || M->row0 != 0 || C->row0 != 0) return false;
+    // one pattern: the same device index arrays, or host copies that lsa_csr_axpby has found equal and made one object
+    const bool same_dev = M->rp == C->rp && M->ci == C->ci;
+    const bool same_host = M->h_rp.size() > 0 && M->h_rp.same_object(C->h_rp) && M->h_ci.same_object(C->h_ci);
+    if (M->nnz != C->nnz || !(same_dev || same_host)) return false;
+    return k_spmv_plain_subwave_lanes(M) == 16 && k_spmv_plain_subwave_lanes(C) == 16;
+}
+
+int k_cgs2_tail_parts(int64_t n) { return (int)((n * 16 + kThreads - 1) / kThreads); }
+
+int k_cgs2_fused_tail(lsa_ctx* ctx, int64_t n, int j, const void* V, int64_t ldv, const void* y, void* w, void* vnext, void* hcol_dev, void* work,
+                      const lsa_mat* M, const lsa_mat* C, void* t, double* tail_part) {
+    typedef cplx T;
+    int64_t rpb = 0;
+    if (!cgs2_fused_shape(n, j, &rpb)) return lsa_set_error(ctx, LSA_ERR_ARG, "k_cgs2_fused_tail: shape outside the fused form");
+    const int nchunks = (int)((n + rpb - 1) / rpb);
+    const int blocks = (int)((n + 63) / 64);
+    const size_t esz = 16;
+    char* p = (char*)work;
+    void* part1 = p;
+    p += esz * (size_t)kFuseChunks * kFuseCols;
+    void* part2 = p;
+    p += esz * (size_t)kFuseChunks * kFuseCols;
+    void* h1 = p;
+    p += esz * kFuseCols;
+    void* h2 = p;
+    p += esz * kFuseCols;
+    double* chk_part = (double*)p;
+    double* nrm_part = chk_part + 2 * kFuseChunks;
+    const dim3 dgrid(nchunks, (j + kColTile - 1) / kColTile);
+    hipLaunchKernelGGL((cgs_dot_kernel<T>), dgrid, dim3(kThreads), 0, ctx->stream, n, j, rpb, (const T*)V, ldv, (const T*)y, (T*)part1, kFuseCols,
+                       (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL((cgs_axpy_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, j, (const T*)V, ldv, (const T*)part1, nchunks, kFuseCols,
+                       (const T*)y, (T*)w, (T*)h1, (double*)nullptr, (const double*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL((cgs_dot_kernel<T>), dgrid, dim3(kThreads), 0, ctx->stream, n, j, rpb, (const T*)V, ldv, (const T*)w, (T*)part2, kFuseCols,
+                       (const T*)nullptr, (const T*)nullptr, (double*)nullptr);
+    hipLaunchKernelGGL((cgs_axpy_kernel<T>), dim3(blocks), dim3(kThreads), 0, ctx->stream, n, j, (const T*)V, ldv, (const T*)part2, nchunks, kFuseCols,
+                       (const T*)w, (T*)w, (T*)h2, nrm_part, (const double*)nullptr, (double*)nullptr);
+    const int tparts = k_cgs2_tail_parts(n);
+    if (M->dtype == LSA_C128)
+        hipLaunchKernelGGL((cgs_tail_kernel<cplx, 16>), dim3(tparts), dim3(kThreads), 0, ctx->stream, (int32_t)n, C->rp, C->ci, (const cplx*)M->val,
+                           (const cplx*)C->val, (const T*)w, (const T*)y, (const double*)nrm_part, blocks, (T*)vnext, (T*)t, j, (const T*)h1, (const T*)h2,
+                           (T*)hcol_dev, tail_part);
+    else
+        hipLaunchKernelGGL((cgs_tail_kernel<double, 16>), dim3(tparts), dim3(kThreads), 0, ctx->stream, (int32_t)n, C->rp, C->ci, (const double*)M->val,
+                           (const cplx*)C->val, (const T*)w, (const T*)y, (const double*)nrm_part, blocks, (T*)vnext, (T*)t, j, (const T*)h1, (const T*)h2,
+                           (T*)hcol_dev, tail_part);
+    return check_launch(ctx, "cgs2_fused_tail");
+}
+
+int k_cgs2_tail_checks(lsa_ctx* ctx, int nslots, int nparts, const double* tail_parts, double* checks) {
+    if (nslots <= 0) return LSA_OK;
+    hipLaunchKernelGGL(cgs_tail_checks_kernel, dim3(nslots), dim3(kThreads), 0, ctx->stream, nparts, tail_parts, checks);
+    return check_launch(ctx, "cgs2_tail_checks");
 }

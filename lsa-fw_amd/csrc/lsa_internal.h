@@ -231,6 +231,16 @@ int k_hess_column(lsa_ctx* ctx, int dtype, int j, const void* h1, const void* h2
 size_t k_cgs2_fused_work_bytes(lsa_ctx* ctx, int64_t n, int jmax);
 int k_cgs2_fused(lsa_ctx* ctx, int dtype, int64_t n, int j, const void* V, int64_t ldv, void* w, void* vnext, void* hcol_dev, void* work,
                  const void* chk_b, const void* chk_z, double* chk_out);
+// The same CGS2 for an Arnoldi step of OP = C^-1 M whose matrices share their index arrays, in five launches that leave y alone
+// and end with ONE kernel that normalises (v_next = w / ||w||, Hessenberg column), multiplies t <- M v_next for the next step
+// and checks this step's inner solve (|t - C y|^2, |t|^2 per workgroup into tail_part, summed by k_cgs2_tail_checks): 18
+// launches per step instead of 20.  The two products are bit for bit those of k_spmv.  Complex vectors only.
+bool k_cgs2_tail_fits(lsa_ctx* ctx, int64_t n, int jmax, const lsa_mat* M, const lsa_mat* C);
+int k_cgs2_tail_parts(int64_t n);  // workgroups of the tail kernel = (|t - C y|^2, |t|^2) pairs per step
+int k_cgs2_fused_tail(lsa_ctx* ctx, int64_t n, int j, const void* V, int64_t ldv, const void* y, void* w, void* vnext, void* hcol_dev, void* work,
+                      const lsa_mat* M, const lsa_mat* C, void* t, double* tail_part);
+int k_cgs2_tail_checks(lsa_ctx* ctx, int nslots, int nparts, const double* tail_parts, double* checks);
+int k_spmv_plain_subwave_lanes(const lsa_mat* A);  // spmv.hip
 // Out[:, 0:k] = V[:, 0:m] Q   (Q m x k column-major on the device, ldq)
 int k_basis_gemm(lsa_ctx* ctx, int dtype, int64_t n, int m, int k, const void* V, int64_t ldv, const void* Q, int ldq,
                  void* Out, int64_t ldo);

@@ -474,10 +474,16 @@ struct lsa_krylov {
     double* checks = nullptr;  // batch x 2: ||b - C x||^2, ||b||^2
     int32_t batch = 0;
     bool pipeline = false;
+    // tail form of a pipelined step (k_cgs2_fused_tail): the step's last launch also multiplies t = M v_{j+1} for the next step
+    // and leaves the pairs of this step's check of the inner solve; w2 takes the orthogonalised vector (w keeps the solve's result)
+    void* w2 = nullptr;
+    double* tail_parts = nullptr;  // batch x tail_nparts pairs
+    int32_t tail_nparts = 0;
+    int32_t t_for = -1;            // op->t holds M v_j for this j (valid inside one lsa_krylov_extend call), -1: nothing
 };
 
 static void krylov_free(lsa_krylov* k) {
-    for (void* p : {k->V, k->V2, k->w, k->qdev, k->Hdev, (void*)k->checks, (void*)k->imag2, k->xtmp, (void*)k->row_perm})
+    for (void* p : {k->V, k->V2, k->w, k->qdev, k->Hdev, (void*)k->checks, (void*)k->imag2, k->xtmp, (void*)k->row_perm, k->w2, (void*)k->tail_parts})
         if (p) (void)hipFree(p);
     k->ow.release();
     delete k;
@@ -928,21 +934,44 @@ int lsa_krylov_inject(lsa_ctx* ctx, lsa_krylov* k, int32_t j, const void* host_v
 // One batch of Arnoldi steps [j, j + nb) queued without a host round trip: operator apply by one exact LU solve, the
 // check b - C x of that solve, CGS2.  Everything the host decides on (the check, the Hessenberg column, breakdown) is read
 // back once per batch.
-static int krylov_enqueue_step(lsa_ctx* ctx, lsa_krylov* k, int32_t j, int32_t slot) {
+// the steps of a batch can take the tail form: a generalised problem whose M and C share their index arrays, whole on this rank,
+// plain forward products, nothing between the solve and the orthogonalisation (no projection mask, no refinement step)
+static bool krylov_tail_ok(lsa_ctx* ctx, const lsa_krylov* k) {
+    static const bool enabled = !(getenv("LSA_KRYLOV_TAIL") && atoi(getenv("LSA_KRYLOV_TAIL")) == 0);
+    static const bool fuse = !(getenv("LSA_KRYLOV_FUSED") && atoi(getenv("LSA_KRYLOV_FUSED")) == 0);
+    const lsa_op* op = k->op;
+    if (!enabled || !fuse || !op->Kmul || !op->Kfac || op->adjoint || op->keep || op->refine || op->n != k->n) return false;
+    return k_cgs2_tail_fits(ctx, k->n, k->ncv, op->Kmul, op->Kfac);
+}
+
+static int krylov_enqueue_step(lsa_ctx* ctx, lsa_krylov* k, int32_t j, int32_t slot, bool tail) {
     lsa_op* op = k->op;
     const int dtype = LSA_C128;
     const size_t vb = (size_t)k->n * 16;
     const void* vj = (char*)k->V + (size_t)j * vb;
     void* vn = (char*)k->V + (size_t)(j + 1) * vb;
     const void* rhs = vj;
-    if (op->Kmul) {
-        LSA_CHECK(spmv_global(ctx, op->Kmul, dtype, vj, op->t, op->adjoint));
-        rhs = op->t;
-    }
     PcRef pcr;
     pcr.nd = op->nd;
     pcr.nd_dist = op->nd_dist;
     pcr.adjoint = op->adjoint;
+    void* hcol_dev = (char*)k->Hdev + (size_t)slot * (size_t)(k->ncv + 2) * 16;
+    if (tail) {
+        // 18 launches: [M v_j unless the previous step's tail left it] + the sweeps + dot, update, dot, update + tail
+        if (k->t_for != j) LSA_CHECK(spmv_global(ctx, op->Kmul, dtype, vj, op->t, false));
+        k->t_for = -1;
+        LSA_CHECK(pc_global(ctx, pcr, op->Kfac->row0, op->n, dtype, op->t, k->w));
+        LSA_CHECK(k->ow.ensure_fused(ctx, k->n));
+        LSA_CHECK(k_cgs2_fused_tail(ctx, k->n, j + 1, k->V, k->n, k->w, k->w2, vn, hcol_dev, k->ow.fused, op->Kmul, op->Kfac, op->t,
+                                    k->tail_parts + (size_t)slot * 2 * (size_t)k->tail_nparts));
+        k->t_for = j + 1;
+        return LSA_OK;
+    }
+    k->t_for = -1;
+    if (op->Kmul) {
+        LSA_CHECK(spmv_global(ctx, op->Kmul, dtype, vj, op->t, op->adjoint));
+        rhs = op->t;
+    }
     LSA_CHECK(pc_global(ctx, pcr, op->Kfac->row0, op->n, dtype, rhs, k->w));
     LSA_CHECK(spmv_global(ctx, op->Kfac, dtype, k->w, op->gw.z, op->adjoint));
     if (op->refine) {
@@ -954,7 +983,6 @@ static int krylov_enqueue_step(lsa_ctx* ctx, lsa_krylov* k, int32_t j, int32_t s
         LSA_CHECK(k_axpy(ctx, dtype, op->n, one, op->gw.z, k->w));
         LSA_CHECK(spmv_global(ctx, op->Kfac, dtype, k->w, op->gw.z, op->adjoint));
     }
-    void* hcol_dev = (char*)k->Hdev + (size_t)slot * (size_t)(k->ncv + 2) * 16;
     static const bool fuse = !(getenv("LSA_KRYLOV_FUSED") && atoi(getenv("LSA_KRYLOV_FUSED")) == 0);
     if (fuse) {
         // the check ||b - C y||, ||b|| rides in the first reduction of the orthogonalisation (its vector b - C y is needed only
@@ -1005,17 +1033,25 @@ int lsa_krylov_extend(lsa_ctx* ctx, lsa_krylov* k, int32_t j0, int32_t j1, void*
         const size_t colb = (size_t)(k->ncv + 2) * 16;
         LSA_CHECK(lsa_ensure_scratch(ctx, 0, (size_t)k->batch * (colb + 2 * sizeof(double))));
         const double rtol = op->opts.ksp_rtol;
+        k->t_for = -1;  // (op->t is anybody's between calls)
         while (j < j1 && k->pipeline) {
             const int32_t nb = std::min<int32_t>(k->batch, j1 - j);
             const double tq = now_s();
+            const bool tail = krylov_tail_ok(ctx, k);
+            if (tail && !k->tail_parts) {
+                k->tail_nparts = k_cgs2_tail_parts(k->n);
+                LSA_HIP_ALLOC(ctx, hipMalloc(&k->w2, (size_t)k->n * 16));
+                LSA_HIP_ALLOC(ctx, hipMalloc((void**)&k->tail_parts, (size_t)k->batch * 2 * (size_t)k->tail_nparts * sizeof(double)));
+            }
             for (int32_t s = 0; s < nb; ++s) {
-                int rc = krylov_enqueue_step(ctx, k, j + s, s);
+                int rc = krylov_enqueue_step(ctx, k, j + s, s, tail);
                 if (rc != LSA_OK) {
                     (void)hipStreamSynchronize(ctx->stream);
                     op->st.seconds_solve += now_s() - t0;
                     return rc;
                 }
             }
+            if (tail) LSA_CHECK(k_cgs2_tail_checks(ctx, nb, k->tail_nparts, k->tail_parts, k->checks));
             char* host = (char*)ctx->pinned;
             LSA_HIP_CHECK(ctx, hipMemcpyAsync(host, k->Hdev, (size_t)nb * colb, hipMemcpyDeviceToHost, ctx->stream));
             LSA_HIP_CHECK(ctx, hipMemcpyAsync(host + (size_t)k->batch * colb, k->checks, (size_t)nb * 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -1059,8 +1095,10 @@ int lsa_krylov_extend(lsa_ctx* ctx, lsa_krylov* k, int32_t j0, int32_t j1, void*
                 }
             }
             j += accepted;
+            if (accepted < nb) k->t_for = -1;  // the steps behind the one that stopped the batch ran on; t is theirs
         }
     }
+    k->t_for = -1;
     for (; j < j1; ++j) {
         const void* vj = (char*)k->V + (size_t)j * vb;
         void* vn = (char*)k->V + (size_t)(j + 1) * vb;

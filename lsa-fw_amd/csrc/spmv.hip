@@ -397,6 +397,15 @@ static int spmv_variant() {
     return e ? (int)strtol(e, nullptr, 0) : 0;
 }
 
+// LPR when k_spmv runs the plain row-per-sub-wave kernel on A with complex vectors (no variant word, no row groups, no compressed
+// indices), 0 otherwise: the fused tail of an Arnoldi step (blas.hip::cgs_tail_kernel) walks the rows the same way, so that
+// its two products are bit for bit those of k_spmv
+int k_spmv_plain_subwave_lanes(const lsa_mat* A) {
+    const int variant = spmv_variant();
+    if (variant != 0 || spmv_wants_groups(A, variant) || spmv_wants_ci16(A, variant)) return 0;
+    return spmv_lanes_per_row(A, variant);
+}
+
 template <typename MT, typename VT>
 static void dispatch_spmv(lsa_ctx* ctx, const lsa_mat* A, const void* x, void* y) {
     const int variant = spmv_variant();

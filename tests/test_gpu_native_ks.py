@@ -112,7 +112,8 @@ es = fem.cylinder_case("S5k")
 s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=8, atol=1e-10, ncv=40), check_hermitian=False)
 s.solver.set_st_type(iSTType.SINVERT); s.solver.set_st_pc_type(PreconditionerType.LU); s.solver.set_target(fem.SIGMA_RE50)
 pairs = s.solve()
-out["cylinder"] = {"lam": [[p[0].real, p[0].imag] for p in pairs], "res": float(s.solver.residuals()[:8].max()), "applies": s.solver.stats["op_applies"]}
+out["cylinder"] = {"lam": [[p[0].real, p[0].imag] for p in pairs], "res": float(s.solver.residuals()[:8].max()), "applies": s.solver.stats["op_applies"],
+                   "max_rel_res": s.solver.stats["max_rel_res"], "spmv_calls": s.solver.stats["spmv_calls"]}
 s.solver.release()
 K, M, _bnd = fem.assemble_membrane(24, 24)  # real symmetric pair: the float64 kernels
 s = EigenSolver(K, M, EigensolverConfig(num_eig=6, atol=1e-10, ncv=30), check_hermitian=False)
@@ -134,7 +135,8 @@ def test_cgs2_kernel_per_stage_forms_agree_with_the_five_launch_form(tmp_path):
 
     root = str(Path(__file__).resolve().parents[1])
     runs = {}
-    for name, env in (("default", {}), ("three_passes", {"LSA_KRYLOV_FUSED": "0"}), ("four_passes", {"LSA_KRYLOV_FUSED": "0", "LSA_KRYLOV_PASSES": "4"})):
+    for name, env in (("default", {}), ("three_passes", {"LSA_KRYLOV_FUSED": "0"}), ("four_passes", {"LSA_KRYLOV_FUSED": "0", "LSA_KRYLOV_PASSES": "4"}),
+                      ("no_tail", {"LSA_KRYLOV_TAIL": "0"})):
         p = subprocess.run([sys.executable, "-c", _CGS_CHILD, root], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         runs[name] = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
@@ -144,3 +146,10 @@ def test_cgs2_kernel_per_stage_forms_agree_with_the_five_launch_form(tmp_path):
             lam = np.array([complex(a, b) for a, b in runs[name][prob]["lam"]])
             assert runs[name][prob]["res"] <= 1e-8
             assert len(lam) == len(ref) and np.abs(lam - ref).max() <= 1e-10 * np.abs(ref).max(), (prob, name)
+        # round 4: the tail form of a step (its last launch normalises, multiplies M v for the next step and checks the inner
+        # solve: csrc/blas.hip::cgs_tail_kernel) against the five launches plus two products it replaces: the SAME bits, the same
+        # operator applies; only the sums of the check are added in another order
+        assert runs["no_tail"][prob]["lam"] == runs["default"][prob]["lam"], prob
+        assert runs["no_tail"][prob]["applies"] == runs["default"][prob]["applies"]
+    a, b = runs["default"]["cylinder"]["max_rel_res"], runs["no_tail"]["cylinder"]["max_rel_res"]
+    assert 0.0 < a <= 1e-11 and abs(a - b) <= 1e-3 * max(a, b), (a, b)

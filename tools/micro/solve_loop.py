@@ -23,4 +23,4 @@ for _ in range(reps):
 dt = (time.perf_counter() - t) / reps
 st = s.solver.stats
 print(f"{case}: {1e3 * dt:.2f} ms per solve, expand {1e3 * st.get('seconds_expand', 0):.2f} dense {1e3 * st.get('seconds_dense', 0):.2f} "
-      f"restart {1e3 * st.get('seconds_restart', 0):.2f} factor {1e3 * st.get('seconds_factor', 0):.2f}; lambda0 {pairs[0][0]!r}")
+      f"applies {st.get('op_applies')} restart {1e3 * st.get('seconds_restart', 0):.2f} factor {1e3 * st.get('seconds_factor', 0):.2f}; lambda0 {pairs[0][0]!r}")

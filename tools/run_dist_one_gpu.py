@@ -31,6 +31,20 @@ def rank_main(rank, world, port, out_dir, case, k, env):
     from Solver.utils import PreconditionerType, iSTType
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    if rank == 0:  # a line a minute: a long rehearsal must not look hung
+        import threading
+
+        phase = ["assembling"]
+
+        def beat():
+            t_start = time.time()
+            while phase[0] != "done":
+                time.sleep(45)
+                print(f"[run_dist_one_gpu] {time.time() - t_start:.0f} s: {phase[0]}", file=sys.stderr, flush=True)
+
+        threading.Thread(target=beat, daemon=True).start()
+    else:
+        phase = [""]
     t0 = time.time()
     es = fem.cube_case(case) if case.startswith("C") else fem.cylinder_case(case)
     sigma = fem.SIGMA_CUBE if case.startswith("C") else fem.SIGMA_RE50
@@ -40,10 +54,12 @@ def rank_main(rank, world, port, out_dir, case, k, env):
     s.solver.set_target(sigma)
     s.solver.set_st_pc_type(PreconditionerType.LU)
     t0 = time.time()
+    phase[0] = "analysis"
     s.solver.prepare()
     t_prep = time.time() - t0
     forest = s.solver._prepared["forest"]
     t0 = time.time()
+    phase[0] = "factorisation and solve"
     pairs = s.solve()
     t_solve = time.time() - t0
     st = s.solver.stats
@@ -53,6 +69,7 @@ def rank_main(rank, world, port, out_dir, case, k, env):
            "stats": {kk: (float(v) if isinstance(v, (int, float)) else str(v)) for kk, v in st.items()},
            "lambda": [[float(p[0].real), float(p[0].imag)] for p in pairs[:k]]}
     (Path(out_dir) / f"rank{rank}.json").write_text(json.dumps(rec))
+    phase[0] = "done"
     s.solver.release()
     dist.barrier()
     dist.destroy_process_group()

@@ -683,7 +683,7 @@ __global__ __launch_bounds__(64) void col_phase_finish_kernel(cplx* __restrict__
 }
 
 // Out[i, k0+t] = sum_c V[i, c] Q[c, k0+t], t < kOutTile
-constexpr int kOutTile = 4;
+constexpr int kOutTile = 8;  // (round 4: 4 -> 8 halves the passes over a basis that does not fit the caches)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void basis_gemm_kernel(int64_t n, int m, int k, const T* __restrict__ V, int64_t ldv,
                                                               const T* __restrict__ Q, int ldq, T* __restrict__ Out,
@@ -702,7 +702,18 @@ __global__ __launch_bounds__(kThreads) void basis_gemm_kernel(int64_t n, int m, 
         T acc[kOutTile];
 #pragma unroll
         for (int t = 0; t < kOutTile; ++t) acc[t] = scalar_traits<T>::zero();
-        for (int c = 0; c < m; ++c) {
+        int c = 0;
+        for (; c + 7 < m; c += 8) {  // eight basis entries requested at once (a loop of single loads is a chain of m round trips)
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = V[i + (int64_t)(c + u) * ldv];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int t = 0; t < kOutTile; ++t) fma_acc(acc[t], qs[c + u + t * m], v[u]);
+            }
+        }
+        for (; c < m; ++c) {
             const T v = V[i + (int64_t)c * ldv];
 #pragma unroll
             for (int t = 0; t < kOutTile; ++t) fma_acc(acc[t], qs[c + t * m], v);
@@ -819,10 +830,15 @@ __global__ __launch_bounds__(kThreads) void cgs_axpy_dot_kernel(int64_t n, int j
         const int c = wave + 4 * k;
         if (c < j) fma_acc(acc, hs[c], v[k]);
     }
+    // Every wavefront needs the OLD w[i] and wavefront 0 writes the new one: the old value is read in front of the barrier.
+    // (Round 3 read it behind the barrier in all four wavefronts -- a wavefront that fell behind wavefront 0 then saw the new
+    //  value and subtracted the projection twice for its columns.  Met in round 4 with four ranks time-sharing one GPU: one
+    //  tile in some step of some rank, an error of 1e-9 .. 1e-5 in a Hessenberg column, ranks out of step.)
+    const T w_old = in ? w[i] : scalar_traits<T>::zero();
     accs[wave][lane] = acc;
     __syncthreads();
     T wi = scalar_traits<T>::zero();
-    if (in) wi = s_sub(w[i], s_add(s_add(accs[0][lane], accs[1][lane]), s_add(accs[2][lane], accs[3][lane])));
+    if (in) wi = s_sub(w_old, s_add(s_add(accs[0][lane], accs[1][lane]), s_add(accs[2][lane], accs[3][lane])));
     if (wave == 0 && in) w[i] = wi;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {

@@ -88,6 +88,12 @@ int k_allgather_inplace(lsa_ctx* ctx, void* vec, size_t bytes_per_rank) {
     if (ctx->nranks <= 1) return LSA_OK;
     ++ctx->comm_calls;
     ctx->comm_bytes += (int64_t)bytes_per_rank * (ctx->nranks - 1);  // received per rank
+    {
+        // LSA_TRACE_COMM: one line per exchange on standard error.  Ranks that take different turns show up as sequences that
+        // differ (tools/micro/dist_c1m_comm.sh compares them); this is how round 4's out-of-step ranks were traced.
+        static const bool trace = getenv("LSA_TRACE_COMM") != nullptr;
+        if (trace) fprintf(stderr, "[comm rank %d] call %lld bytes %zu\n", ctx->rank, (long long)ctx->comm_calls, bytes_per_rank);
+    }
     if (ctx->host_gather) {
         // host-staged transport (lsa_comm_init_host): own block to pinned memory, the caller's exchange (e.g.
         // torch.distributed over gloo), everything back.  Same layout and call sites as the RCCL path.

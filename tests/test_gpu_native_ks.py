@@ -153,3 +153,45 @@ def test_cgs2_kernel_per_stage_forms_agree_with_the_five_launch_form(tmp_path):
         assert runs["no_tail"][prob]["applies"] == runs["default"][prob]["applies"]
     a, b = runs["default"]["cylinder"]["max_rel_res"], runs["no_tail"]["cylinder"]["max_rel_res"]
     assert 0.0 < a <= 1e-11 and abs(a - b) <= 1e-3 * max(a, b), (a, b)
+
+
+_REPRO_CHILD = r"""
+import json, sys
+sys.path[:0] = [sys.argv[1], sys.argv[1] + "/lsa-fw_amd", sys.argv[1] + "/tests"]
+from synthetic import fem
+from Solver.eigen import EigenSolver, EigensolverConfig
+from Solver.utils import PreconditionerType, iSTType
+es = fem.cylinder_case("S30k")
+s = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=8, atol=1e-10, ncv=40), check_hermitian=False)
+s.solver.set_st_type(iSTType.SINVERT); s.solver.set_st_pc_type(PreconditionerType.LU); s.solver.set_target(fem.SIGMA_RE50)
+out = []
+for _ in range(int(sys.argv[2])):
+    pairs = s.solve()
+    out.append([[p[0].real.hex(), p[0].imag.hex()] for p in pairs[:8]])
+print(json.dumps(out))
+"""
+
+
+def test_long_vector_cgs2_gives_the_same_bits_in_processes_that_share_the_gpu():
+    """The kernel-per-stage CGS2 of long vectors (``cgs_axpy_dot_kernel``: first projection and second dot product in one pass)
+    forced onto the 30 k-unknown case, in four processes that time-share the GPU, several solves each: every solve of every
+    process returns the same bits.  Round 4 met a read-after-write race in that kernel this way (all four wavefronts of a
+    workgroup read ``w[i]`` behind the barrier, wavefront 0 wrote it): ranks of a sharded solve, whose replicated vectors must
+    stay bit-identical, went out of step once in a few runs of a 1 M-unknown case."""
+    import os
+    import subprocess
+    import sys
+
+    root = str(Path(__file__).resolve().parents[1])
+    env = {**os.environ, "LSA_KRYLOV_FUSED": "0"}
+    procs = [subprocess.Popen([sys.executable, "-c", _REPRO_CHILD, root, "6"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(4)]
+    results = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+        results.append(json.loads([ln for ln in so.splitlines() if ln.startswith("[")][-1]))
+    first = results[0][0]
+    assert len(first) == 8
+    for r in results:
+        for solve in r:
+            assert solve == first

@@ -92,5 +92,8 @@ if __name__ == "__main__":
         recs = [json.loads((Path(tmp) / f"rank{r}.json").read_text()) for r in range(args.ranks)]
     same = all(r["lambda"] == recs[0]["lambda"] for r in recs)
     out = {"case": args.case, "ranks": args.ranks, "env": args.env, "ranks_bit_identical": same, "rank0": recs[0],
-           "solve_s_per_rank": [r["solve_s"] for r in recs], "factor_s_per_rank": [r["stats"].get("seconds_factor") for r in recs]}
+           "solve_s_per_rank": [r["solve_s"] for r in recs], "factor_s_per_rank": [r["stats"].get("seconds_factor") for r in recs],
+           # what must be the same on every rank: a difference says that the ranks took different turns (collectives out of step)
+           "per_rank": [{k: r["stats"].get(k) for k in ("op_applies", "refined_solves", "allgather_calls", "max_rel_res", "last_rel_res", "krylov_restarts")}
+                        | {"max_residual": r["max_residual"], "lambda0": r["lambda"][0] if r["lambda"] else None} for r in recs]}
     print(json.dumps(out))

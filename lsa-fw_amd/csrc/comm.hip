@@ -174,6 +174,23 @@ int k_agree_min_i64(lsa_ctx* ctx, int64_t* value) {
     return LSA_OK;
 }
 
+// Are the ranks in step?  Every rank passes the number of exchanges it has made so far; a rank that took a different turn
+// somewhere (a decision taken from replicated data that was not bit-identical after all) has made more or fewer.  Exchanges of
+// equal size pair up silently whatever they were meant to carry, so an out-of-step run can end with wrong numbers on every rank
+// instead of a hang: this check turns that into an error.  Collective; one 16-byte all-gather.
+int k_agree_in_step(lsa_ctx* ctx, const char* where) {
+    if (ctx->nranks <= 1) return LSA_OK;
+    const int64_t mine = ctx->comm_calls;
+    int64_t lo = mine, hi = -mine;
+    LSA_CHECK(k_agree_min_i64(ctx, &lo));
+    LSA_CHECK(k_agree_min_i64(ctx, &hi));  // min of the negatives = -max; (both calls count alike on every rank)
+    if (lo != -hi)
+        return lsa_set_error(ctx, LSA_ERR_COMM, "%s: the ranks are out of step (between %lld and %lld exchanges so far; this rank %lld): a decision was "
+                             "taken from replicated data that differs between ranks; the results of this solve cannot be trusted",
+                             where, (long long)lo, (long long)-hi, (long long)mine);
+    return LSA_OK;
+}
+
 void comm_release(lsa_ctx* ctx) {
     if (ctx->comm) {
         Rccl& r = rccl();

@@ -728,7 +728,7 @@ int lsa_krylov_solve(lsa_ctx* ctx, lsa_krylov* k, const lsa_ks_options* o, const
             result->restarts = restarts;
             result->op_applies = applies;
             result->next_unconverged = nconv < m ? rel[(size_t)rank[(size_t)nconv]] : 0.0;
-            return LSA_OK;
+            return k_agree_in_step(ctx, "lsa_krylov_solve");  // (a sharded solve ends with the ranks comparing their exchange counts)
         }
         // ---- truncate to the wanted part of the Schur form and restart ----
         int knew = nconv + (int)((m - nconv) * keep_fraction);

@@ -171,6 +171,7 @@ lsa_mat* mat_row_view(const lsa_mat* full, int32_t r0, int32_t r1);
 void comm_release(lsa_ctx* ctx);  // comm.hip
 int k_agree_status(lsa_ctx* ctx, int rc);  // comm.hip: collective agreement on a status (returns rc on one rank)
 int k_agree_min_i64(lsa_ctx* ctx, int64_t* value);  // comm.hip: the smallest of the ranks' values (collective)
+int k_agree_in_step(lsa_ctx* ctx, const char* where);  // comm.hip: error on every rank unless all ranks have made the same number of exchanges (collective)
 int lsa_ensure_scratch(lsa_ctx* ctx, size_t dbytes, size_t hbytes);
 
 #define LSA_HIP_CHECK(ctx, expr)                                                                         \

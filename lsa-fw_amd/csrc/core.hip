@@ -275,6 +275,8 @@ extern "C" int lsa_csr_axpby(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* B, c
         B->h_ci = A->h_ci;
         if (!A->h_hash) A->h_hash = B->h_hash ? B->h_hash : std::make_shared<uint64_t>(0);
         B->h_hash = A->h_hash;
+        if (!A->h_shared) A->h_shared = B->h_shared ? B->h_shared : std::make_shared<PatternShared>();
+        B->h_shared = A->h_shared;
     }
     if (out_dtype == LSA_F64 && (A->dtype != LSA_F64 || B->dtype != LSA_F64 || alpha[1] != 0.0 || beta[1] != 0.0))
         return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_csr_axpby: a real result needs real operands and real coefficients");
@@ -292,6 +294,8 @@ extern "C" int lsa_csr_axpby(lsa_ctx* ctx, const lsa_mat* A, const lsa_mat* B, c
     C->h_ci = A->h_ci;
     if (!A->h_hash) A->h_hash = std::make_shared<uint64_t>(0);
     C->h_hash = A->h_hash;
+    if (!A->h_shared) A->h_shared = std::make_shared<PatternShared>();
+    C->h_shared = A->h_shared;
     C->val = nullptr;
     hipError_t e = hipMalloc(&C->val, (size_t)(C->nnz > 0 ? C->nnz : 1) * dtype_size(out_dtype));
     if (e != hipSuccess) {

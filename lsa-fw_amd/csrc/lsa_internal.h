@@ -134,6 +134,22 @@ struct SharedInts {
     bool operator!=(const SharedInts& o) const { return !(*this == o); }
 };
 
+// The transpose of a pattern in pull form (built on first use of the transposed product, shared by the matrices of one pattern):
+// output c sums the entries q in [rp[c], rp[c + 1]): the value at position src[q] of the CSR arrays times x[ci[q]].
+struct TransposeIndex {
+    int32_t *rp = nullptr, *ci = nullptr, *src = nullptr;  // device: ncols + 1, nnz, nnz
+    int32_t ncols = 0;
+    int64_t nnz = 0;
+    ~TransposeIndex() {
+        for (void* p : {(void*)rp, (void*)ci, (void*)src})
+            if (p) (void)hipFree(p);
+    }
+};
+
+struct PatternShared {  // what the matrices of one pattern build once and share (a slot, so that whoever builds it first fills it for all)
+    std::shared_ptr<TransposeIndex> tr;
+};
+
 struct lsa_mat {
     lsa_ctx* ctx;
     int32_t n;        // rows held locally
@@ -151,6 +167,7 @@ struct lsa_mat {
     // nested-dissection LU is matched by it once per solve -- hashing 15 M indices anew took 18 ms of a 0.36 s solve)
     mutable SharedInts h_rp, h_ci;
     mutable std::shared_ptr<uint64_t> h_hash;
+    mutable std::shared_ptr<PatternShared> h_shared;  // (shared like the hash: A, M and every C = A - sigma M built on their pattern)
     // compressed column indices for the SpMV (built on first use): col = cbase[row] + ci16[p] when every row spans
     // fewer than 65 536 columns (banded FEM matrices do); ci16_state: 0 = not tried, 1 = available, -1 = does not fit
     mutable uint16_t* ci16 = nullptr;

@@ -118,15 +118,9 @@ int upload_small(lsa_ctx* ctx, int dtype, const zc* src, size_t count, void* dst
 // y = A x for a (possibly row-sharded) matrix; x and y are global-length vectors replicated on every rank: the
 // shard writes its own rows, then the equal-sized padded blocks are exchanged with one in-place all-gather
 int spmv_global(lsa_ctx* ctx, const lsa_mat* A, int dtype, const void* x, void* y, bool adjoint = false) {
-    if (adjoint) {
-        // y = A^H x with the whole matrix (lsa_op_set_adjoint sees to that on every rank).  The transposed product scatters with
-        // floating-point atomics: its rounding depends on the order the additions arrive in, so two ranks need not get the same
-        // bits -- and the ranks of a sharded solve take their turns from replicated vectors.  Every rank therefore keeps its own
-        // block of the result and takes the others' from their owners: one more exchange, the same vector everywhere.
-        LSA_CHECK(k_spmv_transpose(ctx, A, 1, dtype, x, y));
-        if (ctx->nranks > 1 && A->ncols % ctx->nranks == 0) LSA_CHECK(k_allgather_inplace(ctx, y, (size_t)(A->ncols / ctx->nranks) * esize(dtype)));
-        return LSA_OK;
-    }
+    // y = A^H x with the whole matrix (lsa_op_set_adjoint sees to that on every rank); the pull-form product is reproducible bit for
+    // bit, so the ranks' replicated vectors stay alike without an exchange
+    if (adjoint) return k_spmv_transpose(ctx, A, 1, dtype, x, y);
     const size_t es = esize(dtype);
     LSA_CHECK(k_spmv(ctx, A, dtype, x, (char*)y + (size_t)A->row0 * es));
     // (a whole square matrix was multiplied on every rank: nothing to exchange)

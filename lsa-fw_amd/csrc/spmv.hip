@@ -423,47 +423,80 @@ int k_spmv(lsa_ctx* ctx, const lsa_mat* A, int xdtype, const void* x, void* y) {
     return LSA_OK;
 }
 
-// ---- y = A^T x / A^H x by scatter (adjoint eigenproblem; not on the inner-loop path) ----------------------------
-__device__ __forceinline__ void atomic_add_t(double* p, double v) { unsafeAtomicAdd(p, v); }
-__device__ __forceinline__ void atomic_add_t(cplx* p, cplx v) {
-    unsafeAtomicAdd(&p->re, v.re);
-    unsafeAtomicAdd(&p->im, v.im);
-}
-
+// ---- y = A^T x / A^H x (adjoint eigenproblem; not on the inner-loop path) --------------------------------------------------------
+// Pull form over a transposed index built once per pattern on the host (counting sort of the column indices): output c walks
+// its entries q with a sub-wave of 16 lanes, value val[src[q]], vector entry x[ci[q]] -- the additions in a fixed order, so the
+// product is reproducible bit for bit.  (Rounds 2-3 scattered with floating-point atomics: the only kernel of the path whose
+// rounding depended on the order in which additions arrived -- 11 of 12 adjoint solves in processes sharing a GPU differed in
+// the last bits, tools/micro/repro_under_sharing.py, and the ranks of a sharded adjoint solve need replicated vectors alike.)
 template <typename MT, typename VT>
-__global__ __launch_bounds__(256) void spmv_transpose_kernel(int32_t n, int conj, const int32_t* __restrict__ rp,
-                                                             const int32_t* __restrict__ ci, const MT* __restrict__ val,
-                                                             const VT* __restrict__ x, VT* __restrict__ y) {
+__global__ __launch_bounds__(256) void spmv_transpose_pull_kernel(int32_t ncols, int conj, const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                                  const int32_t* __restrict__ src, const MT* __restrict__ val,
+                                                                  const VT* __restrict__ x, VT* __restrict__ y) {
     constexpr int LPR = 16;
     const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int32_t lane = (int32_t)(gid % LPR);
-    const int64_t row_stride = ((int64_t)gridDim.x * blockDim.x) / LPR;
-    for (int64_t row = gid / LPR; row < n; row += row_stride) {
-        const VT xr = x[row];
-        for (int32_t p = rp[row] + lane; p < rp[row + 1]; p += LPR) {
-            MT a = val[p];
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) / LPR;
+    for (int64_t c = gid / LPR; c < ncols; c += stride) {
+        VT acc = scalar_traits<VT>::zero();
+        for (int32_t q = rp[c] + lane; q < rp[c + 1]; q += LPR) {
+            MT a = val[src[q]];
             if (conj) a = s_conj(a);
-            atomic_add_t(&y[ci[p]], s_mul(a, xr));
+            fma_acc(acc, a, x[ci[q]]);
         }
+#pragma unroll
+        for (int m = LPR / 2; m > 0; m >>= 1) acc = s_add(acc, shfl_xor_t<VT>(acc, m));
+        if (lane == 0) y[c] = acc;
     }
+}
+
+static int ensure_transpose(lsa_ctx* ctx, const lsa_mat* A) {
+    if (!A->h_shared) A->h_shared = std::make_shared<PatternShared>();
+    if (A->h_shared->tr && A->h_shared->tr->nnz == A->nnz && A->h_shared->tr->ncols == A->ncols) return LSA_OK;
+    const int32_t n = A->n, nc = A->ncols;
+    if ((int64_t)A->h_rp.size() != (int64_t)n + 1 || (int64_t)A->h_ci.size() != A->nnz)
+        return lsa_set_error(ctx, LSA_ERR_ARG, "spmv_transpose: the matrix has no host copy of its pattern");
+    if (A->nnz > 0x7FFFFFFF) return lsa_set_error(ctx, LSA_ERR_ARG, "spmv_transpose: more than 2^31 entries");
+    std::vector<int32_t> rp((size_t)nc + 1, 0), ci((size_t)std::max<int64_t>(A->nnz, 1)), src((size_t)std::max<int64_t>(A->nnz, 1));
+    for (int64_t p = 0; p < A->nnz; ++p) ++rp[(size_t)A->h_ci[(size_t)p] + 1];
+    for (int32_t c = 0; c < nc; ++c) rp[(size_t)c + 1] += rp[(size_t)c];
+    std::vector<int32_t> next(rp.begin(), rp.end() - 1);
+    for (int32_t r = 0; r < n; ++r)  // rows ascending: every output's entries end up ordered by row
+        for (int32_t p = A->h_rp[(size_t)r]; p < A->h_rp[(size_t)r + 1]; ++p) {
+            const int32_t q = next[(size_t)A->h_ci[(size_t)p]]++;
+            ci[(size_t)q] = r;
+            src[(size_t)q] = p;
+        }
+    auto T = std::make_shared<TransposeIndex>();
+    T->ncols = nc;
+    T->nnz = A->nnz;
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&T->rp, rp.size() * sizeof(int32_t)));
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&T->ci, ci.size() * sizeof(int32_t)));
+    LSA_HIP_ALLOC(ctx, hipMalloc((void**)&T->src, src.size() * sizeof(int32_t)));
+    LSA_HIP_CHECK(ctx, hipMemcpy(T->rp, rp.data(), rp.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    LSA_HIP_CHECK(ctx, hipMemcpy(T->ci, ci.data(), ci.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    LSA_HIP_CHECK(ctx, hipMemcpy(T->src, src.data(), src.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    A->h_shared->tr = T;
+    return LSA_OK;
 }
 
 int k_spmv_transpose(lsa_ctx* ctx, const lsa_mat* A, int conj, int xdtype, const void* x, void* y) {
     if (A->row0 != 0 || A->n != A->ncols) return lsa_set_error(ctx, LSA_ERR_ARG, "spmv_transpose: sharded matrices are not supported");
-    LSA_CHECK(k_set_zero(ctx, xdtype, A->ncols, y));
+    LSA_CHECK(ensure_transpose(ctx, A));
+    const TransposeIndex& T = *A->h_shared->tr;
     const int threads = 256;
-    int64_t want = ((int64_t)A->n * 16 + threads - 1) / threads;
-    int64_t cap = (int64_t)ctx->num_cu * 32;
+    int64_t want = ((int64_t)A->ncols * 16 + threads - 1) / threads;
+    int64_t cap = (int64_t)ctx->num_cu * 64;
     int blocks = (int)(want < 1 ? 1 : (want > cap ? cap : want));
     if (A->dtype == LSA_F64 && xdtype == LSA_F64)
-        hipLaunchKernelGGL((spmv_transpose_kernel<double, double>), dim3(blocks), dim3(threads), 0, ctx->stream, A->n, conj, A->rp,
-                           A->ci, (const double*)A->val, (const double*)x, (double*)y);
+        hipLaunchKernelGGL((spmv_transpose_pull_kernel<double, double>), dim3(blocks), dim3(threads), 0, ctx->stream, A->ncols, conj, T.rp, T.ci, T.src,
+                           (const double*)A->val, (const double*)x, (double*)y);
     else if (A->dtype == LSA_F64 && xdtype == LSA_C128)
-        hipLaunchKernelGGL((spmv_transpose_kernel<double, cplx>), dim3(blocks), dim3(threads), 0, ctx->stream, A->n, conj, A->rp,
-                           A->ci, (const double*)A->val, (const cplx*)x, (cplx*)y);
+        hipLaunchKernelGGL((spmv_transpose_pull_kernel<double, cplx>), dim3(blocks), dim3(threads), 0, ctx->stream, A->ncols, conj, T.rp, T.ci, T.src,
+                           (const double*)A->val, (const cplx*)x, (cplx*)y);
     else if (A->dtype == LSA_C128 && xdtype == LSA_C128)
-        hipLaunchKernelGGL((spmv_transpose_kernel<cplx, cplx>), dim3(blocks), dim3(threads), 0, ctx->stream, A->n, conj, A->rp,
-                           A->ci, (const cplx*)A->val, (const cplx*)x, (cplx*)y);
+        hipLaunchKernelGGL((spmv_transpose_pull_kernel<cplx, cplx>), dim3(blocks), dim3(threads), 0, ctx->stream, A->ncols, conj, T.rp, T.ci, T.src,
+                           (const cplx*)A->val, (const cplx*)x, (cplx*)y);
     else return lsa_set_error(ctx, LSA_ERR_ARG, "spmv_transpose: a complex matrix needs complex vectors");
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return lsa_set_error(ctx, LSA_ERR_HIP, "spmv_transpose launch failed: %s", hipGetErrorString(e));

@@ -93,8 +93,9 @@ int lsa_csr_axpby(lsa_ctx *ctx, const lsa_mat *A, const lsa_mat *B, const double
                   int out_dtype, lsa_mat **out);
 /* y = A x: MatMult (Solver/eigen2.py:174).  Real matrix with complex vectors is supported. */
 int lsa_spmv(lsa_ctx *ctx, const lsa_mat *A, const lsa_vec *x, lsa_vec *y);
-/* y = A^T x or A^H x (conj != 0) without forming the transpose: the adjoint eigenproblem of
- * Sensitivity/__init__.py:47-57,247-248 */
+/* y = A^T x or A^H x (conj != 0) without a second copy of the values: a transposed INDEX (row pointers, rows, positions of the
+ * values) is built once per pattern and shared by the matrices of that pattern; additions in a fixed order.  The adjoint
+ * eigenproblem of Sensitivity/__init__.py:47-57,247-248 */
 int lsa_spmv_transpose(lsa_ctx *ctx, const lsa_mat *A, int conj, const lsa_vec *x, lsa_vec *y);
 /* Which kernel lsa_spmv launches for this matrix and vector type (template arguments included) and the bytes that
  * kernel moves per launch: values + column indices (2-byte offsets from the row's first column when the compressed form

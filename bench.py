@@ -177,12 +177,14 @@ def solves_in_flight(es, sigma, args, device, jobs=2, rounds=4):
         so.solver.prepare()
         so.solve()
     pairs = [0] * jobs
+    bits = [set() for _ in range(jobs)]  # the eigenvalues every solve returned, as bit patterns
 
     def work(j):
         for _ in range(rounds):
             so = solvers[j]
-            so.solve()
+            got = so.solve()
             pairs[j] += int(np.sum(so.solver.residuals()[: args.k] <= RESIDUAL_TOL))
+            bits[j].add(np.array([p[0] for p in got[: args.k]], dtype=np.complex128).tobytes())
 
     threads = [threading.Thread(target=work, args=(j,)) for j in range(jobs)]
     t0 = time.perf_counter()
@@ -194,6 +196,8 @@ def solves_in_flight(es, sigma, args, device, jobs=2, rounds=4):
     for so in solvers:
         so.solver.release()
     return {"jobs": jobs, "eigenpairs_per_s": sum(pairs) / dt, "ms_per_round": 1e3 * dt / rounds,
+            # solves that overlap on the GPU must return the bits of a solve that has the GPU to itself
+            "bit_identical_eigenvalues": len(set().union(*bits)) == 1,
             "note": "secondary: independent solves overlapped on one GPU (threads); `value` is one solve at a time"}
 
 

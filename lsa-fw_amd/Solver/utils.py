@@ -487,10 +487,9 @@ class iEpsSolver:
             zd = Kc.diagonal() == 0
             an = lsa_hip.NdAnalysis(Kc, 0, constraint=zd if zd.any() else None)  # (constraints last: no retry across ranks)
             ex = an.export()
-            # (top nodes with large fronts -- the 3D cases -- are distributed over the ranks; the transposed sweeps of the adjoint
-            #  problem exist for the replicated form of the top only)
-            forest = sharding.partition_forest(ex["perm"], ex["node_start"], ex["parent"], ex["front_size"], world,
-                                               dist_min=0 if self._adjoint else None)
+            # (top nodes with large fronts -- the 3D cases -- are distributed over the ranks, for the adjoint problem too: the
+            #  transposed sweeps sum a distributed node's partial results of all ranks in rank order)
+            forest = sharding.partition_forest(ex["perm"], ex["node_start"], ex["parent"], ex["front_size"], world)
             perm, part = forest.order, forest.rows
             dA = lsa_hip.CsrMatrix.from_scipy(ctx, sharding.pad_square(_permute(A, perm), part))
             dM = None if M is None else lsa_hip.CsrMatrix.from_scipy(ctx, sharding.pad_square(_permute(M, perm), part))

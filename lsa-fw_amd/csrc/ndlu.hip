@@ -1350,31 +1350,34 @@ __device__ __forceinline__ MT maybe_conj(MT a) {
 template <typename MT, typename VT, bool CONJ, bool DOWN>
 __global__ __launch_bounds__(256) void nd_sweepT_kernel(const NdSweepNode* __restrict__ lnodes, const MT* __restrict__ lfac, const MT* __restrict__ ufac,
                                                         const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
-                                                        const VT* __restrict__ rhs, VT* __restrict__ x, VT* __restrict__ ubuf) {
+                                                        const VT* __restrict__ rhs, VT* __restrict__ x, VT* __restrict__ ubuf,
+                                                        const int64_t* __restrict__ tgoff, VT* __restrict__ pz, int64_t tg_slot, int32_t rank) {
     __shared__ VT vs[kCH];
     __shared__ VT part[4][64];
     const NdSweepNode nd = lnodes[blockIdx.x];
     const int32_t m = nd.m, f = nd.f, b = f - m;
-    const int32_t ncols = DOWN ? m : f;       // outputs of this sweep
-    const int32_t K = DOWN ? b : m;           // rows summed over
+    const bool dist = (nd.flags & 1) != 0;  // a distributed node: this rank's rows only, the sums go to its slot of the partial buffer
+    const int32_t ncols = DOWN ? m : f;                         // outputs of this sweep
+    const int32_t klo = DOWN ? nd.brow0 : nd.orow0;             // rows summed over: this rank's (all of them unless the node is distributed)
+    const int32_t K = DOWN ? nd.brow : nd.orows;
     const int32_t c0 = (int32_t)blockIdx.y * 64;
     if (c0 >= ncols || (DOWN && b == 0)) return;
     const int32_t* ix = idx + nd.idx_off;
     const int32_t* ge = gell + nd.ge_off;
     const int tid = threadIdx.x, lane = tid & 63, sl = tid >> 6;
     const int32_t col = min(c0 + lane, ncols - 1);
-    // this lane's column: base pointer and row stride inside the packed blocks
+    // this lane's column: base pointer and row stride inside the packed blocks (rows = the rank's rows, local numbering)
     const MT* Fc;
     int32_t ld;
-    if (DOWN) Fc = lfac + nd.lfac_off + (size_t)m * m + col, ld = m;
+    if (DOWN) Fc = lfac + nd.lfac_off + (size_t)nd.orows * m + col, ld = m;
     else if (col < m) Fc = lfac + nd.lfac_off + col, ld = m;
     else Fc = ufac + nd.ufac_off + (col - m), ld = b;
     VT acc = scalar_traits<VT>::zero();
     for (int32_t k0 = 0; k0 < K; k0 += kCH) {
         const int32_t kn = min(kCH, K - k0);
         for (int32_t j = tid; j < kn; j += 256) {
-            if (DOWN) vs[j] = x[ix[m + k0 + j]];
-            else vs[j] = gather_updates(ge, nd.nchild, f, k0 + j, ubuf, rhs[ix[k0 + j]]);
+            if (DOWN) vs[j] = x[ix[m + klo + k0 + j]];
+            else vs[j] = gather_updates(ge, nd.nchild, f, klo + k0 + j, ubuf, rhs[ix[klo + k0 + j]]);
         }
         __syncthreads();
         const MT* Fk = Fc + (size_t)k0 * ld;
@@ -1394,9 +1397,39 @@ __global__ __launch_bounds__(256) void nd_sweepT_kernel(const NdSweepNode* __res
     if (sl == 0 && c0 + lane < ncols) {
         const VT z = s_add(s_add(part[0][lane], part[1][lane]), s_add(part[2][lane], part[3][lane]));
         const int32_t r = c0 + lane;
-        if (DOWN) x[ix[r]] = s_add(x[ix[r]], z);
+        if (dist) pz[(int64_t)rank * tg_slot + tgoff[blockIdx.x] + r] = z;  // summed over the ranks by nd_distT_finish_kernel
+        else if (DOWN) x[ix[r]] = s_add(x[ix[r]], z);
         else if (r < m) x[ix[r]] = z;
         else ubuf[nd.u_off + (r - m)] = s_sub(gather_updates(ge, nd.nchild, f, r, ubuf, scalar_traits<VT>::zero()), z);
+    }
+}
+
+// The distributed nodes of a level after the exchange of their partial sums: z = the ranks' partials added in rank order (the same
+// bits on every rank), then what nd_sweepT_kernel does for an ordinary node.  Upwards the node's update vector is written in the
+// layout its parent's gather rows expect: entry j in the slot of the rank that owns boundary row j in the forward sweeps.
+template <typename VT, bool DOWN>
+__global__ __launch_bounds__(256) void nd_distT_finish_kernel(const NdSweepNode* __restrict__ lnodes, const int64_t* __restrict__ tgoff,
+                                                              const int32_t* __restrict__ idx, const int32_t* __restrict__ gell,
+                                                              const VT* __restrict__ pz, int64_t tg_slot, int32_t nranks, int32_t rank, int64_t ux_slot,
+                                                              VT* __restrict__ x, VT* __restrict__ ubuf) {
+    const NdSweepNode nd = lnodes[blockIdx.x];
+    if (!(nd.flags & 1)) return;
+    const int32_t m = nd.m, f = nd.f, b = f - m;
+    const int32_t ncols = DOWN ? m : f;
+    const int32_t r = (int32_t)blockIdx.y * 256 + threadIdx.x;
+    if (r >= ncols || (DOWN && b == 0)) return;
+    const int64_t off = tgoff[blockIdx.x] + r;
+    VT z = scalar_traits<VT>::zero();
+    for (int32_t p = 0; p < nranks; ++p) z = s_add(z, pz[(int64_t)p * tg_slot + off]);
+    const int32_t* ix = idx + nd.idx_off;
+    if (DOWN) {
+        x[ix[r]] = s_add(x[ix[r]], z);
+    } else if (r < m) {
+        x[ix[r]] = z;
+    } else {
+        const int32_t j = r - m, w = (b + nranks - 1) / nranks, owner = j / w;
+        const VT u = s_sub(gather_updates(gell + nd.ge_off, nd.nchild, f, r, ubuf, scalar_traits<VT>::zero()), z);
+        ubuf[nd.u_off + (int64_t)(owner - rank) * ux_slot + (j - owner * w)] = u;
     }
 }
 
@@ -1413,6 +1446,12 @@ struct lsa_ndlu {
     NdSweepNode *d_lnodes = nullptr, *d_lnodes_bwd = nullptr;  // in lvl_nodes order: the sweeps' records (downwards a distributed node appears as its slice of own rows)
     int32_t *d_dist_nodes = nullptr, *d_child_ptr = nullptr, *d_child_idx = nullptr;  // distributed nodes by level; children of every node
     void *d_xstage = nullptr, *d_xg = nullptr;          // staging of update rows on their way to distributed parents; own-row exchange buffer of the sweeps
+    // transposed sweeps with distributed nodes (built by the first adjoint solve): per sweep record its offset in a rank's slot of the
+    // partial-sum buffer (-1: not distributed), the buffer (nranks slots of tg_slot_max vector scalars), the slot size of every level
+    int64_t* d_tgoff = nullptr;
+    void* d_tg = nullptr;
+    std::vector<int64_t> tg_slot;
+    int64_t tg_slot_max = 0;
     int64_t xstage_slot = 0;                            // scalars per rank of d_xstage
     std::vector<int64_t> h_upd_off, h_lfac_off;         // per node: its update matrix in the update arena, its packed L (host copies of the plan)
     int64_t chunk_node_upd_off(int32_t t) const { return h_upd_off[(size_t)t]; }
@@ -1446,7 +1485,7 @@ namespace {
 
 void nd_free(lsa_ndlu* f) {
     if (!f) return;
-    for (void* p : {(void*)f->d_lnodes_bwd, (void*)f->d_dist_nodes, (void*)f->d_child_ptr, (void*)f->d_child_idx, f->d_xstage, f->d_xg})
+    for (void* p : {(void*)f->d_lnodes_bwd, (void*)f->d_dist_nodes, (void*)f->d_child_ptr, (void*)f->d_child_idx, f->d_xstage, f->d_xg, (void*)f->d_tgoff, f->d_tg})
         if (p) (void)hipFree(p);
     for (void* p : {(void*)f->d_nodes, (void*)f->d_lnodes, (void*)f->d_gell, (void*)f->d_idx, (void*)f->d_cmap, (void*)f->d_tiles,
                     (void*)f->d_chunk_nodes, (void*)f->d_asm_dst, (void*)f->d_asm_src, (void*)f->d_ipiv, (void*)f->d_rowq, (void*)f->d_flag, (void*)f->d_xflag, (void*)f->d_maxabs,
@@ -2183,25 +2222,65 @@ int nd_apply(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
 }  // namespace
 
 namespace {
+// the partial-sum buffer of the transposed sweeps over distributed nodes, built by the first adjoint solve: a level's slot holds
+// the f outputs of each of its distributed nodes (the downward sweep's m fit the same places)
+int nd_ensure_transposed_dist(lsa_ctx* ctx, lsa_ndlu* f) {
+    const NdSymbolic& S = f->S;
+    if (!S.has_dist || f->d_tgoff) return LSA_OK;
+    std::vector<int64_t> off(S.lvl_nodes.size(), -1);
+    f->tg_slot.assign(f->levels.size(), 0);
+    f->tg_slot_max = 0;
+    for (size_t l = 0; l < f->levels.size(); ++l) {
+        const NdLevel& L = f->levels[l];
+        int64_t run = 0;
+        for (int32_t q = 0; q < L.node_count; ++q) {
+            const int32_t t = S.lvl_nodes[(size_t)L.node_begin + q];
+            if (S.kind[(size_t)t] != 4) continue;
+            off[(size_t)L.node_begin + q] = run;
+            run += S.f[(size_t)t];
+        }
+        f->tg_slot[l] = run;
+        f->tg_slot_max = std::max(f->tg_slot_max, run);
+    }
+    LSA_HIP_ALLOC(ctx, hipMalloc(&f->d_tg, (size_t)std::max<int64_t>(f->tg_slot_max, 1) * (size_t)S.nranks * 16));
+    LSA_CHECK(upload(ctx, off, &f->d_tgoff));
+    return LSA_OK;
+}
+
 template <typename MT, typename VT, bool CONJ>
 int nd_apply_T(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
     hipStream_t st = ctx->stream;
     const MT* lfac = (const MT*)f->d_lfac;
     const MT* ufac = (const MT*)f->d_ufac;
     const NdSymbolic& S = f->S;
+    LSA_CHECK(nd_ensure_transposed_dist(ctx, f));
+    VT* pz = (VT*)f->d_tg;
     for (size_t li = 0; li <= f->levels.size(); ++li) {
         if ((int32_t)li == S.phase_b_level && S.nranks > 1 && S.xu_slot > 0) LSA_CHECK(k_allgather_inplace(ctx, f->d_ubuf, (size_t)S.xu_slot * sizeof(VT)));
         if (li == f->levels.size()) break;
         const NdLevel& L = f->levels[li];
+        const int64_t slot = L.dist_count > 0 ? f->tg_slot[li] : 0;
         if (L.fwd_tiles > 0)
             hipLaunchKernelGGL((nd_sweepT_kernel<MT, VT, CONJ, false>), dim3(L.node_count, (L.max_f + 63) / 64), dim3(256), 0, st, f->d_lnodes + L.node_begin,
-                               lfac, ufac, f->d_idx, f->d_gell, b, x, (VT*)f->d_ubuf);
+                               lfac, ufac, f->d_idx, f->d_gell, b, x, (VT*)f->d_ubuf, f->d_tgoff ? f->d_tgoff + L.node_begin : nullptr, pz, slot, S.rank);
+        if (L.dist_count > 0) {
+            // the distributed nodes of the level: every rank summed over its rows; partials to all, added in rank order
+            LSA_CHECK(k_allgather_inplace(ctx, pz, (size_t)slot * sizeof(VT)));
+            hipLaunchKernelGGL((nd_distT_finish_kernel<VT, false>), dim3(L.node_count, (L.max_f + 255) / 256), dim3(256), 0, st, f->d_lnodes + L.node_begin,
+                               f->d_tgoff + L.node_begin, f->d_idx, f->d_gell, (const VT*)pz, slot, S.nranks, S.rank, L.ux_slot, x, (VT*)f->d_ubuf);
+        }
     }
     for (size_t l = f->levels.size(); l-- > 0;) {
         const NdLevel& L = f->levels[l];
-        if (L.bwd_tiles > 0)
+        const int64_t slot = L.dist_count > 0 ? f->tg_slot[l] : 0;
+        if (L.bwd_tiles > 0 || L.dist_count > 0)
             hipLaunchKernelGGL((nd_sweepT_kernel<MT, VT, CONJ, true>), dim3(L.node_count, (L.max_m + 63) / 64), dim3(256), 0, st, f->d_lnodes + L.node_begin,
-                               lfac, ufac, f->d_idx, f->d_gell, b, x, (VT*)f->d_ubuf);
+                               lfac, ufac, f->d_idx, f->d_gell, b, x, (VT*)f->d_ubuf, f->d_tgoff ? f->d_tgoff + L.node_begin : nullptr, pz, slot, S.rank);
+        if (L.dist_count > 0) {
+            LSA_CHECK(k_allgather_inplace(ctx, pz, (size_t)slot * sizeof(VT)));
+            hipLaunchKernelGGL((nd_distT_finish_kernel<VT, true>), dim3(L.node_count, (L.max_m + 255) / 256), dim3(256), 0, st, f->d_lnodes + L.node_begin,
+                               f->d_tgoff + L.node_begin, f->d_idx, f->d_gell, (const VT*)pz, slot, S.nranks, S.rank, L.ux_slot, x, (VT*)f->d_ubuf);
+        }
     }
     LSA_HIP_CHECK(ctx, hipGetLastError());
     return LSA_OK;
@@ -2211,9 +2290,6 @@ int nd_apply_T(lsa_ctx* ctx, lsa_ndlu* f, const VT* b, VT* x) {
 // x = C^-T b (conj == 0) or C^-H b (conj != 0) on the factors of C
 int ndlu_solve_adjoint_dev(lsa_ctx* ctx, lsa_ndlu* f, int conj, int vdtype, const void* b, void* x) {
     if (f->dtype == LSA_C128 && vdtype != LSA_C128) return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve_adjoint: complex factors need complex vectors");
-    if (f->S.has_dist)
-        return lsa_set_error(ctx, LSA_ERR_ARG, "lsa_ndlu_solve_adjoint: the transposed sweeps are not available for a forest with distributed top nodes "
-                                               "(cut it with replicated top nodes: LSA_ND_DIST_MIN=0)");
     if (f->S.n == 0) return LSA_OK;
     if (b == x) {
         LSA_HIP_CHECK(ctx, hipMemcpyAsync(f->d_tmp, b, (size_t)f->S.n * esize(vdtype), hipMemcpyDeviceToDevice, ctx->stream));

@@ -218,12 +218,15 @@ def helpers_match(found, ref):
     return np.array([np.min(np.abs(found - r)) / abs(r) for r in ref])
 
 
-def _rank_adjoint(rank: int, world: int, port: int, out_dir: str) -> None:
+def _rank_adjoint(rank: int, world: int, port: int, out_dir: str, case: str = "S2k", env: str = "") -> None:
     import os
     import sys
     from pathlib import Path
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    for item in filter(None, env.split(",")):
+        key, _, val = item.partition("=")
+        os.environ[key] = val
     root = Path(__file__).resolve().parents[1]
     sys.path[:0] = [str(root), str(root / "lsa-fw_amd"), str(root / "tests")]
     import torch.distributed as dist
@@ -233,14 +236,16 @@ def _rank_adjoint(rank: int, world: int, port: int, out_dir: str) -> None:
     from Solver.utils import PreconditionerType, iSTType
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    es = fem.cylinder_case("S2k")
+    cube = case.startswith("C")
+    es = fem.cube_case(case) if cube else fem.cylinder_case(case)
     solver = EigenSolver(es.A, es.M, EigensolverConfig(num_eig=4, atol=1e-10, ncv=40), check_hermitian=False, layout="sharded", adjoint=True)
     solver.solver.set_st_type(iSTType.SINVERT)
-    solver.solver.set_target(np.conj(fem.SIGMA_RE50))
+    solver.solver.set_target(np.conj(-5.0 + 0.5j if cube else fem.SIGMA_RE50))
     solver.solver.set_st_pc_type(PreconditionerType.LU)
     pairs = solver.solve()
+    forest = solver.solver._prepared["forest"]
     np.savez(Path(out_dir) / f"adj{rank}.npz", lam=np.array([p[0] for p in pairs[:4]]), V=np.column_stack([p[1].as_array() for p in pairs[:4]]),
-             res=solver.solver.residuals()[:4], gmres=solver.solver.stats["gmres_iters"])
+             res=solver.solver.residuals()[:4], gmres=solver.solver.stats["gmres_iters"], ndist=int((forest.owner == -2).sum()))
     solver.solver.release()
     dist.barrier()
     dist.destroy_process_group()
@@ -267,6 +272,38 @@ def test_sharded_adjoint_solve(tmp_path, world):
         assert np.array_equal(o["lam"], out[0]["lam"]) and np.array_equal(o["V"], out[0]["V"])
     es = fem.cylinder_case("S2k")
     ref, _, _ = shift_invert.solve(es.A, es.M, fem.SIGMA_RE50, k=4, tol=1e-13)
+    for r in ref:
+        assert np.min(np.abs(out[0]["lam"] - np.conj(r))) <= 1e-8 * abs(r)
+    AH, MH = es.A.conj().T.tocsr(), es.M.conj().T.tocsr()
+    assert shift_invert.compute_residuals(AH, MH, out[0]["lam"], out[0]["V"]).max() <= 1e-8
+    assert out[0]["res"].max() <= 1e-8 and int(out[0]["gmres"]) == 0
+
+
+@pytest.mark.parametrize("world,case,env", [(2, "S2k", "LSA_ND_DIST_MIN=1"), (3, "C9k", "LSA_ND_DIST_MIN=600"), (4, "C9k", "LSA_ND_DIST_MIN=1")])
+def test_sharded_adjoint_solve_with_distributed_top_fronts(tmp_path, world, case, env):
+    """The adjoint eigenproblem with the top fronts of the forest distributed over the ranks (round 4, second half): a distributed
+    node's transposed sweeps sum over the rows a rank holds, the partial results are exchanged and added in rank order
+    (``nd_sweepT_kernel`` with row ranges, ``nd_distT_finish_kernel``).  Eigenvalues = the conjugates of the direct problem's,
+    vectors = eigenvectors of (A^H, M^H) to 1e-8, no inner iteration, ranks bit-identical."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from oracle import shift_invert
+    from synthetic import fem
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_rank_adjoint, args=(world, port, str(tmp_path), case, env), nprocs=world, join=True)
+    out = [np.load(tmp_path / f"adj{r}.npz") for r in range(world)]
+    assert int(out[0]["ndist"]) > 0  # the forest has distributed nodes
+    for o in out[1:]:
+        assert np.array_equal(o["lam"], out[0]["lam"]) and np.array_equal(o["V"], out[0]["V"])
+    cube = case.startswith("C")
+    es = fem.cube_case(case) if cube else fem.cylinder_case(case)
+    sigma = -5.0 + 0.5j if cube else fem.SIGMA_RE50
+    ref, _, _ = shift_invert.solve(es.A, es.M, sigma, k=4, tol=1e-13)
     for r in ref:
         assert np.min(np.abs(out[0]["lam"] - np.conj(r))) <= 1e-8 * abs(r)
     AH, MH = es.A.conj().T.tocsr(), es.M.conj().T.tocsr()

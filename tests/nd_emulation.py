@@ -424,3 +424,109 @@ class EmulatedDistributedTop:
             ok = ~np.isnan(xs[r])
             x[ok] = xs[r][ok]
         return x
+
+
+    def solve_transposed(self, rhs: np.ndarray, conj: bool = False) -> np.ndarray:
+        """``C^T x = rhs`` (``C^H`` with ``conj``) on the same factors, with the data flow of ``nd_apply_T``: the fronts of the
+        transposed forest are the transposed fronts, so an output of a node sums over ROWS of its packed blocks -- for a
+        distributed node every rank sums over the rows it holds, the partial results are added in rank order
+        (``nd_sweepT_kernel`` with row ranges, ``nd_distT_finish_kernel``); a distributed node's update vector is written, whole,
+        into the slots of the level's exchange region on every rank."""
+        P = self.P
+        cj = (lambda a: np.conj(a)) if conj else (lambda a: a)
+        dt = np.result_type(rhs.dtype, self.r[0]["front"].dtype)
+        xs = [np.full(rhs.shape, np.nan, dtype=dt) for _ in range(P)]
+        us = [np.zeros(int(d["u_entries"]), dtype=dt) for d in self.r]
+        uslot = self.r[0]["u_slot"]
+
+        def gather(d, ub, q):
+            f = int(d["f"][q])
+            gp = d["gptr"][d["g_off"][q]:d["g_off"][q + 1]]
+            return np.array([ub[d["gidx"][gp[j]:gp[j + 1]]].sum() for j in range(f)])
+
+        def up_plain(d, x, ub, q):
+            m, f = int(d["m"][q]), int(d["f"][q])
+            ix = d["idx"][d["idx_off"][q]:d["idx_off"][q + 1]]
+            gath = gather(d, ub, q)
+            z = cj(self._F(d, q)[:m, :]).T @ (rhs[ix[:m]] + gath[:m])  # [inv | U]^T v
+            x[ix[:m]] = z[:m]
+            ub[d["u_off"][q]:d["u_off"][q] + f - m] = gath[m:] - z[m:]
+
+        def down_plain(d, x, q):
+            m = int(d["m"][q])
+            if d["b"][q] == 0:
+                return
+            ix = d["idx"][d["idx_off"][q]:d["idx_off"][q + 1]]
+            x[ix[:m]] += cj(self._F(d, q)[m:, :m]).T @ x[ix[m:]]  # L^T x_boundary
+
+        for r, d in enumerate(self.r):
+            for lv in range(d["phase_b_level"]):
+                for q in d["lvl_nodes"][d["lvl_ptr"][lv]:d["lvl_ptr"][lv + 1]]:
+                    up_plain(d, xs[r], us[r], int(q))
+        for src in range(P):
+            for dst in range(P):
+                if dst != src:
+                    us[dst][src * uslot:(src + 1) * uslot] = us[src][src * uslot:(src + 1) * uslot]
+        d0 = self.r[0]
+        nl = len(d0["lvl_ptr"]) - 1
+        top_levels = [[[int(q) for q in d["lvl_nodes"][d["lvl_ptr"][d["phase_b_level"] + off]:d["lvl_ptr"][d["phase_b_level"] + off + 1]]] for d in self.r]
+                      for off in range(nl - d0["phase_b_level"])]
+        for lists in top_levels:
+            for pos in range(len(lists[0])):
+                if int(d0["kind"][lists[0][pos]]) == 2:
+                    for r, d in enumerate(self.r):
+                        up_plain(d, xs[r], us[r], lists[r][pos])
+                    continue
+                partial = []
+                for r, d in enumerate(self.r):  # every rank: the rows it holds of [inv | U]
+                    q = lists[r][pos]
+                    m = int(d["m"][q])
+                    ix = d["idx"][d["idx_off"][q]:d["idx_off"][q + 1]]
+                    inv, _, Ur = d["fac"][q]
+                    o0, on = int(d["orow0"][q]), int(d["orows"][q])
+                    v = (rhs[ix[:m]] + gather(d, us[r], q)[:m])[o0:o0 + on]
+                    partial.append(np.concatenate([cj(inv[o0:o0 + on]).T @ v, cj(Ur).T @ v if d["b"][q] > 0 else np.zeros(0, dtype=dt)]))
+                z = partial[0].copy()
+                for pz in partial[1:]:  # rank order
+                    z = z + pz
+                for r, d in enumerate(self.r):
+                    q = lists[r][pos]
+                    m, b = int(d["m"][q]), int(d["b"][q])
+                    ix = d["idx"][d["idx_off"][q]:d["idx_off"][q + 1]]
+                    xs[r][ix[:m]] = z[:m]
+                    if b == 0:
+                        continue
+                    u = gather(d, us[r], q)[m:] - z[m:]
+                    w = -(-b // P)
+                    for j in range(b):  # entry j in the slot of the rank that owns boundary row j in the forward sweeps
+                        us[r][int(d["ux_base"][q]) + (j // w) * int(d["ux_stride"][q]) + j % w] = u[j]
+        for lists in reversed(top_levels):
+            for pos in range(len(lists[0])):
+                if int(d0["kind"][lists[0][pos]]) == 2:
+                    for r, d in enumerate(self.r):
+                        down_plain(d, xs[r], lists[r][pos])
+                    continue
+                partial = []
+                for r, d in enumerate(self.r):  # every rank: the boundary rows it holds of L
+                    q = lists[r][pos]
+                    m = int(d["m"][q])
+                    ix = d["idx"][d["idx_off"][q]:d["idx_off"][q + 1]]
+                    lo, cnt = int(d["brow0"][q]), int(d["brow"][q])
+                    partial.append(cj(d["fac"][q][1]).T @ xs[r][ix[m + lo:m + lo + cnt]] if cnt > 0 else np.zeros(m, dtype=dt))
+                z = partial[0].copy()
+                for pz in partial[1:]:
+                    z = z + pz
+                for r, d in enumerate(self.r):
+                    q = lists[r][pos]
+                    m = int(d["m"][q])
+                    ix = d["idx"][d["idx_off"][q]:d["idx_off"][q + 1]]
+                    xs[r][ix[:m]] = xs[r][ix[:m]] + z
+        for r, d in enumerate(self.r):
+            for lv in range(d["phase_b_level"] - 1, -1, -1):
+                for q in d["lvl_nodes"][d["lvl_ptr"][lv]:d["lvl_ptr"][lv + 1]]:
+                    down_plain(d, xs[r], int(q))
+        x = np.full(rhs.shape, np.nan, dtype=dt)
+        for r in range(P):
+            ok = ~np.isnan(xs[r])
+            x[ok] = xs[r][ok]
+        return x

@@ -265,3 +265,7 @@ def test_distributed_top_nodes_are_still_a_direct_solve(case, nranks, dist_min):
     x = fp.rows.unpad_vector(xp)
     assert np.linalg.norm(Cp @ x - b) <= 1e-11 * np.linalg.norm(b)
     assert top.sum() > 0
+    # the transposed systems on the same factors (the adjoint eigenproblem): partial sums over a rank's rows, added in rank order
+    for conj, Ct in ((False, Cp.T.tocsr()), (True, Cp.conj().T.tocsr())):
+        y = fp.rows.unpad_vector(em.solve_transposed(fp.rows.pad_vector(b), conj=conj))
+        assert np.linalg.norm(Ct @ y - b) <= 1e-11 * np.linalg.norm(b), conj

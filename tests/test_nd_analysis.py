@@ -269,3 +269,47 @@ def test_distributed_top_nodes_are_still_a_direct_solve(case, nranks, dist_min):
     for conj, Ct in ((False, Cp.T.tocsr()), (True, Cp.conj().T.tocsr())):
         y = fp.rows.unpad_vector(em.solve_transposed(fp.rows.pad_vector(b), conj=conj))
         assert np.linalg.norm(Ct @ y - b) <= 1e-11 * np.linalg.norm(b), conj
+
+
+@pytest.mark.parametrize("case,nranks", [("C2k", 4), ("S5k", 8)])
+def test_huge_subtree_roots_join_the_distributed_top(monkeypatch, case, nranks):
+    """``LSA_ND_DIST_SPLIT``: a subtree root whose front reaches the split size does not stay with ONE rank whatever the load
+    balance says (at 5 M unknowns in 3D a 66 k-row root front is 35 GB plus a 51 GB update matrix): it moves into the top, its
+    children become subtree roots.  With the split forced below the fronts of the natural subtree roots: every remaining
+    subtree root is smaller than the split or a leaf, the top is closed upwards, every rank still owns rows, and the tables of
+    the deeper top are still a direct solve (forward and transposed)."""
+    from nd_emulation import EmulatedDistributedTop
+
+    es = fem.cube_case(case) if case.startswith("C") else fem.cylinder_case(case)
+    C = _shifted(es, fem.SIGMA_CUBE if case.startswith("C") else fem.SIGMA_RE50)
+    flags = (C.diagonal() == 0) if case.startswith("C") else None
+    ex = lsa_hip.NdAnalysis(C, 64, constraint=flags).export()
+    par = ex["parent"]
+    monkeypatch.setenv("LSA_ND_DIST_SPLIT", "0")  # the cut the load balance alone gives
+    base = sharding.partition_forest(ex["perm"], ex["node_start"], par, ex["front_size"], nranks, dist_min=1)
+    roots = [t for t in range(len(base.parent)) if base.owner[t] >= 0 and (base.parent[t] < 0 or base.owner[base.parent[t]] < 0)]
+    assert len(roots) >= nranks
+    # the largest split size that moves a subtree root of that cut into the top
+    front_new = None
+    for split in sorted(set(int(v) for v in ex["front_size"]), reverse=True):
+        monkeypatch.setenv("LSA_ND_DIST_SPLIT", str(split))
+        fp = sharding.partition_forest(ex["perm"], ex["node_start"], par, ex["front_size"], nranks, dist_min=1)
+        if np.count_nonzero(fp.owner < 0) > np.count_nonzero(base.owner < 0):
+            front_new = split
+            break
+    assert front_new is not None  # some split size moves at least one subtree root into the top
+    top = fp.owner < 0
+    assert all(fp.owner[fp.parent[t]] < 0 for t in np.flatnonzero(top) if fp.parent[t] >= 0)  # closed upwards
+    assert all(np.count_nonzero(fp.owner == r) > 0 for r in range(nranks))
+    Cp = C[fp.order][:, fp.order].tocsr()
+    Cp.sort_indices()
+    Cpad = sharding.pad_square(Cp, fp.rows)
+    tree = {"first": fp.first, "size": fp.size, "parent": fp.parent, "owner": fp.owner}
+    tabs = [lsa_hip.NdAnalysis(Cpad, tree=tree, rank=r, nranks=nranks).export_tables() for r in range(nranks)]
+    em = EmulatedDistributedTop(tabs, Cpad.data)
+    rng = np.random.default_rng(11)
+    b = rng.standard_normal(es.n) + 1j * rng.standard_normal(es.n)
+    x = fp.rows.unpad_vector(em.solve(fp.rows.pad_vector(b)))
+    assert np.linalg.norm(Cp @ x - b) <= 1e-11 * np.linalg.norm(b)
+    y = fp.rows.unpad_vector(em.solve_transposed(fp.rows.pad_vector(b)))
+    assert np.linalg.norm(Cp.T @ y - b) <= 1e-11 * np.linalg.norm(b)
